@@ -1,0 +1,169 @@
+/*
+ * pww_hip.h -- C ABI of libpww_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the
+ * Paint-with-Words attention hot path.
+ *
+ * The reference (cloneofsimo/paint-with-words-sd) has no native code and therefore no FFI; the
+ * entry points below are what a binding for its hot path would call. Each one names the reference
+ * lines it replaces (paths relative to the reference repo root):
+ *
+ *   pww_self_attn_fwd    paint_with_words/paint_with_words.py:83-118 with context=None
+ *                        (head split, QK^T, +0.0, *scale, softmax, PV, head merge)
+ *   pww_cross_attn_fwd   paint_with_words/paint_with_words.py:83-118 with a context dict
+ *                        (same, plus the `+ cross_attention_weight` term of :112)
+ *   pww_qk_reduce        the global reductions weight_function applies to `qk`
+ *                        (paint_with_words.py:402-405 qk.max(); README.md:152 qk.std())
+ *   pww_mask_build       paint_with_words/paint_with_words.py:207-276
+ *                        (_image_context_seperator + _tokens_img_attention_weight +
+ *                         _img_importance_flatten for ratios 8/16/32/64)
+ *   pww_cfg_combine      paint_with_words/paint_with_words.py:501-503 (classifier-free guidance)
+ *
+ * Conventions
+ *   - All tensor arguments are DEVICE pointers owned by the caller. The library never allocates,
+ *     frees or retains device memory and keeps no global state except a thread-local error string.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream). Every function only
+ *     enqueues work on that stream and returns; none synchronises, so all of them are legal
+ *     inside hipGraph stream capture.
+ *   - Return value: 0 on success, a negative errno-style code on failure
+ *     (PWW_EINVAL bad shape/stride/alignment, PWW_ENOTSUP unsupported head-dim/dtype/arch,
+ *     PWW_EHIP a HIP runtime error). pww_last_error() describes the last failure on the calling
+ *     thread. No C++ exception crosses this boundary.
+ *   - Strides are in ELEMENTS of the tensor's dtype. The innermost (head-dim / key) stride is 1.
+ */
+#ifndef PWW_HIP_H
+#define PWW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PWW_VERSION 100 /* 0.1.0 */
+
+#define PWW_OK 0
+#define PWW_EINVAL (-22)
+#define PWW_ENOTSUP (-95)
+#define PWW_EHIP (-5)
+
+/* 2-byte storage types of Q/K/V/O. Accumulation and softmax are always fp32. */
+#define PWW_DTYPE_F16 0
+#define PWW_DTYPE_BF16 1
+
+/* Largest supported head dim (SD1.x uses 40/80/160, SD2.x 64). D must be a multiple of 8. */
+#define PWW_MAX_HEAD_DIM 160
+
+/*
+ * Shape/stride descriptor of one attention call. Tensors are addressed as
+ *   Q[b][h][n][d] = q + b*q_stride[0] + h*q_stride[1] + n*q_stride[2] + d      (n < N, d < D)
+ *   K[b][h][m][d], V[b][h][m][d]   likewise with m < M
+ *   O[b][h][n][d]                  likewise
+ * so the diffusers layout [B, tokens, H*D] is read/written in place (stride {tokens*H*D, D, H*D}):
+ * reshape_heads_to_batch_dim / reshape_batch_dim_to_heads (paint_with_words.py:83-85,:118) never
+ * materialise. Base pointers and all strides must keep every row 16-byte aligned
+ * (pointer % 16 == 0, stride % 8 == 0).
+ */
+typedef struct pww_attn_desc {
+    int32_t dtype;        /* PWW_DTYPE_* */
+    int32_t B, H, N, M, D;
+    int64_t q_stride[3];  /* b, h, n */
+    int64_t k_stride[3];  /* b, h, m */
+    int64_t v_stride[3];  /* b, h, m */
+    int64_t o_stride[3];  /* b, h, n */
+    float scale;          /* CrossAttention.scale = D^-0.5, applied AFTER the bias add (:112) */
+    /* bias[b][h][n][m] = bias + b*bs[0] + h*bs[1] + n*bs[2] + m*bs[3]  (fp32 elements; a stride
+       of 0 broadcasts that axis). Ignored when the bias pointer is NULL. */
+    int64_t bias_stride[4];
+} pww_attn_desc_t;
+
+/* ABI version (PWW_VERSION of the built library). */
+int pww_version(void);
+
+/* Description of the last error on this thread ("" if none). */
+const char *pww_last_error(void);
+
+/* Name of the HIP device the library would launch on, e.g. "gfx950". Writes at most n bytes. */
+int pww_device_arch(char *buf, size_t n);
+
+/*
+ * O = softmax((Q K^T) * scale) V, flash-style (no [N,M] score tensor in HBM).
+ * Replaces paint_with_words.py:83-118 for context=None (attn1) and for the unconditional pass
+ * (`WEIGHT_FUNCTION = lambda ...: 0.0`, :491-494).
+ */
+int pww_self_attn_fwd(const void *q, const void *k, const void *v, void *o,
+                      const pww_attn_desc_t *desc, void *stream);
+
+/*
+ * O = softmax((Q K^T + c[b] * bias) * scale) V.
+ *   bias        fp32, addressed through desc->bias_stride; NULL = no bias.
+ *   bias_coeff  fp32 [B] device array of per-image coefficients c[b] (NULL = 1.0). Lets the host
+ *               pass the constant `w` map (paint_with_words.py:94) plus a device scalar such as
+ *               0.4*log(1+sigma)*qk.max() without materialising their product.
+ * The bias is added to the RAW scores before the 1/sqrt(D) scaling, exactly as :112 does.
+ */
+int pww_cross_attn_fwd(const void *q, const void *k, const void *v, void *o,
+                       const float *bias, const float *bias_coeff,
+                       const pww_attn_desc_t *desc, void *stream);
+
+/*
+ * Per-image global statistics of the raw score tensor S = Q K^T over all heads, rows and keys
+ * (what weight_function reduces: qk.max(), qk.min(), qk.mean(), qk.std()).
+ *   stats  double [B][4] = { max, min, sum, sum of squares } per image b.
+ * The function first enqueues the initialisation of `stats`, then the reduction kernel.
+ * Only q/k strides, B/H/N/M/D and dtype of the descriptor are read.
+ */
+int pww_qk_reduce(const void *q, const void *k, const pww_attn_desc_t *desc,
+                  double *stats, void *stream);
+
+/*
+ * Region table entry for pww_mask_build: one (color -> strength) pair of color_context
+ * (paint_with_words.py:218-238).
+ */
+typedef struct pww_region {
+    uint8_t r, g, b, _pad;
+    float strength;
+} pww_region_t;
+
+/*
+ * RGB color map -> the four per-resolution token weight maps of paint_with_words.py:346-357.
+ *   rgb       uint8 [H][W][3] device image
+ *   regions   device array [R]
+ *   col_ptr   int32 [T+1] device, CSR over the T prompt positions (T = 77)
+ *   col_reg   int32 [col_ptr[T]] device: for column t the region ordinals whose phrase covers
+ *             prompt position t, in the reference's accumulation order (:257-268)
+ *   out[i]    fp32 [round(H/r_i) * round(W/r_i)][T] device, r = {8,16,32,64}; any may be NULL
+ * Each output element is the sum, in list order, of the bilinear(align_corners=True) downsample
+ * of `strength * (pixel == color)` (:38-45, :231-236). Every element is written (zeros included).
+ */
+int pww_mask_build(const uint8_t *rgb, int32_t H, int32_t W,
+                   const pww_region_t *regions, int32_t R,
+                   const int32_t *col_ptr, const int32_t *col_reg, int32_t T,
+                   float *out8, float *out16, float *out32, float *out64, void *stream);
+
+/* One output of pww_mask_build at an arbitrary integer `ratio` (ratio 1 gives the reference's
+   CROSS_ATTENTION_WEIGHT_ORIG map of paint_with_words.py:343-345, shape [H*W][T]). */
+int pww_mask_build_rgb(const uint8_t *rgb, int32_t H, int32_t W,
+                       const pww_region_t *regions, int32_t R,
+                       const int32_t *col_ptr, const int32_t *col_reg, int32_t T,
+                       int32_t ratio, float *out, void *stream);
+
+/* Same accumulation from R float32 masks [R][H][W] (already strength-scaled and optionally
+   blurred, paint_with_words.py:236,:307-312) instead of an RGB image; `ratio` selects one output. */
+int pww_mask_build_f32(const float *masks, int32_t H, int32_t W, int32_t R,
+                       const int32_t *col_ptr, const int32_t *col_reg, int32_t T,
+                       int32_t ratio, float *out, void *stream);
+
+/*
+ * out = uncond + g * (cond - uncond)  (paint_with_words.py:501-503), fp32 math, n elements of
+ * `dtype` in, fp32 out.
+ */
+int pww_cfg_combine(const void *cond, const void *uncond, float guidance, float *out,
+                    int64_t n, int32_t dtype, void *stream);
+
+/* Device workspace the library needs from the caller: currently 0 for every entry point. */
+size_t pww_workspace_bytes(const pww_attn_desc_t *desc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PWW_HIP_H */

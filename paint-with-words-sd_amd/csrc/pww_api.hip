@@ -1,0 +1,113 @@
+// extern "C" surface of libpww_hip.so (declared in include/pww_hip.h) + error plumbing.
+#include <string.h>
+#include "pww_common.h"
+
+namespace pww {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_hip(hipError_t e, const char *what) {
+    if (e == hipSuccess) return PWW_OK;
+    set_error("%s: %s (%s)", what, hipGetErrorString(e), hipGetErrorName(e));
+    return PWW_EHIP;
+}
+
+static int query_arch(char *buf, size_t n) {
+    int dev = 0;
+    if (int rc = check_hip(hipGetDevice(&dev), "hipGetDevice")) return rc;
+    hipDeviceProp_t prop;
+    if (int rc = check_hip(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties")) return rc;
+    // gcnArchName looks like "gfx950:sramecc+:xnack-"
+    size_t len = strcspn(prop.gcnArchName, ":");
+    if (len >= n) len = n ? n - 1 : 0;
+    if (n) { memcpy(buf, prop.gcnArchName, len); buf[len] = 0; }
+    return PWW_OK;
+}
+
+// The code objects in this library are built for gfx950 only; refuse anything else loudly instead
+// of failing inside a launch.
+bool arch_ok() {
+    static thread_local int cached = -1;  // -1 unknown, 0 bad, 1 ok
+    if (cached < 0) {
+        char arch[64] = "";
+        if (query_arch(arch, sizeof(arch)) != PWW_OK) return false;
+        cached = strcmp(arch, "gfx950") == 0 ? 1 : 0;
+        if (!cached) set_error("libpww_hip is built for gfx950 (MI355X) only; device reports '%s'", arch);
+    } else if (cached == 0) {
+        set_error("libpww_hip is built for gfx950 (MI355X) only");
+    }
+    return cached == 1;
+}
+
+int attn_fwd(const void *q, const void *k, const void *v, void *o, const float *bias, const float *bias_coeff,
+             const pww_attn_desc_t *d, hipStream_t stream);
+int qk_reduce(const void *q, const void *k, const pww_attn_desc_t *d, double *stats, hipStream_t stream);
+int mask_build(const uint8_t *rgb, int H, int W, const pww_region_t *regions, int R, const int32_t *col_ptr,
+               const int32_t *col_reg, int T, float *out8, float *out16, float *out32, float *out64,
+               hipStream_t stream);
+int mask_build_rgb(const uint8_t *rgb, int H, int W, const pww_region_t *regions, int R, const int32_t *col_ptr,
+                   const int32_t *col_reg, int T, int ratio, float *out, hipStream_t stream);
+int mask_build_f32(const float *masks, int H, int W, int R, const int32_t *col_ptr, const int32_t *col_reg, int T,
+                   int ratio, float *out, hipStream_t stream);
+int cfg_combine(const void *cond, const void *uncond, float g, float *out, long n, int dtype, hipStream_t stream);
+
+}  // namespace pww
+
+extern "C" {
+
+int pww_version(void) { return PWW_VERSION; }
+
+const char *pww_last_error(void) { return pww::g_err; }
+
+int pww_device_arch(char *buf, size_t n) {
+    if (!buf || !n) { pww::set_error("pww_device_arch: null buffer"); return PWW_EINVAL; }
+    return pww::query_arch(buf, n);
+}
+
+int pww_self_attn_fwd(const void *q, const void *k, const void *v, void *o, const pww_attn_desc_t *desc,
+                      void *stream) {
+    return pww::attn_fwd(q, k, v, o, nullptr, nullptr, desc, static_cast<hipStream_t>(stream));
+}
+
+int pww_cross_attn_fwd(const void *q, const void *k, const void *v, void *o, const float *bias,
+                       const float *bias_coeff, const pww_attn_desc_t *desc, void *stream) {
+    return pww::attn_fwd(q, k, v, o, bias, bias_coeff, desc, static_cast<hipStream_t>(stream));
+}
+
+int pww_qk_reduce(const void *q, const void *k, const pww_attn_desc_t *desc, double *stats, void *stream) {
+    return pww::qk_reduce(q, k, desc, stats, static_cast<hipStream_t>(stream));
+}
+
+int pww_mask_build(const uint8_t *rgb, int32_t H, int32_t W, const pww_region_t *regions, int32_t R,
+                   const int32_t *col_ptr, const int32_t *col_reg, int32_t T, float *out8, float *out16,
+                   float *out32, float *out64, void *stream) {
+    return pww::mask_build(rgb, H, W, regions, R, col_ptr, col_reg, T, out8, out16, out32, out64,
+                           static_cast<hipStream_t>(stream));
+}
+
+int pww_mask_build_rgb(const uint8_t *rgb, int32_t H, int32_t W, const pww_region_t *regions, int32_t R,
+                       const int32_t *col_ptr, const int32_t *col_reg, int32_t T, int32_t ratio, float *out,
+                       void *stream) {
+    return pww::mask_build_rgb(rgb, H, W, regions, R, col_ptr, col_reg, T, ratio, out, static_cast<hipStream_t>(stream));
+}
+
+int pww_mask_build_f32(const float *masks, int32_t H, int32_t W, int32_t R, const int32_t *col_ptr,
+                       const int32_t *col_reg, int32_t T, int32_t ratio, float *out, void *stream) {
+    return pww::mask_build_f32(masks, H, W, R, col_ptr, col_reg, T, ratio, out, static_cast<hipStream_t>(stream));
+}
+
+int pww_cfg_combine(const void *cond, const void *uncond, float guidance, float *out, int64_t n, int32_t dtype,
+                    void *stream) {
+    return pww::cfg_combine(cond, uncond, guidance, out, (long)n, dtype, static_cast<hipStream_t>(stream));
+}
+
+size_t pww_workspace_bytes(const pww_attn_desc_t *desc) { (void)desc; return 0; }
+
+}  // extern "C"

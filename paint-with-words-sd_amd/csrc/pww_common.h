@@ -1,0 +1,46 @@
+// Shared device/host helpers for libpww_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/pww_hip.h"
+
+namespace pww {
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Vec;
+template <> struct Vec<f16> { typedef f16x8 v8; typedef f16x4 v4; };
+template <> struct Vec<bf16> { typedef bf16x8 v8; typedef bf16x4 v4; };
+
+// D(32x32 f32) += A(32x16) * B(16x32). Lane l supplies A[l&31][8*(l>>5)+j] and B[8*(l>>5)+j][l&31],
+// j=0..7; receives D[(r&3)+8*(r>>2)+4*(l>>5)][l&31] in register r (guide: cdna_hip_programming §3).
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <typename V8> __device__ __forceinline__ V8 zero8() {
+    uint4 z = make_uint4(0, 0, 0, 0);
+    return __builtin_bit_cast(V8, z);
+}
+
+// Swap bits 2 and 3 of a 5-bit row index. Feeding K rows to the MFMA in this order makes each
+// lane's 8 consecutive accumulator registers correspond to 8 consecutive keys (see pww_attn.hip).
+__device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
+// ---- host side -------------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+int check_hip(hipError_t e, const char *what);
+bool arch_ok();
+
+}  // namespace pww

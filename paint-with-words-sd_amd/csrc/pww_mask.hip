@@ -1,0 +1,152 @@
+// Mask preparation: RGB color map -> per-resolution per-token weight maps
+// (paint_with_words/paint_with_words.py:207-276), and the classifier-free-guidance combine
+// (:501-503). Both are HBM-bound streaming kernels: coalesced loads, LDS only to share the
+// per-pixel region values among the threads that write the 77 token columns.
+//
+// Semantics restated from the reference (NOT copied; see oracle/pww_oracle.py for the CPU twin):
+//   region mask_r[y][x] = strength_r if rgb[y][x] == color_r else 0               (:231-236)
+//   down_r = bilinear(mask_r, size=(Hr, Wr), align_corners=True)                  (:38-45)
+//        src = dst * (in-1)/(out-1); i0 = floor(src); i1 = i0 + (i0 < in-1); l1 = src - i0
+//        v = (1-ly) * ((1-lx) p00 + lx p01) + ly * ((1-lx) p10 + lx p11)          fp32, no FMA
+//   out[pix][t] = sum over the regions listed for prompt position t, in list order (:257-268)
+#include "pww_common.h"
+
+namespace pww {
+
+constexpr int MASK_PIX = 64;      // output pixels per workgroup
+constexpr int MASK_THREADS = 256;
+constexpr int MASK_MAX_R = 64;    // regions per call (color_context entries)
+
+struct RgbTap {
+    const uint8_t *rgb; int W; const pww_region_t *regions;
+    __device__ __forceinline__ float operator()(int r, int y, int x) const {
+        const uint8_t *px = rgb + ((long)y * W + x) * 3;
+        const pww_region_t reg = regions[r];
+        return (px[0] == reg.r && px[1] == reg.g && px[2] == reg.b) ? reg.strength : 0.f;
+    }
+};
+struct F32Tap {
+    const float *masks; int H, W;
+    __device__ __forceinline__ float operator()(int r, int y, int x) const {
+        return masks[((long)r * H + y) * W + x];
+    }
+};
+
+template <typename Tap>
+__global__ void __launch_bounds__(MASK_THREADS)
+mask_build_kernel(Tap tap, int H, int W, int Hr, int Wr, int R, const int32_t *col_ptr,
+                  const int32_t *col_reg, int T, float *out) {
+    __shared__ float vals[MASK_PIX][MASK_MAX_R + 1];
+    const int tid = threadIdx.x;
+    const int pix0 = blockIdx.x * MASK_PIX;
+    const int npix = Hr * Wr;
+    // ATen: area_pixel_compute_scale(align_corners=True) = (in - 1) / (out - 1) in fp32, 0 if out == 1
+    const float sy = Hr > 1 ? __fdiv_rn((float)(H - 1), (float)(Hr - 1)) : 0.f;
+    const float sx = Wr > 1 ? __fdiv_rn((float)(W - 1), (float)(Wr - 1)) : 0.f;
+
+    for (int i = tid; i < MASK_PIX * R; i += MASK_THREADS) {
+        const int lp = i % MASK_PIX, r = i / MASK_PIX;
+        const int pix = pix0 + lp;
+        float v = 0.f;
+        if (pix < npix) {
+            const int oy = pix / Wr, ox = pix - oy * Wr;
+            const float fy = __fmul_rn(sy, (float)oy), fx = __fmul_rn(sx, (float)ox);
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+            const float ly = fminf(fmaxf(__fsub_rn(fy, (float)y0), 0.f), 1.f);
+            const float lx = fminf(fmaxf(__fsub_rn(fx, (float)x0), 0.f), 1.f);
+            const float hy = __fsub_rn(1.f, ly), hx = __fsub_rn(1.f, lx);
+            const float top = __fadd_rn(__fmul_rn(tap(r, y0, x0), hx), __fmul_rn(tap(r, y0, x1), lx));
+            const float bot = __fadd_rn(__fmul_rn(tap(r, y1, x0), hx), __fmul_rn(tap(r, y1, x1), lx));
+            v = __fadd_rn(__fmul_rn(top, hy), __fmul_rn(bot, ly));
+        }
+        vals[lp][r] = v;
+    }
+    __syncthreads();
+    const int nlocal = min(MASK_PIX, npix - pix0);
+    for (int i = tid; i < nlocal * T; i += MASK_THREADS) {
+        const int lp = i / T, t = i - lp * T;
+        float acc = 0.f;
+        for (int e = col_ptr[t]; e < col_ptr[t + 1]; ++e) acc = __fadd_rn(acc, vals[lp][col_reg[e]]);
+        out[(long)pix0 * T + i] = acc;  // [pix][T] row-major: consecutive threads -> consecutive floats
+    }
+}
+
+// Round-half-up division result used by the reference for the per-ratio sizes
+// (always_round, paint_with_words.py:18-26): for x >= 0 this is floor(x + 0.5).
+static int round_div(int a, int ratio) { return (int)((2L * a + ratio) / (2L * ratio)); }
+
+template <typename Tap>
+static int launch_mask(Tap tap, int H, int W, int ratio, int R, const int32_t *col_ptr,
+                       const int32_t *col_reg, int T, float *out, hipStream_t stream) {
+    const int Hr = round_div(H, ratio), Wr = round_div(W, ratio);
+    if (Hr <= 0 || Wr <= 0) { set_error("mask_build: image %dx%d too small for ratio %d", H, W, ratio); return PWW_EINVAL; }
+    const int npix = Hr * Wr;
+    hipLaunchKernelGGL((mask_build_kernel<Tap>), dim3((npix + MASK_PIX - 1) / MASK_PIX), dim3(MASK_THREADS), 0,
+                       stream, tap, H, W, Hr, Wr, R, col_ptr, col_reg, T, out);
+    return check_hip(hipGetLastError(), "mask_build_kernel launch");
+}
+
+static int check_mask_args(const void *src, int H, int W, int R, const int32_t *col_ptr, const int32_t *col_reg, int T) {
+    if (!src || !col_ptr || !col_reg) { set_error("mask_build: null argument"); return PWW_EINVAL; }
+    if (H <= 0 || W <= 0 || T <= 0) { set_error("mask_build: bad size H=%d W=%d T=%d", H, W, T); return PWW_EINVAL; }
+    if (R <= 0 || R > MASK_MAX_R) { set_error("mask_build: region count %d outside 1..%d", R, MASK_MAX_R); return PWW_ENOTSUP; }
+    if (!arch_ok()) return PWW_ENOTSUP;
+    return PWW_OK;
+}
+
+int mask_build(const uint8_t *rgb, int H, int W, const pww_region_t *regions, int R, const int32_t *col_ptr,
+               const int32_t *col_reg, int T, float *out8, float *out16, float *out32, float *out64,
+               hipStream_t stream) {
+    if (int rc = check_mask_args(rgb, H, W, R, col_ptr, col_reg, T)) return rc;
+    if (!regions) { set_error("mask_build: null regions"); return PWW_EINVAL; }
+    RgbTap tap{rgb, W, regions};
+    float *outs[4] = {out8, out16, out32, out64};
+    const int ratios[4] = {8, 16, 32, 64};
+    for (int i = 0; i < 4; ++i) {
+        if (!outs[i]) continue;
+        if (int rc = launch_mask(tap, H, W, ratios[i], R, col_ptr, col_reg, T, outs[i], stream)) return rc;
+    }
+    return PWW_OK;
+}
+
+int mask_build_rgb(const uint8_t *rgb, int H, int W, const pww_region_t *regions, int R, const int32_t *col_ptr,
+                   const int32_t *col_reg, int T, int ratio, float *out, hipStream_t stream) {
+    if (int rc = check_mask_args(rgb, H, W, R, col_ptr, col_reg, T)) return rc;
+    if (!regions || !out || ratio <= 0) { set_error("mask_build_rgb: bad regions/out/ratio"); return PWW_EINVAL; }
+    RgbTap tap{rgb, W, regions};
+    return launch_mask(tap, H, W, ratio, R, col_ptr, col_reg, T, out, stream);
+}
+
+int mask_build_f32(const float *masks, int H, int W, int R, const int32_t *col_ptr, const int32_t *col_reg, int T,
+                   int ratio, float *out, hipStream_t stream) {
+    if (int rc = check_mask_args(masks, H, W, R, col_ptr, col_reg, T)) return rc;
+    if (!out || ratio <= 0) { set_error("mask_build_f32: bad out/ratio"); return PWW_EINVAL; }
+    F32Tap tap{masks, H, W};
+    return launch_mask(tap, H, W, ratio, R, col_ptr, col_reg, T, out, stream);
+}
+
+// ---- classifier-free guidance combine ---------------------------------------------------------
+template <typename T>
+__global__ void cfg_combine_kernel(const T *cond, const T *uncond, float g, float *out, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float c = (float)cond[i], u = (float)uncond[i];
+        out[i] = __fadd_rn(u, __fmul_rn(g, __fsub_rn(c, u)));
+    }
+}
+
+int cfg_combine(const void *cond, const void *uncond, float g, float *out, long n, int dtype, hipStream_t stream) {
+    if (!cond || !uncond || !out || n <= 0) { set_error("cfg_combine: bad argument"); return PWW_EINVAL; }
+    if (!arch_ok()) return PWW_ENOTSUP;
+    const int threads = 256;
+    const int blocks = (int)((n + threads - 1) / threads < 2048 ? (n + threads - 1) / threads : 2048);
+    if (dtype == PWW_DTYPE_F16)
+        hipLaunchKernelGGL(cfg_combine_kernel<f16>, dim3(blocks), dim3(threads), 0, stream, (const f16 *)cond, (const f16 *)uncond, g, out, n);
+    else if (dtype == PWW_DTYPE_BF16)
+        hipLaunchKernelGGL(cfg_combine_kernel<bf16>, dim3(blocks), dim3(threads), 0, stream, (const bf16 *)cond, (const bf16 *)uncond, g, out, n);
+    else { set_error("cfg_combine: dtype %d unsupported", dtype); return PWW_ENOTSUP; }
+    return check_hip(hipGetLastError(), "cfg_combine_kernel launch");
+}
+
+}  // namespace pww

@@ -1,0 +1,166 @@
+// Score-reduction pre-pass: per-image max / min / sum / sum-of-squares of the RAW score tensor
+// S = Q K^T over all heads, query rows and keys, without writing S to HBM.
+//
+// The reference's weight_function receives the whole score tensor and every shipped variant takes
+// a global scalar reduction of it (qk.max(): paint_with_words/paint_with_words.py:402-405,
+// runner.py:104; qk.std(): README.md:152). That scalar feeds the bias of the SAME attention call,
+// so it has to exist before the fused kernel runs: this kernel recomputes the score tiles with the
+// same MFMA path as pww_attn.hip (pww_tile.h) and reduces them wave -> workgroup -> one atomic per
+// statistic per workgroup. HBM-bound streaming of Q and K (K is L2-resident after the first
+// query block of each head).
+#include "pww_tile.h"
+
+namespace pww {
+
+struct ReduceParams {
+    const void *q, *k;
+    int B, H, N, M, D;
+    long q_sb, q_sh, q_sn;
+    long k_sb, k_sh, k_sm;
+    double *stats;  // [B][4] = max, min, sum, sumsq
+};
+
+__global__ void qk_stats_init_kernel(double *stats, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) {
+        stats[i * 4 + 0] = -INFINITY;
+        stats[i * 4 + 1] = INFINITY;
+        stats[i * 4 + 2] = 0.0;
+        stats[i * 4 + 3] = 0.0;
+    }
+}
+
+// Order-preserving atomic max/min on IEEE doubles via their integer images.
+__device__ __forceinline__ void atomic_max_f64(double *addr, double v) {
+    if (v >= 0.0) atomicMax(reinterpret_cast<long long *>(addr), __double_as_longlong(v));
+    else atomicMin(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(v));
+}
+__device__ __forceinline__ void atomic_min_f64(double *addr, double v) {
+    if (v >= 0.0) atomicMin(reinterpret_cast<long long *>(addr), __double_as_longlong(v));
+    else atomicMax(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+template <typename T, int KS, int NW>
+__global__ void __launch_bounds__(NW * 64) qk_reduce_kernel(const ReduceParams p) {
+    typedef typename Vec<T>::v8 V8;
+    typedef KTile<KS> KT;
+    constexpr int NT = NW * 64;
+    constexpr int KPT = (KT::NCHUNK + NT - 1) / NT;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *Ks = smem;
+    float *red = reinterpret_cast<float *>(smem + KT::BYTES);  // [NW][4]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int BH = p.B * p.H;
+    const int bh = blockIdx.x % BH, qb = blockIdx.x / BH;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const T *Qp = reinterpret_cast<const T *>(p.q) + b * p.q_sb + h * p.q_sh;
+    const T *Kp = reinterpret_cast<const T *>(p.k) + b * p.k_sb + h * p.k_sh;
+    const int qrow = (qb * NW + wave) * 32 + l31;
+    const bool qvalid = qrow < p.N;
+
+    V8 qf[KS];
+    load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qvalid, hi, p.D);
+
+    float vmax = -INFINITY, vmin = INFINITY, vsum = 0.f, vsq = 0.f;
+    uint4 kreg[KPT];
+    const int ntiles = (p.M + KVBLK - 1) / KVBLK;
+    ktile_load<T, KS, NT, KPT>(kreg, Kp, p.k_sm, 0, p.M, p.D, tid);
+    for (int t = 0; t < ntiles; ++t) {
+        const int key0 = t * KVBLK;
+        __syncthreads();
+        ktile_store<KS, NT, KPT>(kreg, Ks, tid);
+        __syncthreads();
+        if (t + 1 < ntiles) ktile_load<T, KS, NT, KPT>(kreg, Kp, p.k_sm, key0 + KVBLK, p.M, p.D, tid);
+        f32x16 s[2];
+        score_tile<T, KS>(s, qf, Ks, key0, p.M, l31, hi);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool live = qvalid && (key0 + key_of(kb, r, hi) < p.M);
+                const float x = s[kb][r];
+                vmax = fmaxf(vmax, live ? x : -INFINITY);
+                vmin = fminf(vmin, live ? x : INFINITY);
+                vsum += live ? x : 0.f;
+                vsq += live ? x * x : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+        vmin = fminf(vmin, __shfl_xor(vmin, off));
+        vsum += __shfl_xor(vsum, off);
+        vsq += __shfl_xor(vsq, off);
+    }
+    __syncthreads();
+    if (lane == 0) {
+        red[wave * 4 + 0] = vmax; red[wave * 4 + 1] = vmin;
+        red[wave * 4 + 2] = vsum; red[wave * 4 + 3] = vsq;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double dmax = -INFINITY, dmin = INFINITY, dsum = 0.0, dsq = 0.0;
+        for (int w = 0; w < NW; ++w) {
+            dmax = fmax(dmax, (double)red[w * 4 + 0]);
+            dmin = fmin(dmin, (double)red[w * 4 + 1]);
+            dsum += (double)red[w * 4 + 2];
+            dsq += (double)red[w * 4 + 3];
+        }
+        double *st = p.stats + b * 4;
+        if (dmax > -INFINITY) atomic_max_f64(st + 0, dmax);
+        if (dmin < INFINITY) atomic_min_f64(st + 1, dmin);
+        atomicAdd(st + 2, dsum);
+        atomicAdd(st + 3, dsq);
+    }
+}
+
+template <typename T, int KS, int NW>
+static int launch_reduce(const ReduceParams &p, hipStream_t stream) {
+    constexpr size_t lds = KTile<KS>::BYTES + NW * 4 * sizeof(float);
+    const int qblocks = (p.N + NW * 32 - 1) / (NW * 32);
+    hipLaunchKernelGGL((qk_reduce_kernel<T, KS, NW>), dim3((unsigned)(qblocks * p.B * p.H)), dim3(NW * 64),
+                       lds, stream, p);
+    return check_hip(hipGetLastError(), "qk_reduce_kernel launch");
+}
+
+template <typename T> static int dispatch_reduce(const ReduceParams &p, hipStream_t s) {
+    const int D = p.D;
+    const long rows32 = (long)((p.N + 31) / 32) * p.B * p.H;
+    const bool wide = rows32 >= 4 * 256 && p.N >= 128;
+#define PWW_RED(KS_) (wide ? launch_reduce<T, KS_, 4>(p, s) : launch_reduce<T, KS_, 2>(p, s))
+    if (D <= 48) return PWW_RED(3);
+    if (D <= 64) return PWW_RED(4);
+    if (D <= 80) return PWW_RED(5);
+    if (D <= 96) return PWW_RED(6);
+    if (D <= 128) return PWW_RED(8);
+    return PWW_RED(10);
+#undef PWW_RED
+}
+
+int qk_reduce(const void *q, const void *k, const pww_attn_desc_t *d, double *stats, hipStream_t stream) {
+    if (!d || !q || !k || !stats) { set_error("qk_reduce: null argument"); return PWW_EINVAL; }
+    if (d->B <= 0 || d->H <= 0 || d->N <= 0 || d->M <= 0 || d->D <= 0) { set_error("qk_reduce: non-positive dimension"); return PWW_EINVAL; }
+    if (d->D % 8 != 0 || d->D > PWW_MAX_HEAD_DIM) { set_error("qk_reduce: head dim %d unsupported", d->D); return PWW_ENOTSUP; }
+    if (d->dtype != PWW_DTYPE_F16 && d->dtype != PWW_DTYPE_BF16) { set_error("qk_reduce: dtype %d unsupported", d->dtype); return PWW_ENOTSUP; }
+    if ((reinterpret_cast<uintptr_t>(q) & 15) || (reinterpret_cast<uintptr_t>(k) & 15) || (reinterpret_cast<uintptr_t>(stats) & 7)) {
+        set_error("qk_reduce: misaligned pointer"); return PWW_EINVAL;
+    }
+    for (int i = 0; i < 3; ++i)
+        if (d->q_stride[i] % 8 || d->k_stride[i] % 8) { set_error("qk_reduce: strides must be multiples of 8 elements"); return PWW_EINVAL; }
+    if (!arch_ok()) return PWW_ENOTSUP;
+    ReduceParams p;
+    p.q = q; p.k = k; p.B = d->B; p.H = d->H; p.N = d->N; p.M = d->M; p.D = d->D;
+    p.q_sb = d->q_stride[0]; p.q_sh = d->q_stride[1]; p.q_sn = d->q_stride[2];
+    p.k_sb = d->k_stride[0]; p.k_sh = d->k_stride[1]; p.k_sm = d->k_stride[2];
+    p.stats = stats;
+    hipLaunchKernelGGL(qk_stats_init_kernel, dim3((d->B + 63) / 64), dim3(64), 0, stream, stats, d->B);
+    if (int rc = check_hip(hipGetLastError(), "qk_stats_init_kernel launch")) return rc;
+    return d->dtype == PWW_DTYPE_F16 ? dispatch_reduce<f16>(p, stream) : dispatch_reduce<bf16>(p, stream);
+}
+
+}  // namespace pww

@@ -1,0 +1,104 @@
+// Tile machinery shared by the fused attention kernel (pww_attn.hip) and the score-reduction
+// pre-pass (pww_reduce.hip): Q fragments in registers, K tiles staged through LDS, and the
+// "swapped" score tile S^T = K Q^T on the 32x32x16 MFMA so that every lane owns ONE query row.
+//
+// Geometry (gfx950, wave64):
+//   - a wave owns 32 query rows; lane l works for row (l & 31); hi = l >> 5 selects which half of
+//     each 16-wide contraction slice / which 8 of every 16 keys the lane holds.
+//   - a KV tile is KVBLK = 64 keys = two 32-key blocks. For block kb the MFMA A operand is
+//     K[key = kb*32 + swap23(l & 31)][d = ks*16 + hi*8 .. +7], the B operand is the lane's own
+//     Q[row][same d range]. Accumulator register r of block kb then holds the raw score of
+//     key = kb*32 + 16*(r >> 3) + 8*hi + (r & 7): 8 consecutive keys per 8 consecutive registers,
+//     which is exactly the B-operand packing the PV MFMA wants (no cross-lane traffic for P).
+#pragma once
+#include "pww_common.h"
+
+namespace pww {
+
+constexpr int KVBLK = 64;
+
+template <int KS> struct KTile {
+    static constexpr int DPAD = KS * 16;           // head dim padded to the MFMA k granularity
+    static constexpr int CHK = DPAD / 8;           // 16-byte chunks per key row
+    static constexpr int STRIDE = DPAD * 2 + 16;   // bytes; +16 makes the row->slot map odd => conflict-free b128 reads
+    static constexpr int BYTES = KVBLK * STRIDE;
+    static constexpr int NCHUNK = KVBLK * CHK;
+};
+
+// Q fragments of one wave: lane (hi, row) keeps Q[row][ks*16 + hi*8 .. +7] for every k-step.
+template <typename T, int KS>
+__device__ __forceinline__ void load_q_frags(typename Vec<T>::v8 (&qf)[KS], const T *qrow_ptr,
+                                              bool qvalid, int hi, int D) {
+    typedef typename Vec<T>::v8 V8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int d0 = ks * 16 + hi * 8;
+        V8 v = zero8<V8>();
+        if (qvalid && d0 < D) v = *reinterpret_cast<const V8 *>(qrow_ptr + d0);
+        qf[ks] = v;
+    }
+}
+
+// Global -> registers for one K tile (keys key0 .. key0+63). Out-of-range keys and the head-dim
+// padding are zero-filled so the MFMA never sees uninitialised LDS.
+template <typename T, int KS, int NT, int KPT>
+__device__ __forceinline__ void ktile_load(uint4 (&kreg)[KPT], const T *Kp, long k_sm, int key0,
+                                           int M, int D, int tid) {
+    typedef KTile<KS> KT;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const int c = tid + i * NT;
+        uint4 val = make_uint4(0, 0, 0, 0);
+        if (c < KT::NCHUNK) {
+            const int key = c / KT::CHK, ch = c % KT::CHK;
+            const int gk = key0 + key, d0 = ch * 8;
+            if (gk < M && d0 < D) val = *reinterpret_cast<const uint4 *>(Kp + (long)gk * k_sm + d0);
+        }
+        kreg[i] = val;
+    }
+}
+
+template <int KS, int NT, int KPT>
+__device__ __forceinline__ void ktile_store(const uint4 (&kreg)[KPT], char *Ks, int tid) {
+    typedef KTile<KS> KT;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const int c = tid + i * NT;
+        if (c < KT::NCHUNK) {
+            const int key = c / KT::CHK, ch = c % KT::CHK;
+            *reinterpret_cast<uint4 *>(Ks + key * KT::STRIDE + ch * 16) = kreg[i];
+        }
+    }
+}
+
+// s[kb] = K_block(kb) Q^T for the two 32-key blocks of the tile; a block entirely past M is
+// skipped (wave-uniform) and left at zero.
+template <typename T, int KS>
+__device__ __forceinline__ void score_tile(f32x16 (&s)[2], const typename Vec<T>::v8 (&qf)[KS],
+                                           const char *Ks, int key0, int M, int l31, int hi) {
+    typedef typename Vec<T>::v8 V8;
+    typedef KTile<KS> KT;
+    const int krow = swap23(l31);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (key0 + kb * 32 < M) {
+            const char *base = Ks + (kb * 32 + krow) * KT::STRIDE + hi * 16;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const V8 kf = *reinterpret_cast<const V8 *>(base + ks * 32);
+                acc = mfma32(kf, qf[ks], acc);
+            }
+        }
+        s[kb] = acc;
+    }
+}
+
+// key index (within the tile) of accumulator register r of block kb for this lane.
+__device__ __forceinline__ int key_of(int kb, int r, int hi) {
+    return kb * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+}
+
+}  // namespace pww

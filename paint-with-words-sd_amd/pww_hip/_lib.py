@@ -1,0 +1,85 @@
+"""ctypes binding of libpww_hip.so (the C ABI declared in include/pww_hip.h).
+
+The library is plain HIP behind `extern "C"`; nothing here depends on torch. Loading fails LOUDLY:
+there is no CPU or PyTorch fallback for the kernels (the oracle under oracle/ is test-only).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("PWW_HIP_LIB", os.path.join(_HERE, "libpww_hip.so"))
+
+PWW_OK, PWW_EINVAL, PWW_ENOTSUP, PWW_EHIP = 0, -22, -95, -5
+DTYPE_F16, DTYPE_BF16 = 0, 1
+MAX_HEAD_DIM = 160
+
+# every symbol include/pww_hip.h declares (tests check the library exports all of them)
+EXPORTS = ("pww_version", "pww_last_error", "pww_device_arch", "pww_self_attn_fwd", "pww_cross_attn_fwd",
+           "pww_qk_reduce", "pww_mask_build", "pww_mask_build_rgb", "pww_mask_build_f32", "pww_cfg_combine",
+           "pww_workspace_bytes")
+
+
+class AttnDesc(ctypes.Structure):
+    """struct pww_attn_desc (include/pww_hip.h)."""
+    _fields_ = [("dtype", ctypes.c_int32), ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("N", ctypes.c_int32),
+                ("M", ctypes.c_int32), ("D", ctypes.c_int32),
+                ("q_stride", ctypes.c_int64 * 3), ("k_stride", ctypes.c_int64 * 3),
+                ("v_stride", ctypes.c_int64 * 3), ("o_stride", ctypes.c_int64 * 3),
+                ("scale", ctypes.c_float), ("bias_stride", ctypes.c_int64 * 4)]
+
+
+class Region(ctypes.Structure):
+    """struct pww_region."""
+    _fields_ = [("r", ctypes.c_uint8), ("g", ctypes.c_uint8), ("b", ctypes.c_uint8), ("_pad", ctypes.c_uint8),
+                ("strength", ctypes.c_float)]
+
+
+class PwwHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libpww_hip.so once; raise PwwHipError with build instructions if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise PwwHipError(
+            "libpww_hip.so not found at %s. Build it with `python paint-with-words-sd_amd/build.py` "
+            "(or __graft_entry__.build()). There is no CPU/PyTorch fallback for the PwW kernels." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+    lib.pww_version.restype = ctypes.c_int
+    lib.pww_last_error.restype = ctypes.c_char_p
+    lib.pww_device_arch.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    lib.pww_self_attn_fwd.argtypes = [vp, vp, vp, vp, ctypes.POINTER(AttnDesc), vp]
+    lib.pww_cross_attn_fwd.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.POINTER(AttnDesc), vp]
+    lib.pww_qk_reduce.argtypes = [vp, vp, ctypes.POINTER(AttnDesc), vp, vp]
+    lib.pww_mask_build.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
+    lib.pww_mask_build_rgb.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, i32, vp, vp]
+    lib.pww_mask_build_f32.argtypes = [vp, i32, i32, i32, vp, vp, i32, i32, vp, vp]
+    lib.pww_cfg_combine.argtypes = [vp, vp, f32, vp, i64, i32, vp]
+    lib.pww_workspace_bytes.argtypes = [ctypes.POINTER(AttnDesc)]
+    lib.pww_workspace_bytes.restype = ctypes.c_size_t
+    for name in ("pww_device_arch", "pww_self_attn_fwd", "pww_cross_attn_fwd", "pww_qk_reduce", "pww_mask_build",
+                 "pww_mask_build_rgb", "pww_mask_build_f32", "pww_cfg_combine"):
+        getattr(lib, name).restype = ctypes.c_int
+    if lib.pww_version() // 100 != 1:
+        raise PwwHipError("libpww_hip ABI version %d is not 1.x" % lib.pww_version())
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != PWW_OK:
+        msg = load().pww_last_error().decode("utf-8", "replace")
+        raise PwwHipError("%s failed (rc=%d): %s" % (what, rc, msg))
+
+
+def device_arch():
+    buf = ctypes.create_string_buffer(64)
+    check(load().pww_device_arch(buf, 64), "pww_device_arch")
+    return buf.value.decode()

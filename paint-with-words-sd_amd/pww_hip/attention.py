@@ -1,0 +1,304 @@
+"""The Paint-with-Words attention plug for PyTorch-ROCm, backed by libpww_hip.so.
+
+Mirrors the reference's interface for this path (paint_with_words/paint_with_words.py, cited per
+function): ``inj_forward`` has the same signature and context protocol as the reference's
+(:60-125) and is installed by the same class-level patch (:193-195); ``PwWAttnProcessor`` offers the
+same computation through the attention-processor plug point of newer diffusers.
+
+What changes is WHERE the arithmetic happens: projections stay torch ``nn.Linear`` (hipBLASLt), the
+head split / merge disappears into kernel strides, and scores + bias + softmax + PV run in one fused
+HIP kernel. The user's ``weight_function(w, sigma, qk)`` still receives ``qk`` -- as a ``QKProxy``
+whose reductions are computed by the score-reduction kernel instead of from a materialised tensor.
+"""
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import PwwHipError
+
+_HALF = (torch.float16, torch.bfloat16)
+_warned = set()
+
+
+def _warn_once(key, msg):
+    if key not in _warned:
+        _warned.add(key)
+        warnings.warn(msg, stacklevel=3)
+
+
+class QKProxy:
+    """Stands in for the raw score tensor ``qk = Q K^T`` ([B*heads, N, M]) that the reference hands
+    to ``weight_function`` (:87, :106). Global reductions -- all the shipped weight functions use
+    (``qk.max()`` :402-405 / runner.py:104, ``qk.std()`` README.md:152) -- are answered by
+    ``pww_qk_reduce`` without materialising the tensor. Anything else materialises ``qk`` with a
+    plain batched GEMM (correct, slower) and delegates to the real tensor.
+
+    With batch > 1 the reductions are PER IMAGE (the reference only ever sees batch 1): they return
+    a [B, 1, 1, 1] tensor so the resulting bias broadcasts to [B, heads, N, M].
+    """
+
+    def __init__(self, q, k, heads):
+        self._q, self._k, self._heads = q, k, heads
+        self._stats = None
+        self._full = None
+        B, N, C = q.shape
+        self.shape = torch.Size((B * heads, N, k.shape[1]))
+        self.dtype = q.dtype
+        self.device = q.device
+
+    # -- lazily computed per-image statistics ---------------------------------------------------
+    def _st(self):
+        if self._stats is None:
+            self._stats = ops.qk_stats(self._q, self._k, self._heads)  # [B, 4] float64
+        return self._stats
+
+    def _count(self):
+        return self.shape[0] // self._q.shape[0] * self.shape[1] * self.shape[2]
+
+    def _shape_out(self, t):
+        t = t.to(torch.float32)
+        return t.reshape(()) if t.numel() == 1 else t.reshape(-1, 1, 1, 1)
+
+    def max(self, *args, **kw):
+        if args or kw:
+            return self._materialize().max(*args, **kw)
+        return self._shape_out(self._st()[:, 0])
+
+    def min(self, *args, **kw):
+        if args or kw:
+            return self._materialize().min(*args, **kw)
+        return self._shape_out(self._st()[:, 1])
+
+    def sum(self, *args, **kw):
+        if args or kw:
+            return self._materialize().sum(*args, **kw)
+        return self._shape_out(self._st()[:, 2])
+
+    def mean(self, *args, **kw):
+        if args or kw:
+            return self._materialize().mean(*args, **kw)
+        return self._shape_out(self._st()[:, 2] / self._count())
+
+    def var(self, *args, **kw):
+        if args or kw:
+            return self._materialize().var(*args, **kw)
+        st, n = self._st(), self._count()
+        var = (st[:, 3] - st[:, 2] * st[:, 2] / n) / max(n - 1, 1)   # unbiased, like torch.var
+        return self._shape_out(var.clamp_min(0))
+
+    def std(self, *args, **kw):
+        if args or kw:
+            return self._materialize().std(*args, **kw)
+        return self.var().sqrt()
+
+    def abs(self):
+        return _AbsQK(self)
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return 3
+
+    def numel(self):
+        return self.shape[0] * self.shape[1] * self.shape[2]
+
+    # -- escape hatch: the real tensor -----------------------------------------------------------
+    def _materialize(self):
+        if self._full is None:
+            _warn_once("materialize", "weight_function uses qk beyond global reductions; materialising Q K^T "
+                                      "(correct but slower than the fused reduction path)")
+            B, N, C = self._q.shape
+            h = self._heads
+            qh = self._q.reshape(B, N, h, C // h).permute(0, 2, 1, 3)
+            kh = self._k.reshape(B, -1, h, C // h).permute(0, 2, 3, 1)
+            self._full = torch.matmul(qh, kh).reshape(B * h, N, -1)
+        return self._full
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self._materialize(), name)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        conv = lambda a: a._materialize() if isinstance(a, QKProxy) else a  # noqa: E731
+        return func(*[conv(a) for a in args], **{k: conv(v) for k, v in (kwargs or {}).items()})
+
+    def __add__(self, other):
+        return self._materialize() + other
+
+    def __radd__(self, other):
+        return other + self._materialize()
+
+    def __sub__(self, other):
+        return self._materialize() - other
+
+    def __rsub__(self, other):
+        return other - self._materialize()
+
+    def __mul__(self, other):
+        return self._materialize() * other
+
+    def __rmul__(self, other):
+        return other * self._materialize()
+
+    def __truediv__(self, other):
+        return self._materialize() / other
+
+    def __rtruediv__(self, other):
+        return other / self._materialize()
+
+    def __pow__(self, other):
+        return self._materialize() ** other
+
+    def __neg__(self):
+        return -self._materialize()
+
+    def __getitem__(self, idx):
+        return self._materialize()[idx]
+
+
+class _AbsQK:
+    """``qk.abs()``: its max / mean-free reductions follow from the signed statistics."""
+
+    def __init__(self, proxy):
+        self._p = proxy
+
+    def max(self):
+        st = self._p._st()
+        return self._p._shape_out(torch.maximum(st[:, 0].abs(), st[:, 1].abs()))
+
+    def __getattr__(self, name):
+        return getattr(self._p._materialize().abs(), name)
+
+
+def _orig_weight_to_tokens(w_orig, n_tokens):
+    """The reference's fallback when no CROSS_ATTENTION_WEIGHT_<N> key exists (:96-101): bilinear
+    (align_corners=True) by 1/sqrt(H*W/N), then 1-D nearest to N. Rare (sizes not divisible by 64),
+    host-side torch ops on the device tensor."""
+    img_h, img_w, nc = w_orig.shape
+    ratio = math.sqrt(img_h * img_w / n_tokens)
+    w = F.interpolate(w_orig.permute(2, 0, 1).unsqueeze(0), scale_factor=1 / ratio, mode="bilinear", align_corners=True)
+    w = F.interpolate(w.reshape(1, nc, -1), size=(n_tokens,), mode="nearest").permute(2, 1, 0).squeeze()
+    return w
+
+
+def _half(t, like_dtype):
+    """q/k/v must be fp16/bf16 for the MFMA path. The reference runs under autocast (fp16 matmuls,
+    :60); an fp32 module without autocast is cast to bf16 with a one-time warning."""
+    if t.dtype in _HALF:
+        return t
+    _warn_once("cast", "pww_hip attention received %s activations; casting to %s for the MFMA kernels "
+                       "(the reference computes this path in fp16 under autocast)" % (t.dtype, like_dtype))
+    return t.to(like_dtype)
+
+
+def pww_attention(attn, hidden_states, context=None):
+    """Core of inj_forward (:63-118): projections -> [optional bias] -> fused attention, returning the
+    merged-head [B, N, heads*D] tensor BEFORE the output projection."""
+    is_dict = True
+    if context is not None:
+        try:
+            context_tensor = context["CONTEXT_TENSOR"]
+        except Exception:   # plain tensor context: vanilla pipelines keep working (:65-69)
+            context_tensor = context
+            is_dict = False
+    else:
+        context_tensor = hidden_states
+    if not hidden_states.is_cuda:
+        raise PwwHipError("pww_hip attention needs HIP tensors (got %s); the CPU restatement lives in oracle/ "
+                          "and is test-only" % hidden_states.device)
+
+    wdt = attn.to_q.weight.dtype
+    if context_tensor.dtype != wdt and not torch.is_autocast_enabled():
+        context_tensor = context_tensor.to(wdt)   # text encoder is fp32 in the reference (:171)
+    if hidden_states.dtype != wdt and not torch.is_autocast_enabled():
+        hidden_states = hidden_states.to(wdt)
+    query = attn.to_q(hidden_states)
+    key = attn.to_k(context_tensor)
+    value = attn.to_v(context_tensor)
+    cdt = query.dtype if query.dtype in _HALF else torch.bfloat16
+    query, key, value = _half(query, cdt), _half(key, cdt), _half(value, cdt)
+
+    bias = None
+    if context is not None and is_dict:
+        f = context["WEIGHT_FUNCTION"]
+        n_img = query.shape[1]
+        try:
+            w = context[f"CROSS_ATTENTION_WEIGHT_{n_img}"]
+        except KeyError:
+            w = context["CROSS_ATTENTION_WEIGHT_ORIG"]
+            if not isinstance(w, int):
+                cache = context.setdefault("_PWW_ORIG_CACHE", {})
+                if n_img not in cache:
+                    cache[n_img] = _orig_weight_to_tokens(w, n_img)
+                w = cache[n_img]
+            else:
+                w = 0
+        bias = f(w, context["SIGMA"], QKProxy(query, key, attn.heads))
+
+    if isinstance(bias, QKProxy):
+        bias = bias._materialize()
+    if not torch.is_tensor(bias) or bias.dim() == 0:
+        # python scalar / 0-dim tensor: a constant added to every logit of a row cancels in softmax
+        # (the unconditional pass returns 0.0, :493)
+        bias = None
+    return ops.attention(query, key, value, attn.heads, attn.scale, bias=bias)
+
+
+def inj_forward(self, hidden_states, context=None, mask=None):
+    """Drop-in for the reference's ``inj_forward`` (:60-125): same signature, same context protocol
+    ({None | Tensor | dict with CONTEXT_TENSOR / CROSS_ATTENTION_WEIGHT_* / SIGMA / WEIGHT_FUNCTION}),
+    ``mask`` accepted and ignored like the reference (:61)."""
+    out = pww_attention(self, hidden_states, context)
+    out = self.to_out[0](out.to(self.to_out[0].weight.dtype))
+    out = self.to_out[1](out)
+    return out
+
+
+def install(unet):
+    """The reference's plug (:193-195): for every module whose class is named ``CrossAttention``
+    replace ``__call__`` at class level. Returns the number of modules found."""
+    n = 0
+    for module in unet.modules():
+        if module.__class__.__name__ == "CrossAttention":
+            module.__class__.__call__ = inj_forward
+            n += 1
+    return n
+
+
+def uninstall(unet):
+    for module in unet.modules():
+        cls = module.__class__
+        if cls.__name__ == "CrossAttention" and cls.__dict__.get("__call__") is inj_forward:
+            del cls.__call__
+
+
+class PwWAttnProcessor:
+    """Attention-processor form of the same op for diffusers >= 0.12 ``Attention`` modules
+    (``unet.set_attn_processor(PwWAttnProcessor())``): ``encoder_hidden_states`` carries the PwW dict."""
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, **kwargs):
+        residual = hidden_states
+        spatial = hidden_states.dim() == 4
+        if spatial:
+            b, c, h, w = hidden_states.shape
+            hidden_states = hidden_states.view(b, c, h * w).transpose(1, 2)
+        ctx = encoder_hidden_states
+        if getattr(attn, "norm_cross", None) is not None and ctx is not None:
+            if isinstance(ctx, dict):
+                ctx = dict(ctx, CONTEXT_TENSOR=attn.norm_encoder_hidden_states(ctx["CONTEXT_TENSOR"]))
+            else:
+                ctx = attn.norm_encoder_hidden_states(ctx)
+        out = pww_attention(attn, hidden_states, ctx)
+        out = attn.to_out[0](out.to(attn.to_out[0].weight.dtype))
+        out = attn.to_out[1](out)
+        if spatial:
+            out = out.transpose(-1, -2).reshape(b, c, h, w)
+        if getattr(attn, "residual_connection", False):
+            out = out + residual
+        return out / getattr(attn, "rescale_output_factor", 1.0)

@@ -1,0 +1,174 @@
+"""Conditioning builder: color map + color_context + prompt -> the two encoder_hidden_states dicts of
+the PwW protocol (reference paint_with_words/paint_with_words.py:207-388), with the per-resolution
+token weight maps produced ON DEVICE by pww_mask_build instead of the reference's Python loops over
+F.interpolate (:247-276).
+
+Host side (strings, token matching, the region table) stays Python, as in the reference; function
+names follow the reference's so the call sites read the same.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def always_round(x):
+    """:18-26 (round half up for the non-negative sizes it is applied to)."""
+    intx = int(x)
+    if intx % 2 == 0:
+        return intx if x < intx + 0.5 else intx + 1
+    return round(x)
+
+
+def _extract_seed_and_sigma_from_context(color_context, ignore_seed=-1):
+    """:279-297: "text,strength[,seed[,sigma]]" -> strip the tail; mutates `color_context` like the
+    reference does (:296). Returns (color_context, {ordinal: seed}, {ordinal: sigma})."""
+    extra_seeds, extra_sigmas = {}, {}
+    for i, (k, ctx) in enumerate(color_context.items()):
+        parts = ctx.split(",")
+        if len(parts) > 2:
+            try:
+                seed = int(parts[-2])
+                sigma = float(parts[-1])
+                parts = parts[:-2]
+                extra_sigmas[i] = sigma
+            except ValueError:
+                seed = int(parts[-1])
+                parts = parts[:-1]
+            if seed != ignore_seed:
+                extra_seeds[i] = seed
+        color_context[k] = ",".join(parts)
+    return color_context, extra_seeds, extra_sigmas
+
+
+def _parse_regions(color_context, tokenizer):
+    """Host half of _image_context_seperator (:218-230): [(token_ids, (r, g, b), strength)]."""
+    table = []
+    for color, v in color_context.items():
+        fields = v.split(",")
+        strength = float(fields[-1])
+        text = ",".join(fields[:-1])
+        ids = tokenizer(text, max_length=tokenizer.model_max_length, truncation=True)["input_ids"][1:-1]
+        if isinstance(color, str):
+            color = (int(color[1:3], 16), int(color[3:5], 16), int(color[5:7], 16))
+        table.append((list(ids), tuple(int(c) for c in color), strength))
+    return table
+
+
+def _column_lists(table, token_lis, ratio_tag="8"):
+    """For every prompt position the region ordinals accumulated into it, in the reference's order
+    (:257-268); warns like :270-271 when a phrase does not occur in the prompt."""
+    cols = [[] for _ in token_lis]
+    for r, (ids, _, _) in enumerate(table):
+        L = len(ids)
+        found = False
+        for idx in range(len(token_lis)):
+            if token_lis[idx: idx + L] == ids:
+                found = True
+                for c in range(idx, min(idx + L, len(token_lis))):
+                    cols[c].append(r)
+        if not found:
+            print(f"Warning ratio {ratio_tag} : tokens {ids} not found in text")
+    return cols
+
+
+def gaussian_blur_mask(mask, sigma, ksize=39):
+    """_blur_image_mask (:307-312): torchvision GaussianBlur(39x39, sigma) semantics -- separable
+    Gaussian exp(-0.5 (x/sigma)^2) normalised, reflect padding -- as torch ops on the device mask."""
+    half = (ksize - 1) * 0.5
+    x = torch.linspace(-half, half, steps=ksize, device=mask.device, dtype=torch.float32)
+    k = torch.exp(-0.5 * (x / sigma) ** 2)
+    k = k / k.sum()
+    k2 = torch.mm(k[:, None], k[None, :])
+    p = ksize // 2
+    m = F.pad(mask[None, None].float(), [p, p, p, p], mode="reflect")
+    return F.conv2d(m, k2[None, None])[0, 0]
+
+
+def build_weight_maps(color_map_rgb, table, token_lis, device, extra_sigmas=None, with_orig=True):
+    """RGB map -> {"ORIG": [H, W, T], N_8: [N, T], ...} fp32 device tensors, keyed like :370-377.
+    color_map_rgb: uint8 numpy / tensor [H, W, 3]."""
+    rgb = torch.as_tensor(np.ascontiguousarray(color_map_rgb), dtype=torch.uint8).to(device)
+    H, W = rgb.shape[:2]
+    cols = _column_lists(table, token_lis)
+    regions = [(c[0], c[1], c[2], s) for (_, c, s) in table]
+    ratios = (8, 16, 32, 64)
+    if extra_sigmas:
+        # blurred regions need float masks (:338-340): build them on device, blur, then accumulate
+        print("Use extra sigma to smooth mask", extra_sigmas)
+        masks = []
+        for r, (_, c, s) in enumerate(table):
+            m = (rgb == torch.tensor(c, dtype=torch.uint8, device=device)).all(dim=-1).float() * s
+            if r in extra_sigmas:
+                m = gaussian_blur_mask(m, extra_sigmas[r])
+            masks.append(m)
+        masks = torch.stack(masks)
+        outs = ops.mask_build_f32(masks, cols, ratios + ((1,) if with_orig else ()))
+    else:
+        outs = ops.mask_build(rgb, regions, cols, ratios)
+        if with_orig:
+            outs.update(ops.mask_build(rgb, regions, cols, (1,)))
+    maps = {}
+    for r in ratios:
+        maps[always_round(H / r) * always_round(W / r)] = outs[r]
+    if with_orig:
+        maps["ORIG"] = outs[1].reshape(H, W, len(token_lis))
+    return maps
+
+
+def _warn_missing_colors(color_map_rgb, table):
+    """:233-234."""
+    img = np.asarray(color_map_rgb)
+    for _, color, _ in table:
+        if not (img == np.array(color, dtype=img.dtype)).all(axis=-1).any():
+            print(f"Warning : not a single color {color} not found in image")
+
+
+def _encode_text_color_inputs(text_encoder, tokenizer, device, color_map_image, color_context, input_prompt,
+                              unconditional_input_prompt, dtype=None):
+    """:315-388 with the weight maps built by the HIP mask kernel. Returns
+    (extra_seeds, seperated_word_contexts, encoder_hidden_states, uncond_encoder_hidden_states);
+    `seperated_word_contexts` is the region table [(token_ids, (r,g,b), strength)] (the reference
+    returns full-resolution float masks here; the only consumer, region seeding :451, gets what it
+    needs from the table + color map)."""
+    text_input = tokenizer([input_prompt], padding="max_length", max_length=tokenizer.model_max_length,
+                           truncation=True, return_tensors="pt")
+    color_context, extra_seeds, extra_sigmas = _extract_seed_and_sigma_from_context(color_context)
+    rgb = np.array(color_map_image.convert("RGB")) if hasattr(color_map_image, "convert") else np.asarray(color_map_image)
+    height, width = rgb.shape[:2]
+    table = _parse_regions(color_context, tokenizer)
+    token_lis = text_input["input_ids"][0].tolist()
+    keys = [always_round(height / r) * always_round(width / r) for r in (8, 16, 32, 64)]
+    if table:
+        _warn_missing_colors(rgb, table)
+        maps = build_weight_maps(rgb, table, token_lis, device, extra_sigmas)
+    else:   # empty color_context (:242-243): all-zero maps
+        maps = {k: torch.zeros((k, len(token_lis)), dtype=torch.float32, device=device) for k in keys}
+        maps["ORIG"] = torch.zeros((height, width, len(token_lis)), dtype=torch.float32, device=device)
+
+    cond_embeddings = text_encoder(text_input.input_ids.to(device))[0]
+    uncond_input = tokenizer([unconditional_input_prompt], padding="max_length",
+                             max_length=text_input.input_ids.shape[-1], return_tensors="pt")
+    uncond_embeddings = text_encoder(uncond_input.input_ids.to(device))[0]
+    if dtype is not None:
+        cond_embeddings, uncond_embeddings = cond_embeddings.to(dtype), uncond_embeddings.to(dtype)
+
+    encoder_hidden_states = {"CONTEXT_TENSOR": cond_embeddings, "CROSS_ATTENTION_WEIGHT_ORIG": maps["ORIG"]}
+    uncond_encoder_hidden_states = {"CONTEXT_TENSOR": uncond_embeddings, "CROSS_ATTENTION_WEIGHT_ORIG": 0}
+    for k in keys:
+        encoder_hidden_states[f"CROSS_ATTENTION_WEIGHT_{k}"] = maps[k]
+        uncond_encoder_hidden_states[f"CROSS_ATTENTION_WEIGHT_{k}"] = 0
+    return extra_seeds, (table, rgb), encoder_hidden_states, uncond_encoder_hidden_states
+
+
+def _get_binary_mask(table_rgb, extra_seeds, dtype, size):
+    """:300-304: per seeded region, (mask > 0) bilinearly resized (align_corners=False) to `size`."""
+    table, rgb = table_rgb
+    img = torch.as_tensor(rgb)
+    out = []
+    for k in extra_seeds.keys():
+        _, color, strength = table[k]
+        m = ((img == torch.tensor(color, dtype=img.dtype)).all(dim=-1).float() * strength > 0).to(dtype)
+        out.append(F.interpolate(m[None, None], size=size, mode="bilinear"))
+    return out

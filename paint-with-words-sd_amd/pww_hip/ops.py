@@ -1,0 +1,190 @@
+"""Torch-facing wrappers of the C ABI: tensors in, tensors out, launched on torch's current stream.
+
+PyTorch here is plumbing (device memory from the caching allocator, the current HIP stream, dtype /
+stride bookkeeping); all arithmetic happens in libpww_hip.so. Every function requires tensors on a
+HIP device and raises if the library is missing -- there is no fallback path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import AttnDesc, Region, PwwHipError
+
+_DT = {torch.float16: _lib.DTYPE_F16, torch.bfloat16: _lib.DTYPE_BF16}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise PwwHipError("pww_hip ops need tensors on a HIP device (got %s); there is no CPU path" % t.device)
+
+
+def _rows_ok(t):
+    """last dim contiguous, rows 16-byte aligned"""
+    return t.stride(-1) == 1 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0 and t.data_ptr() % 16 == 0
+
+
+def _desc(q, k, v, o, heads, scale):
+    B, N, C = q.shape
+    M = k.shape[1]
+    if C % heads:
+        raise PwwHipError("channels %d not divisible by heads %d" % (C, heads))
+    D = C // heads
+    d = AttnDesc()
+    d.dtype = _DT[q.dtype]
+    d.B, d.H, d.N, d.M, d.D = B, heads, N, M, D
+    d.q_stride[:] = [q.stride(0), D, q.stride(1)]
+    d.k_stride[:] = [k.stride(0), D, k.stride(1)]
+    if v is not None:
+        d.v_stride[:] = [v.stride(0), D, v.stride(1)]
+    if o is not None:
+        d.o_stride[:] = [o.stride(0), D, o.stride(1)]
+    d.scale = float(scale)
+    return d
+
+
+def _prep(t):
+    if t.dtype not in _DT:
+        raise PwwHipError("dtype %s unsupported (float16 / bfloat16)" % t.dtype)
+    return t if _rows_ok(t) else t.contiguous()
+
+
+def attention(q, k, v, heads, scale, bias=None, bias_coeff=None):
+    """softmax((Q K^T + c * bias) * scale) V on [B, tokens, heads*D] tensors (diffusers layout, no
+    head-split copies). bias: fp32 tensor broadcastable to [B, heads, N, M] or None;
+    bias_coeff: optional fp32 [B] device tensor of per-image coefficients."""
+    _require_gpu(q, k, v, bias, bias_coeff)
+    if not (q.dtype == k.dtype == v.dtype):
+        raise PwwHipError("q/k/v dtypes differ: %s %s %s" % (q.dtype, k.dtype, v.dtype))
+    q, k, v = _prep(q), _prep(k), _prep(v)
+    B, N, C = q.shape
+    M = k.shape[1]
+    out = torch.empty((B, N, C), dtype=q.dtype, device=q.device)
+    d = _desc(q, k, v, out, heads, scale)
+    lib = _lib.load()
+    with torch.cuda.device(q.device):
+        if bias is None:
+            rc = lib.pww_self_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), ctypes.byref(d), _stream())
+            _lib.check(rc, "pww_self_attn_fwd")
+        else:
+            if bias.dtype != torch.float32:
+                bias = bias.float()
+            if bias.dim() == 3 and bias.shape[0] == B * heads and B * heads != 1:
+                bias = bias.reshape(B, heads, bias.shape[1], bias.shape[2])
+            bias = torch.broadcast_to(bias, (B, heads, N, M))  # view: broadcast axes get stride 0
+            d.bias_stride[:] = list(bias.stride())
+            if bias_coeff is not None:
+                bias_coeff = bias_coeff.to(torch.float32).reshape(-1).contiguous()
+                if bias_coeff.numel() == 1 and B > 1:
+                    bias_coeff = bias_coeff.expand(B).contiguous()
+                if bias_coeff.numel() != B:
+                    raise PwwHipError("bias_coeff must have B=%d elements" % B)
+            rc = lib.pww_cross_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(bias), _ptr(bias_coeff),
+                                        ctypes.byref(d), _stream())
+            _lib.check(rc, "pww_cross_attn_fwd")
+    return out
+
+
+def qk_stats(q, k, heads):
+    """Per-image statistics of the raw scores Q K^T over heads x rows x keys: float64 [B, 4] =
+    (max, min, sum, sum of squares). q: [B, N, heads*D], k: [B, M, heads*D]."""
+    _require_gpu(q, k)
+    q, k = _prep(q), _prep(k)
+    stats = torch.empty((q.shape[0], 4), dtype=torch.float64, device=q.device)
+    d = _desc(q, k, None, None, heads, 1.0)
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.load().pww_qk_reduce(_ptr(q), _ptr(k), ctypes.byref(d), _ptr(stats), _stream()),
+                   "pww_qk_reduce")
+    return stats
+
+
+def _regions_tensor(regions, device):
+    """[(r, g, b, strength)] -> device byte tensor laid out as struct pww_region[R]."""
+    arr = (Region * len(regions))()
+    for i, (r, g, b, s) in enumerate(regions):
+        arr[i] = Region(int(r), int(g), int(b), 0, float(s))
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+    return raw.to(device)
+
+
+def _csr(cols, device):
+    ptr, reg = [0], []
+    for lst in cols:
+        reg.extend(int(x) for x in lst)
+        ptr.append(len(reg))
+    col_ptr = torch.tensor(ptr, dtype=torch.int32).to(device)
+    col_reg = torch.tensor(reg if reg else [0], dtype=torch.int32).to(device)
+    return col_ptr, col_reg
+
+
+def round_half_up_div(a, ratio):
+    return (2 * a + ratio) // (2 * ratio)
+
+
+def mask_build(rgb, regions, cols, ratios=(8, 16, 32, 64)):
+    """RGB color map (uint8 [H, W, 3] device tensor) -> {ratio: fp32 [Hr*Wr, T]} token weight maps.
+    regions: [(r, g, b, strength)]; cols: per prompt position, the region ordinals added to it."""
+    _require_gpu(rgb)
+    if rgb.dtype != torch.uint8 or rgb.dim() != 3 or rgb.shape[2] != 3:
+        raise PwwHipError("rgb must be uint8 [H, W, 3]")
+    rgb = rgb.contiguous()
+    H, W = rgb.shape[:2]
+    T = len(cols)
+    dev = rgb.device
+    regs = _regions_tensor(regions, dev)
+    col_ptr, col_reg = _csr(cols, dev)
+    outs = {r: torch.empty((round_half_up_div(H, r) * round_half_up_div(W, r), T), dtype=torch.float32, device=dev)
+            for r in ratios}
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        if tuple(ratios) == (8, 16, 32, 64):
+            rc = lib.pww_mask_build(_ptr(rgb), H, W, _ptr(regs), len(regions), _ptr(col_ptr), _ptr(col_reg), T,
+                                    _ptr(outs[8]), _ptr(outs[16]), _ptr(outs[32]), _ptr(outs[64]), _stream())
+            _lib.check(rc, "pww_mask_build")
+        else:
+            for r in ratios:
+                rc = lib.pww_mask_build_rgb(_ptr(rgb), H, W, _ptr(regs), len(regions), _ptr(col_ptr), _ptr(col_reg),
+                                            T, r, _ptr(outs[r]), _stream())
+                _lib.check(rc, "pww_mask_build_rgb")
+    return outs
+
+
+def mask_build_f32(masks, cols, ratios=(8, 16, 32, 64)):
+    """Same accumulation from R float32 region masks [R, H, W] (strength-scaled, possibly blurred)."""
+    _require_gpu(masks)
+    masks = masks.to(torch.float32).contiguous()
+    R, H, W = masks.shape
+    T = len(cols)
+    dev = masks.device
+    col_ptr, col_reg = _csr(cols, dev)
+    outs = {}
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        for r in ratios:
+            out = torch.empty((round_half_up_div(H, r) * round_half_up_div(W, r), T), dtype=torch.float32, device=dev)
+            rc = lib.pww_mask_build_f32(_ptr(masks), H, W, R, _ptr(col_ptr), _ptr(col_reg), T, r, _ptr(out), _stream())
+            _lib.check(rc, "pww_mask_build_f32")
+            outs[r] = out
+    return outs
+
+
+def cfg_combine(cond, uncond, guidance_scale):
+    """uncond + g * (cond - uncond) in fp32 (returns fp32)."""
+    _require_gpu(cond, uncond)
+    if cond.dtype != uncond.dtype or cond.dtype not in _DT or cond.shape != uncond.shape:
+        raise PwwHipError("cfg_combine needs two same-shape float16/bfloat16 tensors")
+    cond, uncond = cond.contiguous(), uncond.contiguous()
+    out = torch.empty(cond.shape, dtype=torch.float32, device=cond.device)
+    with torch.cuda.device(cond.device):
+        _lib.check(_lib.load().pww_cfg_combine(_ptr(cond), _ptr(uncond), float(guidance_scale), _ptr(out),
+                                               cond.numel(), _DT[cond.dtype], _stream()), "pww_cfg_combine")
+    return out

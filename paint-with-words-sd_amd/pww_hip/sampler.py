@@ -1,0 +1,172 @@
+"""Denoising driver around the HIP attention path (reference loop: paint_with_words/paint_with_words.py
+:431-506; inpaint variant paint_with_words_inpaint.py:230-266).
+
+Three execution modes over the SAME arithmetic:
+  "eager"   two batch-1 UNet calls per step (cond dict, then uncond dict), exactly the reference's
+            call pattern (:483-499) -- the parity mode.
+  "folded"  cond and uncond rows of all images in ONE UNet call ([cond rows..., uncond rows...]); the
+            PwW bias is gated per row by the `_PWW_ROW_GATE` coefficients (kernel arg bias_coeff), and
+            the qk reductions stay per image (QKProxy).
+  "graph"   "folded", with each step's UNet call captured once into a hipGraph (torch.cuda.CUDAGraph
+            on ROCm) and replayed: at batch 1 the UNet is launch-bound (~1.5k kernels per call), so
+            replay removes the host launch cost. One graph per step index because the user's
+            weight_function bakes the step's sigma into kernel arguments as a Python float.
+"""
+import torch
+
+from . import ops
+from .attention import install
+
+ROW_GATE = "_PWW_ROW_GATE"
+
+
+def initial_latents(seed, in_channels, height, width, region_masks=None, extra_seeds=None, batch_seeds=None):
+    """:445-455. CPU generator, exactly as the reference, so results do not depend on the device or
+    the number of GPUs. `region_masks`: callable(dtype, size) -> list of [1,1,h,w] masks for the seeded
+    regions (the reference's _get_binary_mask). `batch_seeds`: one latent per seed (batched mode)."""
+    seeds = [seed] if batch_seeds is None else list(batch_seeds)
+    size = (1, in_channels, height // 8, width // 8)
+    out = []
+    for s in seeds:
+        latents = torch.randn(size, generator=torch.manual_seed(s))
+        if extra_seeds:
+            print("Use region based seeding: ", extra_seeds)
+            multi = [torch.randn(size, generator=torch.manual_seed(_s)) for _s in extra_seeds.values()]
+            masks = region_masks(latents[0].dtype, size[-2:])
+            foreground = (sum(masks) > 0).squeeze()
+            summed = sum(l * m for l, m in zip(multi, masks))
+            latents[:, :, foreground] = summed[:, :, foreground]
+        out.append(latents)
+    return torch.cat(out, dim=0)
+
+
+def _fold_context(cond, uncond, n_images, device):
+    """Build the single dict of a folded call: rows [cond x n, uncond x n]."""
+    c, u = cond["CONTEXT_TENSOR"], uncond["CONTEXT_TENSOR"]
+    c = c.expand(n_images, -1, -1) if c.shape[0] == 1 else c
+    u = u.expand(n_images, -1, -1) if u.shape[0] == 1 else u
+    folded = dict(cond)
+    folded["CONTEXT_TENSOR"] = torch.cat([c, u], dim=0).contiguous()
+    folded[ROW_GATE] = torch.cat([torch.ones(n_images), torch.zeros(n_images)]).to(device=device, dtype=torch.float32)
+    return folded
+
+
+class _GraphedUNet:
+    """Capture-once / replay-many wrapper of one folded UNet call per step index."""
+
+    def __init__(self, unet):
+        self.unet = unet
+        self.graphs = {}
+        self.pool = None
+        self.static_in = None
+        self.static_t = None
+
+    def __call__(self, key, x, t_value, context):
+        if self.static_in is None or self.static_in.shape != x.shape or self.static_in.dtype != x.dtype:
+            self.graphs.clear()
+            self.static_in = torch.empty_like(x)
+            self.static_t = torch.zeros((), dtype=torch.float32, device=x.device)
+        self.static_in.copy_(x)
+        self.static_t.fill_(float(t_value))
+        entry = self.graphs.get(key)
+        if entry is None:
+            # warm-up on a side stream (required before capture), then capture
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self.unet(self.static_in, self.static_t, encoder_hidden_states=context)
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            if self.pool is None:
+                self.pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(g, pool=self.pool):
+                out = self.unet(self.static_in, self.static_t, encoder_hidden_states=context).sample
+            entry = (g, out)
+            self.graphs[key] = entry
+        g, out = entry
+        g.replay()
+        return out
+
+
+class PwWSampler:
+    """Runs the reference's sampling loop for one or many images on one GPU."""
+
+    def __init__(self, unet, scheduler, mode="eager"):
+        if mode not in ("eager", "folded", "graph"):
+            raise ValueError("mode must be eager | folded | graph")
+        self.unet, self.scheduler, self.mode = unet, scheduler, mode
+        install(unet)
+        self._graphed = _GraphedUNet(unet) if mode == "graph" else None
+        self._graph_sig = None
+        self._static_folded = None
+
+    def _static_context(self, folded, weight_function, latents, timesteps):
+        """Captured graphs read the context tensors by ADDRESS: keep one set of static tensors alive
+        and copy each new request's values into them; rebuild the graphs when the geometry, the
+        weight function (its constants are baked into kernel arguments) or the schedule changes."""
+        def tensor_sig(d):
+            return tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in d.items() if torch.is_tensor(v)))
+        sig = (id(weight_function), tuple(latents.shape), tuple(float(t) for t in timesteps), tensor_sig(folded))
+        if sig != self._graph_sig:
+            self._graphed.graphs.clear()
+            self._graph_sig = sig
+            self._static_folded = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in folded.items()}
+        else:
+            for k, v in folded.items():
+                if torch.is_tensor(v):
+                    self._static_folded[k].copy_(v)
+        return self._static_folded
+
+    def _sigma_and_index(self, i, t):
+        sch = self.scheduler
+        ts = sch.timesteps
+        # the reference looks the index up by timestep equality (:473); PLMS repeats a timestep, so a
+        # scheduler that is not 1:1 falls back to the loop counter (SURVEY.md 8 a-note)
+        hits = (ts == t).nonzero()
+        idx = int(hits.item()) if hits.numel() == 1 else i
+        return sch.sigmas[idx], idx
+
+    @torch.no_grad()
+    def sample(self, cond, uncond, latents, timesteps, guidance_scale, weight_function, extra_channels=None,
+               on_step=None):
+        """latents: [n_images, C, h, w] already scaled by init_noise_sigma (or noised for img2img).
+        extra_channels: inpaint's cat([mask, masked_image_latents]) ([n or 1, 5, h, w]) or None."""
+        sch, unet, dev = self.scheduler, self.unet, latents.device
+        n = latents.shape[0]
+        udt = unet.dtype if hasattr(unet, "dtype") else next(unet.parameters()).dtype
+        folded = None
+        if self.mode != "eager":
+            folded = _fold_context(cond, uncond, n, dev)
+            if self._graphed is not None:
+                folded = self._static_context(folded, weight_function, latents, timesteps)
+        if extra_channels is not None and extra_channels.shape[0] != n:
+            extra_channels = extra_channels.expand(n, -1, -1, -1)
+        for i, t in enumerate(timesteps):
+            sigma, _ = self._sigma_and_index(i, t)
+            x = sch.scale_model_input(latents, t)
+            if extra_channels is not None:
+                x = torch.cat([x, extra_channels.to(x.dtype)], dim=1)
+            if self.mode == "eager":
+                eps_c, eps_u = [], []
+                for j in range(n):   # the reference is batch-1 (:445); images are independent
+                    cond.update({"SIGMA": sigma, "WEIGHT_FUNCTION": weight_function})
+                    eps_c.append(unet(x[j:j + 1], t, encoder_hidden_states=cond).sample)
+                    uncond.update({"SIGMA": sigma, "WEIGHT_FUNCTION": lambda w, sigma, qk: 0.0})
+                    eps_u.append(unet(x[j:j + 1], t, encoder_hidden_states=uncond).sample)
+                eps_c, eps_u = torch.cat(eps_c), torch.cat(eps_u)
+            else:
+                folded.update({"SIGMA": sigma, "WEIGHT_FUNCTION": weight_function})
+                x2 = torch.cat([x, x], dim=0).to(udt)
+                if self.mode == "graph":
+                    out = self._graphed(i, x2, float(t), folded)
+                else:
+                    out = unet(x2, t, encoder_hidden_states=folded).sample
+                eps_c, eps_u = out[:n], out[n:]
+            if eps_c.dtype in (torch.float16, torch.bfloat16):
+                noise_pred = ops.cfg_combine(eps_c, eps_u, guidance_scale)     # fp32, :501-503
+            else:
+                noise_pred = eps_u + guidance_scale * (eps_c - eps_u)
+            latents = sch.step(noise_pred, t, latents).prev_sample
+            if on_step is not None:
+                on_step(i, latents)
+        return latents

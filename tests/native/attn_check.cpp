@@ -1,0 +1,295 @@
+// Native parity harness for libpww_hip.so (test infrastructure; built by tests/native/Makefile,
+// run on the GPU box by tests/test_native_gpu.py). Calls the C ABI of include/pww_hip.h exactly
+// as a foreign binding would and compares every entry point with an independent fp64 host
+// reference written here (plain loops, no shared code with the kernels).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <string>
+#include <algorithm>
+#include "../../include/pww_hip.h"
+
+#define HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static inline uint32_t rng_u32() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 32); }
+static inline float rng_uniform() { return (rng_u32() >> 8) * (1.0f / 16777216.0f); }
+static inline float rng_normal() { float u1 = rng_uniform() + 1e-7f, u2 = rng_uniform(); return sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2); }
+
+static uint16_t to_bf16(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
+static float from_bf16(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static uint16_t to_f16(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
+static float from_f16(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
+static uint16_t to_t(float f, int dt) { return dt == PWW_DTYPE_F16 ? to_f16(f) : to_bf16(f); }
+static float from_t(uint16_t u, int dt) { return dt == PWW_DTYPE_F16 ? from_f16(u) : from_bf16(u); }
+
+static int g_fail = 0;
+
+struct Case {
+    const char *name; int dtype, B, H, N, M, D;
+    int bias_mode;   // 0 none, 1 [N,M] shared + coeff[B], 2 full [B,H,N,M]
+    bool self;       // K/V come from the same token set as Q (M == N)
+    int row_step;    // check every row_step-th query row
+    float qk_gain;   // scales Q so logits get a realistic spread
+};
+
+template <typename T> static T *dalloc(size_t n) { T *p; HIPCHECK(hipMalloc(&p, n * sizeof(T) + 64)); return p; }
+
+static void run_case(const Case &c, bool timing) {
+    const int B = c.B, H = c.H, N = c.N, M = c.M, D = c.D, C = H * D;
+    std::vector<uint16_t> q((size_t)B * N * C), k((size_t)B * M * C), v((size_t)B * M * C);
+    std::vector<float> qf(q.size()), kf(k.size()), vf(v.size());
+    for (size_t i = 0; i < q.size(); ++i) { q[i] = to_t(rng_normal() * c.qk_gain, c.dtype); qf[i] = from_t(q[i], c.dtype); }
+    for (size_t i = 0; i < k.size(); ++i) { k[i] = to_t(rng_normal(), c.dtype); kf[i] = from_t(k[i], c.dtype); }
+    for (size_t i = 0; i < v.size(); ++i) { v[i] = to_t(rng_normal() + 0.1f * (float)(i % 7), c.dtype); vf[i] = from_t(v[i], c.dtype); }
+    std::vector<float> bias, coeff;
+    pww_attn_desc_t d; memset(&d, 0, sizeof(d));
+    d.dtype = c.dtype; d.B = B; d.H = H; d.N = N; d.M = M; d.D = D;
+    d.q_stride[0] = (int64_t)N * C; d.q_stride[1] = D; d.q_stride[2] = C;
+    d.k_stride[0] = (int64_t)M * C; d.k_stride[1] = D; d.k_stride[2] = C;
+    d.v_stride[0] = (int64_t)M * C; d.v_stride[1] = D; d.v_stride[2] = C;
+    d.o_stride[0] = (int64_t)N * C; d.o_stride[1] = D; d.o_stride[2] = C;
+    d.scale = 1.0f / sqrtf((float)D);
+    if (c.bias_mode == 1) {
+        bias.resize((size_t)N * M); coeff.resize(B);
+        for (auto &x : bias) x = (rng_uniform() < 0.3f) ? rng_uniform() * 1.5f : 0.f;
+        for (int b = 0; b < B; ++b) coeff[b] = 2.0f + 3.0f * b;
+        d.bias_stride[0] = 0; d.bias_stride[1] = 0; d.bias_stride[2] = M; d.bias_stride[3] = 1;
+    } else if (c.bias_mode == 2) {
+        bias.resize((size_t)B * H * N * M);
+        for (auto &x : bias) x = rng_normal() * 2.f;
+        d.bias_stride[0] = (int64_t)H * N * M; d.bias_stride[1] = (int64_t)N * M; d.bias_stride[2] = M; d.bias_stride[3] = 1;
+    }
+    uint16_t *dq = dalloc<uint16_t>(q.size()), *dk = dalloc<uint16_t>(k.size()), *dv = dalloc<uint16_t>(v.size()), *dout = dalloc<uint16_t>(q.size());
+    float *dbias = nullptr, *dcoeff = nullptr;
+    HIPCHECK(hipMemcpy(dq, q.data(), q.size() * 2, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dk, k.data(), k.size() * 2, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dv, v.data(), v.size() * 2, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemset(dout, 0xff, q.size() * 2));
+    if (!bias.empty()) { dbias = dalloc<float>(bias.size()); HIPCHECK(hipMemcpy(dbias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice)); }
+    if (!coeff.empty()) { dcoeff = dalloc<float>(coeff.size()); HIPCHECK(hipMemcpy(dcoeff, coeff.data(), coeff.size() * 4, hipMemcpyHostToDevice)); }
+    double *dstats = dalloc<double>(4 * B);
+
+    int rc = c.bias_mode ? pww_cross_attn_fwd(dq, dk, dv, dout, dbias, dcoeff, &d, nullptr)
+                         : pww_self_attn_fwd(dq, dk, dv, dout, &d, nullptr);
+    if (rc) { printf("FAIL %-28s attn rc=%d err=%s\n", c.name, rc, pww_last_error()); g_fail++; return; }
+    rc = pww_qk_reduce(dq, dk, &d, dstats, nullptr);
+    if (rc) { printf("FAIL %-28s reduce rc=%d err=%s\n", c.name, rc, pww_last_error()); g_fail++; return; }
+    HIPCHECK(hipDeviceSynchronize());
+    std::vector<uint16_t> out(q.size());
+    std::vector<double> stats(4 * B);
+    HIPCHECK(hipMemcpy(out.data(), dout, out.size() * 2, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(stats.data(), dstats, stats.size() * 8, hipMemcpyDeviceToHost));
+
+    // fp64 reference on sampled rows: O = softmax((QK^T + c*bias) * scale) V
+    double max_err = 0, max_ref = 0; long nchk = 0; int nan_count = 0;
+    std::vector<double> logit(M), ref(D);
+    for (int b = 0; b < B; ++b) for (int h = 0; h < H; ++h) for (int n = 0; n < N; ++n) {
+        const bool sample = (n % c.row_step == 0) || n == N - 1 || n == (N > 33 ? 33 : 0);
+        if (!sample) continue;
+        const float *qr = &qf[((size_t)b * N + n) * C + h * D];
+        double mx = -1e300;
+        for (int m = 0; m < M; ++m) {
+            const float *kr = &kf[((size_t)b * M + m) * C + h * D];
+            double s = 0; for (int x = 0; x < D; ++x) s += (double)qr[x] * kr[x];
+            double bv = 0;
+            if (c.bias_mode == 1) bv = (double)coeff[b] * bias[(size_t)n * M + m];
+            else if (c.bias_mode == 2) bv = bias[(((size_t)b * H + h) * N + n) * M + m];
+            logit[m] = (s + bv) * (double)d.scale; mx = std::max(mx, logit[m]);
+        }
+        double den = 0; std::fill(ref.begin(), ref.end(), 0.0);
+        for (int m = 0; m < M; ++m) {
+            const double pr = exp(logit[m] - mx); den += pr;
+            const float *vr = &vf[((size_t)b * M + m) * C + h * D];
+            for (int x = 0; x < D; ++x) ref[x] += pr * vr[x];
+        }
+        for (int x = 0; x < D; ++x) {
+            const double r = ref[x] / den;
+            const float g = from_t(out[((size_t)b * N + n) * C + h * D + x], c.dtype);
+            if (!(g == g)) nan_count++;
+            max_err = std::max(max_err, fabs((double)g - r)); max_ref = std::max(max_ref, fabs(r)); nchk++;
+        }
+    }
+    const double tol = (c.dtype == PWW_DTYPE_F16 ? 2e-3 : 1.6e-2) * max_ref;
+    const bool ok_attn = nan_count == 0 && max_err <= tol;
+
+    // statistics reference over ALL rows (float accumulate of products is what the MFMA does; compare loosely)
+    bool ok_stats = true; double stat_err = 0;
+    {
+        for (int b = 0; b < B; ++b) {
+            double smax = -1e300, smin = 1e300, ssum = 0, ssq = 0;
+            const long total = (long)H * N * M;
+            const int rstep = total > 40000000L ? 16 : 1;   // subsample rows for the big shapes (max/min then compared one-sided)
+            for (int h = 0; h < H; ++h) for (int n = 0; n < N; n += rstep) {
+                const float *qr = &qf[((size_t)b * N + n) * C + h * D];
+                for (int m = 0; m < M; ++m) {
+                    const float *kr = &kf[((size_t)b * M + m) * C + h * D];
+                    double s = 0; for (int x = 0; x < D; ++x) s += (double)qr[x] * kr[x];
+                    smax = std::max(smax, s); smin = std::min(smin, s); ssum += s; ssq += s * s;
+                }
+            }
+            const double *g = &stats[4 * b];
+            if (rstep == 1) {
+                const double mag = std::max(fabs(smax), fabs(smin)) + 1e-6;
+                double e = std::max(fabs(g[0] - smax), fabs(g[1] - smin)) / mag;
+                // mean and (unbiased) std, the quantities weight_function derives from sum / sumsq
+                const double mean_r = ssum / total, var_r = total > 1 ? (ssq - ssum * ssum / total) / (total - 1) : 0.0;
+                const double mean_g = g[2] / total, var_g = total > 1 ? (g[3] - g[2] * g[2] / total) / (total - 1) : 0.0;
+                const double sd = sqrt(std::max(var_r, 0.0)) + 1e-6;
+                e = std::max(e, fabs(mean_g - mean_r) / (sd + fabs(mean_r)));
+                e = std::max(e, fabs(sqrt(std::max(var_g, 0.0)) - sqrt(std::max(var_r, 0.0))) / sd);
+                stat_err = std::max(stat_err, e);
+                if (e > 2e-3) ok_stats = false;
+            } else {
+                if (g[0] < smax - 1e-2 * fabs(smax) || g[1] > smin + 1e-2 * fabs(smin)) ok_stats = false;
+            }
+        }
+    }
+    printf("%s %-28s dtype=%s B=%d H=%d N=%d M=%d D=%d bias=%d | attn max_err=%.3e (tol %.3e, max|O|=%.3f, nan=%d, n=%ld) | stats rel_err=%.2e %s\n",
+           (ok_attn && ok_stats) ? "PASS" : "FAIL", c.name, c.dtype == PWW_DTYPE_F16 ? "f16" : "bf16", B, H, N, M, D, c.bias_mode,
+           max_err, tol, max_ref, nan_count, nchk, stat_err, ok_stats ? "ok" : "BAD");
+    if (!(ok_attn && ok_stats)) g_fail++;
+
+    if (timing) {
+        hipEvent_t e0, e1; HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+        const int iters = 50;
+        for (int i = 0; i < 5; ++i) c.bias_mode ? pww_cross_attn_fwd(dq, dk, dv, dout, dbias, dcoeff, &d, nullptr) : pww_self_attn_fwd(dq, dk, dv, dout, &d, nullptr);
+        HIPCHECK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) c.bias_mode ? pww_cross_attn_fwd(dq, dk, dv, dout, dbias, dcoeff, &d, nullptr) : pww_self_attn_fwd(dq, dk, dv, dout, &d, nullptr);
+        HIPCHECK(hipEventRecord(e1, nullptr)); HIPCHECK(hipEventSynchronize(e1));
+        float ms = 0; HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / iters, flops = 4.0 * B * H * (double)N * M * D;
+        HIPCHECK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) pww_qk_reduce(dq, dk, &d, dstats, nullptr);
+        HIPCHECK(hipEventRecord(e1, nullptr)); HIPCHECK(hipEventSynchronize(e1));
+        float ms2 = 0; HIPCHECK(hipEventElapsedTime(&ms2, e0, e1));
+        printf("TIME %-28s attn %.2f us/call  %.1f TFLOP/s (algorithmic 4BHNMD) | qk_reduce %.2f us/call\n", c.name, us, flops / us * 1e-6, ms2 * 1e3 / iters);
+    }
+    hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dout); hipFree(dstats); if (dbias) hipFree(dbias); if (dcoeff) hipFree(dcoeff);
+}
+
+// ---- mask build ------------------------------------------------------------------------------
+static int round_half_up_div(int a, int r) { return (int)floor((double)a / r + 0.5); }
+
+static void check_mask() {
+    const int H = 512, W = 384, T = 77, R = 5;
+    std::vector<uint8_t> rgb((size_t)H * W * 3);
+    pww_region_t regs[R] = {{0, 0, 0, 0, 1.0f}, {255, 255, 255, 0, 1.0f}, {13, 255, 0, 0, 1.5f}, {90, 206, 255, 0, 0.2f}, {74, 18, 1, 0, 0.2f}};
+    for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) {
+        int r = ((x / 37) + (y / 53) * 3) % (R + 1);   // region R = unmatched colour
+        uint8_t *p = &rgb[((size_t)y * W + x) * 3];
+        if (r < R) { p[0] = regs[r].r; p[1] = regs[r].g; p[2] = regs[r].b; } else { p[0] = 1; p[1] = 2; p[2] = 3; }
+    }
+    // columns: region 0 -> {5}, region 1 -> {7,8}, region 2 -> {9, 7 (overlap)}, region 3 -> {13}, region 4 -> {13 again twice}
+    std::vector<std::vector<int>> cols(T);
+    cols[5] = {0}; cols[7] = {1, 2}; cols[8] = {1}; cols[9] = {2}; cols[13] = {3, 4, 4};
+    std::vector<int32_t> col_ptr(T + 1, 0), col_reg;
+    for (int t = 0; t < T; ++t) { col_ptr[t] = (int)col_reg.size(); for (int r : cols[t]) col_reg.push_back(r); }
+    col_ptr[T] = (int)col_reg.size();
+    uint8_t *drgb = dalloc<uint8_t>(rgb.size()); pww_region_t *dregs = dalloc<pww_region_t>(R);
+    int32_t *dptr = dalloc<int32_t>(T + 1), *dreg = dalloc<int32_t>(col_reg.size() + 1);
+    HIPCHECK(hipMemcpy(drgb, rgb.data(), rgb.size(), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dregs, regs, sizeof(regs), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dptr, col_ptr.data(), (T + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dreg, col_reg.data(), col_reg.size() * 4, hipMemcpyHostToDevice));
+    const int ratios[4] = {8, 16, 32, 64};
+    float *douts[4]; size_t npix[4]; int Hr[4], Wr[4];
+    for (int i = 0; i < 4; ++i) { Hr[i] = round_half_up_div(H, ratios[i]); Wr[i] = round_half_up_div(W, ratios[i]); npix[i] = (size_t)Hr[i] * Wr[i]; douts[i] = dalloc<float>(npix[i] * T); HIPCHECK(hipMemset(douts[i], 0xff, npix[i] * T * 4)); }
+    int rc = pww_mask_build(drgb, H, W, dregs, R, dptr, dreg, T, douts[0], douts[1], douts[2], douts[3], nullptr);
+    if (rc) { printf("FAIL mask_build rc=%d err=%s\n", rc, pww_last_error()); g_fail++; return; }
+    HIPCHECK(hipDeviceSynchronize());
+    for (int i = 0; i < 4; ++i) {
+        std::vector<float> got(npix[i] * T); HIPCHECK(hipMemcpy(got.data(), douts[i], got.size() * 4, hipMemcpyDeviceToHost));
+        const float sy = Hr[i] > 1 ? (float)(H - 1) / (float)(Hr[i] - 1) : 0.f, sx = Wr[i] > 1 ? (float)(W - 1) / (float)(Wr[i] - 1) : 0.f;
+        double max_err = 0; long mism = 0; double checksum = 0;
+        for (int oy = 0; oy < Hr[i]; ++oy) for (int ox = 0; ox < Wr[i]; ++ox) {
+            volatile float fy = sy * (float)oy, fx = sx * (float)ox;
+            const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+            volatile float ly = fy - (float)y0, lx = fx - (float)x0; volatile float hy = 1.f - ly, hx = 1.f - lx;
+            float val[R];
+            for (int r = 0; r < R; ++r) {
+                auto tap = [&](int y, int x) { const uint8_t *p = &rgb[((size_t)y * W + x) * 3]; return (p[0] == regs[r].r && p[1] == regs[r].g && p[2] == regs[r].b) ? regs[r].strength : 0.f; };
+                volatile float a = tap(y0, x0) * hx, b2 = tap(y0, x1) * lx, c2 = tap(y1, x0) * hx, d2 = tap(y1, x1) * lx;
+                volatile float top = a + b2, bot = c2 + d2; volatile float t1 = top * hy, t2 = bot * ly; val[r] = t1 + t2;
+            }
+            for (int t = 0; t < T; ++t) {
+                volatile float acc = 0.f; for (int r : cols[t]) acc = acc + val[r];
+                const float g = got[((size_t)oy * Wr[i] + ox) * T + t];
+                if (g != acc) mism++; max_err = std::max(max_err, (double)fabsf(g - acc)); checksum += g;
+            }
+        }
+        const bool ok = mism == 0;
+        printf("%s mask_build ratio=%d out=%dx%d bit-mismatches=%ld max_err=%.3e checksum=%.4f\n", ok ? "PASS" : "FAIL", ratios[i], Hr[i], Wr[i], mism, max_err, checksum);
+        if (!ok) g_fail++;
+    }
+}
+
+static void check_cfg() {
+    const long n = 4 * 64 * 64 + 3;
+    std::vector<uint16_t> c(n), u(n); std::vector<float> ref(n);
+    for (long i = 0; i < n; ++i) { c[i] = to_bf16(rng_normal()); u[i] = to_bf16(rng_normal()); volatile float d = from_bf16(c[i]) - from_bf16(u[i]); volatile float m = 7.5f * d; ref[i] = from_bf16(u[i]) + m; }
+    uint16_t *dc = dalloc<uint16_t>(n), *du = dalloc<uint16_t>(n); float *dout = dalloc<float>(n);
+    HIPCHECK(hipMemcpy(dc, c.data(), n * 2, hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(du, u.data(), n * 2, hipMemcpyHostToDevice));
+    int rc = pww_cfg_combine(dc, du, 7.5f, dout, n, PWW_DTYPE_BF16, nullptr);
+    HIPCHECK(hipDeviceSynchronize());
+    std::vector<float> got(n); HIPCHECK(hipMemcpy(got.data(), dout, n * 4, hipMemcpyDeviceToHost));
+    long mism = 0; for (long i = 0; i < n; ++i) if (got[i] != ref[i]) mism++;
+    printf("%s cfg_combine rc=%d mismatches=%ld\n", (rc == 0 && mism == 0) ? "PASS" : "FAIL", rc, mism);
+    if (rc || mism) g_fail++;
+}
+
+static void check_errors() {
+    pww_attn_desc_t d; memset(&d, 0, sizeof(d));
+    d.dtype = PWW_DTYPE_F16; d.B = 1; d.H = 1; d.N = 32; d.M = 32; d.D = 36; d.scale = 1.f;
+    for (int i = 0; i < 3; ++i) { d.q_stride[i] = d.k_stride[i] = d.v_stride[i] = d.o_stride[i] = 40; }
+    uint16_t *p = dalloc<uint16_t>(4096);
+    int rc1 = pww_self_attn_fwd(p, p, p, p, &d, nullptr);           // D not a multiple of 8
+    d.D = 200; int rc2 = pww_self_attn_fwd(p, p, p, p, &d, nullptr);  // D too large
+    d.D = 40; int rc3 = pww_self_attn_fwd(nullptr, p, p, p, &d, nullptr);
+    d.dtype = 7; int rc4 = pww_self_attn_fwd(p, p, p, p, &d, nullptr);
+    const bool ok = rc1 == PWW_ENOTSUP && rc2 == PWW_ENOTSUP && rc3 == PWW_EINVAL && rc4 == PWW_ENOTSUP && strlen(pww_last_error()) > 0;
+    printf("%s error codes: %d %d %d %d last='%s'\n", ok ? "PASS" : "FAIL", rc1, rc2, rc3, rc4, pww_last_error());
+    if (!ok) g_fail++;
+    hipFree(p);
+}
+
+int main(int argc, char **argv) {
+    const bool quick = argc > 1 && !strcmp(argv[1], "--quick");
+    char arch[64] = ""; int rc = pww_device_arch(arch, sizeof(arch));
+    printf("libpww_hip version %d, device arch '%s' (rc=%d)\n", pww_version(), arch, rc);
+    std::vector<Case> cases = {
+        {"tiny_self_d40", PWW_DTYPE_F16, 1, 1, 32, 32, 40, 0, true, 1, 1.0f},
+        {"tiny_self_d40_bf16", PWW_DTYPE_BF16, 1, 1, 32, 32, 40, 0, true, 1, 1.0f},
+        {"one_row_one_key", PWW_DTYPE_F16, 1, 2, 1, 1, 64, 0, false, 1, 1.0f},
+        {"m64_exact", PWW_DTYPE_F16, 1, 2, 70, 64, 64, 0, false, 1, 1.0f},
+        {"m65_ragged", PWW_DTYPE_BF16, 2, 3, 100, 65, 64, 2, false, 1, 1.0f},
+        {"sd15_mid_self_n64_d160", PWW_DTYPE_F16, 2, 8, 64, 64, 160, 0, true, 1, 0.5f},
+        {"sd15_mid_cross_n64_d160", PWW_DTYPE_BF16, 2, 8, 64, 77, 160, 1, false, 1, 0.5f},
+        {"sd15_self_n256_d160", PWW_DTYPE_BF16, 2, 8, 256, 256, 160, 0, true, 3, 0.5f},
+        {"sd15_cross_n256_d160", PWW_DTYPE_F16, 1, 8, 256, 77, 160, 1, false, 3, 0.5f},
+        {"sd15_self_n1024_d80", PWW_DTYPE_F16, 1, 8, 1024, 1024, 80, 0, true, 17, 0.7f},
+        {"sd15_cross_n1024_d80", PWW_DTYPE_BF16, 2, 8, 1024, 77, 80, 1, false, 17, 0.7f},
+        {"sd15_self_n4096_d40", PWW_DTYPE_BF16, 1, 8, 4096, 4096, 40, 0, true, 97, 1.0f},
+        {"sd15_self_n4096_d40_f16_b2", PWW_DTYPE_F16, 2, 8, 4096, 4096, 40, 0, true, 193, 1.0f},
+        {"sd15_cross_n4096_d40", PWW_DTYPE_BF16, 2, 8, 4096, 77, 40, 1, false, 97, 1.0f},
+        {"sd15_cross_fullbias_n4096", PWW_DTYPE_F16, 1, 8, 4096, 77, 40, 2, false, 97, 1.0f},
+        {"sd21_self_n2304_d64", PWW_DTYPE_BF16, 1, 10, 2304, 2304, 64, 0, true, 61, 0.8f},
+        {"d96_n200_m130", PWW_DTYPE_F16, 1, 2, 200, 130, 96, 2, false, 1, 0.6f},
+        {"d128_n130_m200", PWW_DTYPE_BF16, 1, 2, 130, 200, 128, 0, false, 1, 0.6f},
+        {"d48_n33_m1", PWW_DTYPE_F16, 1, 1, 33, 1, 48, 0, false, 1, 1.0f},
+    };
+    for (auto &c : cases) {
+        const bool big = (long)c.N * c.M >= 1024L * 1024L || c.N >= 4096;
+        if (quick && big) continue;
+        run_case(c, big);
+    }
+    check_mask();
+    check_cfg();
+    check_errors();
+    printf("%s: %d failure(s)\n", g_fail ? "NATIVE CHECK FAILED" : "NATIVE CHECK OK", g_fail);
+    return g_fail ? 1 : 0;
+}
