@@ -1,0 +1,251 @@
+#!/usr/bin/env python
+"""bench.py -- SD1.5 + Paint-with-Words images/sec on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: every rank generates `--batch` 512x512 images
+(each: mask build + conditioning, 30 PLMS steps x {cond, uncond} UNet forward with the fused PwW
+attention, CFG 7.5) up to the final latent (the quantity parity is checked on; the VAE decode sits
+outside the path and outside the timed region, like in the reference's own it/s numbers).
+Workload = BASELINE.json configs[1]: SD1.5 topology random-init (seed 1234) bf16, example_input.png
+5-region mask (runner.py:9-20), weight_function 0.4*w*log(1+sigma)*qk.max() (runner.py:104).
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  "roofline"     dominant kernel (self-attention N=4096 d=40) TFLOP/s vs the dense bf16 MFMA peak,
+                 timed live with HIP events on the launch stream in an instrumented pass;
+  "cpu_baseline" the CPU oracle (port of the reference path) timed on this box's host cores on a
+                 bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, "paint-with-words-sd_amd")
+for p in (PKG, REPO, os.path.join(REPO, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+_T0 = time.time()
+
+
+def log(*a):
+    if os.environ.get("PWW_BENCH_VERBOSE", "1") == "1":
+        print("[bench %7.1fs]" % (time.time() - _T0), *a, file=sys.stderr, flush=True)
+
+
+MFMA_PEAK_TFLOPS = 2500.0     # dense bf16/f16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def weight_function(w, sigma, qk):          # runner.py:104
+    return 0.4 * w * math.log(1 + sigma) * qk.max()
+
+
+def build_tools(device, dtype, scheduler_name, rank, world, inpaint=False):
+    """SD1.5-topology UNet built on rank 0 from seed 1234 and broadcast over RCCL; small stand-ins for
+    text encoder / tokenizer / VAE (outside the hot path)."""
+    from sd_standin import (build_unet, SD15_CONFIG, SD15_INPAINT_CONFIG, HashTokenizer, TinyTextEncoder, TinyVAE,
+                            LMSDiscreteScheduler, PLMSScheduler, UNet2DConditionModel)
+    from pww_hip import dist as pdist
+    cfg = SD15_INPAINT_CONFIG if inpaint else SD15_CONFIG
+    t0 = time.time()
+    if rank == 0:
+        unet = build_unet(cfg, seed=1234, dtype=dtype, device=device, qk_gain=2.0)
+    else:   # structure only; values arrive by broadcast
+        with torch.device("meta"):
+            unet = UNet2DConditionModel(**cfg)
+        unet = unet.to_empty(device=device).to(dtype).eval().requires_grad_(False)
+    t1 = time.time()
+    nbytes = pdist.broadcast_module(unet, src=0)
+    if world > 1:
+        torch.cuda.synchronize()
+    t2 = time.time()
+    text = TinyTextEncoder(cfg["cross_attention_dim"], seed=1235).to(device=device, dtype=dtype)
+    vae = TinyVAE(4, seed=1236).to(device=device, dtype=dtype)
+    sched = (PLMSScheduler() if scheduler_name == "plms" else
+             LMSDiscreteScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000))
+    info = {"build_s": round(t1 - t0, 2), "broadcast_s": round(t2 - t1, 4), "broadcast_bytes": int(nbytes)}
+    return (vae, unet, text, HashTokenizer(), sched), info
+
+
+class EventTimer:
+    """HIP-event timing of selected kernel launches on the stream they are launched on."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def wrap(self, fn, select):
+        def wrapped(q, k, v, heads, scale, bias=None, bias_coeff=None):
+            if not select(q, k, bias):
+                return fn(q, k, v, heads, scale, bias=bias, bias_coeff=bias_coeff)
+            s = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            out = fn(q, k, v, heads, scale, bias=bias, bias_coeff=bias_coeff)
+            e1.record(s)
+            self.pairs.append((e0, e1, q.shape[0]))
+            return out
+        return wrapped
+
+    def mean_us(self):
+        torch.cuda.synchronize()
+        ts = [a.elapsed_time(b) * 1e3 for a, b, _ in self.pairs]
+        return (sum(ts) / len(ts), len(ts), self.pairs[0][2]) if ts else (None, 0, 0)
+
+
+def cpu_baseline(args, rgb, context, prompt, n_denoise_steps):
+    """The oracle (CPU port of the reference path, fp32) on the host cores: a bounded sample of the same
+    workload -- `--cpu-steps` denoise steps (2 UNet forwards each) of the SD1.5-size loop."""
+    from oracle import pww_oracle as O
+    import pww_cases as cases
+    log("cpu baseline: building fp32 UNet")
+    vae, unet, text, tok, sch = cases.build_tools("sd15", dtype=torch.float32, device="cpu", scheduler="lms", qk_gain=2.0)
+    O.install_oracle_attention(unet)
+    try:
+        seeds, regions, cond, uncond = O.encode_text_color_inputs(text, tok, rgb, dict(context), prompt, "")
+        latents = O.initial_latents(0, 4, rgb.shape[0], rgb.shape[1])
+        sch.set_timesteps(n_denoise_steps)
+        latents = latents * sch.init_noise_sigma
+        times = []
+        for i, t in enumerate(sch.timesteps[: args.cpu_steps]):
+            t0 = time.perf_counter()
+            sigma = sch.sigmas[i]
+            x = sch.scale_model_input(latents, t)
+            cond.update({"SIGMA": sigma, "WEIGHT_FUNCTION": weight_function})
+            ec = unet(x, t, encoder_hidden_states=cond).sample
+            uncond.update({"SIGMA": sigma, "WEIGHT_FUNCTION": lambda w, sigma, qk: 0.0})
+            eu = unet(x, t, encoder_hidden_states=uncond).sample
+            latents = sch.step(O.cfg_combine(ec, eu, 7.5), t, latents).prev_sample
+            times.append(time.perf_counter() - t0)
+            log("cpu baseline step", i, "%.2f s" % times[-1])
+    finally:
+        from sd_standin import CrossAttention
+        if "__call__" in CrossAttention.__dict__:
+            del CrossAttention.__call__
+    per_step = float(np.mean(times))
+    unet_evals = n_denoise_steps + (1 if args.scheduler == "plms" else 0)
+    return {"value": round(1.0 / (per_step * unet_evals), 6), "unit": "images/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "%d of %d denoise steps (2 fp32 UNet forwards each, oracle attention) of the same 512x512 SD1.5 "
+                      "workload, %.2f s/step, extrapolated to %d steps" % (len(times), unet_evals, per_step, unet_evals)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4, help="timed steps (one step = one batch of images per GPU)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--mode", default="graph", choices=["eager", "folded", "graph"])
+    ap.add_argument("--scheduler", default="plms", choices=["plms", "lms"])
+    ap.add_argument("--denoise-steps", type=int, default=30)
+    ap.add_argument("--guidance", type=float, default=7.5)
+    ap.add_argument("--cpu-steps", type=int, default=2, help="denoise steps timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--no-roofline-pass", action="store_true")
+    args = ap.parse_args()
+
+    from pww_hip import dist as pdist, ops
+    import pww_hip
+    import pww_cases as cases
+    from pww_hip.conditioning import _encode_text_color_inputs
+    from pww_hip.sampler import PwWSampler, initial_latents
+
+    rank, world, local = pdist.init_from_env("cuda")
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    pww_hip.load_library()
+
+    log("cpu_count", os.cpu_count(), "torch threads", torch.get_num_threads(), "rank", rank, "world", world)
+    tools, build_info = build_tools(device, dtype, args.scheduler, rank, world)
+    log("tools built", build_info)
+    vae, unet, text, tok, sched = tools
+    sampler = PwWSampler(unet, sched, args.mode)
+
+    # request: rank 0 owns the color map; every rank builds its weight maps with the HIP mask kernel
+    payload = {"rgb": cases.load_example_rgb(), "context": dict(cases.RUNNER_CONTEXT), "prompt": cases.RUNNER_PROMPT} if rank == 0 else None
+    t0 = time.time()
+    payload = pdist.broadcast_request(payload, device, src=0)
+    req_bcast_s = time.time() - t0
+    rgb, context, prompt = payload["rgb"], payload["context"], payload["prompt"]
+    H, W = rgb.shape[:2]
+    n_global = args.batch * world
+
+    def one_step(step_idx):
+        """mask build + conditioning + full denoise loop for this rank's images of global step `step_idx`."""
+        _, _, cond, uncond = _encode_text_color_inputs(text, tok, device, rgb, dict(context), prompt, "", dtype=dtype)
+        seeds = pdist.image_seeds(step_idx * n_global, n_global, rank, world)
+        sched.set_timesteps(args.denoise_steps)
+        lat = initial_latents(0, unet.in_channels, H, W, batch_seeds=seeds).to(device) * sched.init_noise_sigma
+        return sampler.sample(cond, uncond, lat, sched.timesteps, args.guidance, weight_function)
+
+    for w in range(args.warmup):
+        one_step(w)
+        torch.cuda.synchronize()
+        log("warmup step", w, "done")
+    pdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        lat = one_step(args.warmup + s)
+    pdist.barrier()
+    torch.cuda.synchronize()
+    elapsed = pdist.max_over_ranks(time.perf_counter() - t0, device)
+    assert torch.isfinite(lat).all(), "non-finite latents"
+    log("timed region done: %.3f s for %d steps" % (elapsed, args.steps))
+
+    images = args.steps * n_global
+    result = {
+        "metric": "512x512 images/sec (30 steps, CFG) SD1.5+PwW", "value": round(images / elapsed, 4), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: SD1.5 UNet topology random-init (seed 1234), 512x512, %d %s steps "
+                               "(%d UNet evaluations x {cond,uncond}), CFG %.1f, 5-region example_input.png mask, "
+                               "batch %d per GPU, final latent (VAE decode excluded)"
+                               % (args.denoise_steps, args.scheduler.upper(), len(sched.timesteps), args.guidance, args.batch),
+                   "mode": args.mode, "images_per_step": n_global, "parallelism": "image-sharded x%d, no data-path collective" % world,
+                   "weight_broadcast": build_info, "request_broadcast_s": round(req_bcast_s, 4)},
+    }
+
+    if rank == 0 and not args.no_roofline_pass:
+        # instrumented pass (same workload, folded mode so single launches can be bracketed by HIP events
+        # on the launch stream): dominant kernel = self-attention at N = 4096, d = 40
+        timer = EventTimer()
+        orig = ops.attention
+        ops.attention = timer.wrap(orig, lambda q, k, bias: bias is None and q.shape[1] == (H // 8) * (W // 8) and k.shape[1] == q.shape[1])
+        try:
+            s2 = PwWSampler(unet, sched, "folded")
+            _, _, cond, uncond = _encode_text_color_inputs(text, tok, device, rgb, dict(context), prompt, "", dtype=dtype)
+            sched.set_timesteps(args.denoise_steps)
+            lat0 = initial_latents(0, unet.in_channels, H, W, batch_seeds=list(range(args.batch))).to(device) * sched.init_noise_sigma
+            s2.sample(cond, uncond, lat0, sched.timesteps, args.guidance, weight_function)
+        finally:
+            ops.attention = orig
+        us, n_launch, b_rows = timer.mean_us()
+        log("roofline pass done", us, n_launch)
+        if us:
+            heads, n_tok, d = 8, (H // 8) * (W // 8), 40
+            flops = 4.0 * b_rows * heads * n_tok * n_tok * d      # algorithmic: QK^T + PV
+            ach = flops / (us * 1e-6) / 1e12
+            result["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel<%s, d=40> self-attention N=%d (B=%d rows folded)" % (args.dtype, n_tok, b_rows),
+                                  "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                                  "traffic": None, "avg_us": round(us, 2), "launches": n_launch, "flops_per_launch": flops}
+    if rank == 0 and world == 1 and args.cpu_steps > 0:
+        result["cpu_baseline"] = cpu_baseline(args, rgb, context, prompt, args.denoise_steps)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

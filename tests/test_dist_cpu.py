@@ -1,0 +1,73 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercise the sharding / broadcast / gather plumbing
+of pww_hip.dist (the data path itself has no collective: images are independent)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "paint-with-words-sd_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from pww_hip import dist as pdist
+    from sd_standin import build_unet, TINY_CONFIG
+    r, w, _ = pdist.init_from_env("cpu")
+    assert (r, w) == (rank, world)
+    dev = torch.device("cpu")
+    # (a) weights: rank 0 has the seeded model, the others garbage; one flat broadcast per dtype
+    unet = build_unet(TINY_CONFIG, seed=1234 if rank == 0 else 999)
+    nbytes = pdist.broadcast_module(unet, src=0)
+    ref = build_unet(TINY_CONFIG, seed=1234)
+    assert nbytes == sum(p.numel() * p.element_size() for p in ref.parameters())
+    for a, b in zip(unet.parameters(), ref.parameters()):
+        assert torch.equal(a, b)
+    # (b) request broadcast: color map + region table
+    payload = None
+    if rank == 0:
+        rgb = (np.arange(64 * 48 * 3) % 251).astype(np.uint8).reshape(64, 48, 3)
+        payload = {"rgb": rgb, "context": {(1, 2, 3): "dog,1.0"}, "prompt": "a dog"}
+    got = pdist.broadcast_request(payload, dev, src=0)
+    assert got["prompt"] == "a dog" and got["context"] == {(1, 2, 3): "dog,1.0"}
+    assert got["rgb"].shape == (64, 48, 3) and int(got["rgb"].sum()) == int(((np.arange(64 * 48 * 3) % 251).astype(np.uint8)).sum())
+    # (c) image sharding is contiguous, disjoint, complete, and seeds do not depend on the world size
+    seeds = pdist.image_seeds(100, 5, rank, world)
+    lat = torch.stack([torch.full((4, 2, 2), float(s)) for s in seeds]) if seeds else torch.zeros(0, 4, 2, 2)
+    gathered = pdist.gather_latents(lat, dst=0)
+    t = pdist.max_over_ranks(1.0 + rank, dev)
+    assert t == float(world)
+    if rank == 0:
+        allv = torch.cat(gathered)[:, 0, 0, 0].tolist()
+        assert allv == [100.0, 101.0, 102.0, 103.0, 104.0]
+        open(os.path.join(out_dir, "ok"), "w").write("ok")
+    pdist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").read_text() == "ok"
+
+
+def test_shard_range_properties():
+    from pww_hip.dist import shard_range, image_seeds
+    for n in (0, 1, 7, 8, 64):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+    assert sum((image_seeds(10, 64, r, 8) for r in range(8)), []) == list(range(10, 74))

@@ -1,0 +1,16 @@
+"""Runs the native C++ harness (tests/native/attn_check.cpp) that drives the C ABI directly and
+checks every entry point against an independent fp64 host reference."""
+import subprocess
+import sys
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_native_c_abi_harness(gpu_device):
+    import build as pww_build
+    exe = pww_build.build_native_check()
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    sys.stdout.write(res.stdout[-6000:])
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert "NATIVE CHECK OK" in res.stdout
