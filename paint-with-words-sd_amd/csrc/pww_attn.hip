@@ -43,64 +43,209 @@ template <int DT> struct VTile {
     static constexpr int NUNIT = (KVBLK / 4) * (ROWS / 8);  // (4 keys x 8 d) transpose units
 };
 
-// One transpose unit: 4 consecutive keys x 8 consecutive d, i.e. four 16-byte global loads.
-template <typename T, int DT, int NT, int VPT>
-__device__ __forceinline__ void vtile_load(uint4 (&vreg)[VPT][4], const T *Vp, long v_sm, int key0,
-                                           int M, int D, int tid) {
+__device__ __forceinline__ uint32_t half_of(const u32x4 v, int j) {   // j is a compile-time constant at every call
+    const uint32_t w = v[j >> 1];
+    return (j & 1) ? (w >> 16) : (w & 0xffffu);
+}
+
+// Loop-invariant part of a thread's share of the K/V staging: which 16-byte chunks it moves and where
+// they land in an LDS stage buffer. A stage = NSUB sub-tiles of 64 keys, each sub-tile = [K tile | Vt tile].
+// Per stage only the key offset changes, so the hot loop carries no divisions; out-of-range rows are
+// CLAMPED to the last valid key (always-legal address) and zeroed at store time.
+template <int KPT, int VPT> struct StagePlan {
+    int k_row[KPT], k_d0[KPT], k_lds[KPT];
+    bool k_ok[KPT], k_wr[KPT];
+    int v_key[VPT], v_d0[VPT], v_lds[VPT];
+    bool v_ok[VPT];
+};
+
+template <typename T, int KS, int DT, int NT, int NSUB, int KPT, int VPT>
+__device__ __forceinline__ void make_plan(StagePlan<KPT, VPT> &pl, int tid, int D) {
+    typedef KTile<KS> KT;
     typedef VTile<DT> VT;
+    constexpr int SUB_BYTES = KT::BYTES + VT::BYTES;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const int c = tid + i * NT;
+        const int key = c / KT::CHK, ch = c - key * KT::CHK;       // key in [0, 64*NSUB)
+        pl.k_row[i] = key;
+        pl.k_d0[i] = ch * 8 < D ? ch * 8 : 0;
+        pl.k_lds[i] = (key >> 6) * SUB_BYTES + (key & 63) * KT::STRIDE + ch * 16;
+        pl.k_wr[i] = c < NSUB * KT::NCHUNK;                          // pad chunks are WRITTEN (as zeros)
+        pl.k_ok[i] = pl.k_wr[i] && ch * 8 < D;                       // ... but never loaded
+    }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         const int u = tid + i * NT;
-        const int kg = u & 15, dc = u >> 4;
+        const int kg = u % (16 * NSUB), dc = u / (16 * NSUB);        // key group (4 keys) over the whole stage
+        pl.v_key[i] = kg * 4;
+        pl.v_d0[i] = dc * 8 < D ? dc * 8 : 0;
+        pl.v_lds[i] = (kg >> 4) * SUB_BYTES + KT::BYTES + (dc * 8) * VT::STRIDE + (kg & 15) * 8;
+        pl.v_ok[i] = u < NSUB * VT::NUNIT && dc * 8 < D;             // pad rows are initialised once, never staged
+    }
+}
+
+// Issue the global loads of the stage starting at key0. Nothing here CONSUMES the loaded registers, so
+// the loads stay in flight across the compute of the current stage.
+// NOTE: the loads are UNCONDITIONAL on purpose. A load inside an `if` makes hipcc place the phi copy of the
+// loop-carried staging register in the predicated block, i.e. an `s_waitcnt vmcnt(0)` right behind every
+// load (measured: 74% of wave cycles parked). Idle lanes / padding chunks read one fixed, always-valid
+// address instead (same cache line for the whole wave) and their value is dropped at store time.
+template <typename T, int KPT, int VPT>
+__device__ __forceinline__ void stage_load(u32x4 (&kreg)[KPT], u32x4 (&vreg)[VPT][4], const StagePlan<KPT, VPT> &pl,
+                                           const T *Kp, const T *Vp, long k_sm, long v_sm, int key0, int M) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const int gk = min(key0 + pl.k_row[i], M - 1);
+        const T *src = pl.k_ok[i] ? Kp + (long)gk * k_sm + pl.k_d0[i] : Kp;
+        kreg[i] = *reinterpret_cast<const u32x4 *>(src);
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            uint4 val = make_uint4(0, 0, 0, 0);
-            const int gk = key0 + kg * 4 + kk;
-            if (u < VT::NUNIT && gk < M && dc * 8 < D)
-                val = *reinterpret_cast<const uint4 *>(Vp + (long)gk * v_sm + dc * 8);
-            vreg[i][kk] = val;
+            const int gk = min(key0 + pl.v_key[i] + kk, M - 1);
+            const T *src = pl.v_ok[i] ? Vp + (long)gk * v_sm + pl.v_d0[i] : Vp;
+            vreg[i][kk] = *reinterpret_cast<const u32x4 *>(src);
         }
     }
 }
 
-__device__ __forceinline__ uint32_t half_of(const uint4 &v, int j) {
-    const uint32_t w = (j >> 1) == 0 ? v.x : (j >> 1) == 1 ? v.y : (j >> 1) == 2 ? v.z : v.w;
-    return (j & 1) ? (w >> 16) : (w & 0xffffu);
-}
-
-template <int DT, int NT, int VPT>
-__device__ __forceinline__ void vtile_store(const uint4 (&vreg)[VPT][4], char *Vs, int tid) {
+// Registers -> LDS stage buffer. CHECK = the stage may contain keys >= M (tail): those rows become zeros.
+template <int DT, int KPT, int VPT, bool CHECK>
+__device__ __forceinline__ void stage_store(const u32x4 (&kreg)[KPT], const u32x4 (&vreg)[VPT][4],
+                                            const StagePlan<KPT, VPT> &pl, char *buf, int key0, int M) {
     typedef VTile<DT> VT;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        if (pl.k_wr[i]) {
+            const bool ok = pl.k_ok[i] && (!CHECK || key0 + pl.k_row[i] < M);
+            *reinterpret_cast<u32x4 *>(buf + pl.k_lds[i]) = ok ? kreg[i] : z;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-        const int u = tid + i * NT;
-        if (u < VT::NUNIT) {
-            const int kg = u & 15, dc = u >> 4;
-            char *dst = Vs + (dc * 8) * VT::STRIDE + kg * 8;
+        if (pl.v_ok[i]) {   // 4 keys x 8 d -> eight 8-byte writes of (4 keys) at consecutive d rows
+            u32x4 r[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) r[kk] = (!CHECK || key0 + pl.v_key[i] + kk < M) ? vreg[i][kk] : z;
+            char *dst = buf + pl.v_lds[i];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                uint2 w;
-                w.x = half_of(vreg[i][0], j) | (half_of(vreg[i][1], j) << 16);
-                w.y = half_of(vreg[i][2], j) | (half_of(vreg[i][3], j) << 16);
-                *reinterpret_cast<uint2 *>(dst + j * VT::STRIDE) = w;
+                u32x2 w;
+                w[0] = half_of(r[0], j) | (half_of(r[1], j) << 16);
+                w[1] = half_of(r[2], j) | (half_of(r[3], j) << 16);
+                *reinterpret_cast<u32x2 *>(dst + j * VT::STRIDE) = w;
             }
         }
     }
 }
 
-template <typename T, int KS, int DT, int NW>
-__global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnParams p) {
+// max over both half-waves of a per-lane value (lanes l and l^32 hold the two halves of one query row)
+__device__ __forceinline__ float xhalf_max(float x) {
+#if __has_builtin(__builtin_amdgcn_permlane32_swap)
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+#else
+    return fmaxf(x, __shfl_xor(x, 32));
+#endif
+}
+
+// Waves per SIMD the register allocator must leave room for (2 => <= 256 VGPRs+AGPRs). The bias
+// variants (32 extra loads in flight per tile) and the widest heads keep the whole 512-entry file.
+template <int DT, int NW, bool HAS_BIAS> struct MinWaves {
+    static constexpr int value = (HAS_BIAS || DT >= 4 || (NW == 2 && DT >= 3)) ? 1 : 2;
+};
+
+// One KV tile: scores -> (bias) -> online softmax -> PV. MASKED tiles (only the last one can be)
+// additionally kill keys >= M; full tiles skip every key compare.
+// ROWSUM_MFMA: the head dim is not a multiple of 32, so the V^T tile has padding rows; row D holds
+// ones and the PV MFMA accumulates the softmax denominator there for free (no per-element adds).
+template <typename T, int KS, int DT, bool HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
+__device__ __forceinline__ void attn_tile(f32x16 (&oacc)[DT], float &m_run, float &l_run,
+                                          const typename Vec<T>::v8 (&qf)[KS], const char *Ks, const char *Vs,
+                                          int key0, int M, int l31, int hi, const float *bias_row, long b_sm,
+                                          float coeff, float c1, bool qvalid) {
+    typedef typename Vec<T>::v8 V8;
+    typedef VTile<DT> VT;
+    f32x16 s[2];
+    score_tile<T, KS>(s, qf, Ks, key0, MASKED ? M : 0x7fffffff, l31, hi);
+
+    // raw-domain logits x = s + c*bias (scale > 0, so the row max commutes with the scaling)
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + key_of(kb, r, hi);
+            float x = s[kb][r];
+            if (HAS_BIAS) {
+                float bv = 0.f;
+                if (qvalid && (!MASKED || key < M)) bv = bias_row[(long)key * b_sm];
+                x = fmaf(bv, coeff, x);
+            }
+            if (MASKED) x = key < M ? x : -INFINITY;
+            s[kb][r] = x;
+            tmax = fmaxf(tmax, x);
+        }
+    }
+    tmax = xhalf_max(tmax);
+    const float m_new = fmaxf(m_run, tmax);   // finite: key0 < M, so at least one key of the tile is live
+    if (!__all(m_new == m_run)) {             // exact skip: alpha == 1 for every row of the wave
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c1);
+        if (!ROWSUM_MFMA) l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        m_run = m_new;
+    }
+    const float mc = -m_new * c1;
+    float psum = 0.f;
+    V8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c1, mc));   // exp2((x - m) * scale * log2 e)
+            if (!ROWSUM_MFMA) psum += pv;
+            pf[kb][r >> 3][r & 7] = (T)pv;
+        }
+    }
+    if (!ROWSUM_MFMA) l_run += psum;
+
+    // O^T[d][row] += Vt[d][key] * P^T[key][row]
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        if (!MASKED || key0 + kb * 32 < M) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const char *vbase = Vs + l31 * VT::STRIDE + (kb * 32 + k2 * 16 + hi * 8) * 2;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const V8 vf = *reinterpret_cast<const V8 *>(vbase + dt * 32 * VT::STRIDE);
+                    oacc[dt] = mfma32(vf, pf[kb][k2], oacc[dt]);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int KS, int DT, int NW, int NSUB, bool HAS_BIAS, bool ROWSUM_MFMA>
+__global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, HAS_BIAS>::value)) attn_fwd_kernel(const AttnParams p) {
     typedef typename Vec<T>::v8 V8;
     typedef typename Vec<T>::v4 V4;
     typedef KTile<KS> KT;
     typedef VTile<DT> VT;
     constexpr int NT = NW * 64;
-    constexpr int KPT = (KT::NCHUNK + NT - 1) / NT;
-    constexpr int VPT = (VT::NUNIT + NT - 1) / NT;
+    constexpr int SUB_BYTES = KT::BYTES + VT::BYTES;     // one 64-key sub-tile: K rows, then V^T rows
+    constexpr int STAGE_BYTES = NSUB * SUB_BYTES;
+    constexpr int STAGE_KEYS = NSUB * KVBLK;
+    constexpr int KPT = (NSUB * KT::NCHUNK + NT - 1) / NT;
+    constexpr int VPT = (NSUB * VT::NUNIT + NT - 1) / NT;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *Ks = smem;
-    char *Vs = smem + KT::BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // two stage buffers (double buffering)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -120,103 +265,83 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnParams p) {
     V8 qf[KS];
     load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qvalid, hi, p.D);
 
-    const bool has_bias = p.bias != nullptr;
     const float *bias_row = nullptr;
     float coeff = 1.f;
-    if (has_bias) {
+    if (HAS_BIAS) {
         bias_row = p.bias + b * p.b_sb + h * p.b_sh + (long)qrow * p.b_sn;
         if (p.bias_coeff) coeff = p.bias_coeff[b];
     }
     const float c1 = p.scale_log2e;
-    const float cb = coeff * c1;
 
     f32x16 oacc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-    float m_run = -INFINITY;  // running row max (log2 domain), identical in both half-waves
-    float l_run = 0.f;        // running row sum, PARTIAL per half-wave (combined in the epilogue)
+    float m_run = -INFINITY;  // running row max of the raw logits, identical in both half-waves
+    float l_run = 0.f;        // running row sum (VALU path only), PARTIAL per half-wave
 
-    uint4 kreg[KPT];
-    uint4 vreg[VPT][4];
-    const int ntiles = (p.M + KVBLK - 1) / KVBLK;
-    ktile_load<T, KS, NT, KPT>(kreg, Kp, p.k_sm, 0, p.M, p.D, tid);
-    vtile_load<T, DT, NT, VPT>(vreg, Vp, p.v_sm, 0, p.M, p.D, tid);
+    // V^T rows of the head-dim padding are never staged: zero both buffers once; with ROWSUM_MFMA row D
+    // of every V^T tile is all ones (the PV MFMA then accumulates the softmax denominator in O^T row D)
+    for (int i = tid * 16; i < 2 * STAGE_BYTES; i += NT * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    if (ROWSUM_MFMA) {
+        const T one = (T)1.0f;
+        for (int i = tid; i < 2 * NSUB * KVBLK; i += NT)
+            *reinterpret_cast<T *>(smem + (i >> 6) * SUB_BYTES + KT::BYTES + p.D * VT::STRIDE + (i & 63) * 2) = one;
+    }
 
-    for (int t = 0; t < ntiles; ++t) {
-        const int key0 = t * KVBLK;
-        __syncthreads();  // every wave is done reading the previous tile
-        ktile_store<KS, NT, KPT>(kreg, Ks, tid);
-        vtile_store<DT, NT, VPT>(vreg, Vs, tid);
+    StagePlan<KPT, VPT> plan;
+    make_plan<T, KS, DT, NT, NSUB, KPT, VPT>(plan, tid, p.D);
+    u32x4 kreg[KPT];
+    u32x4 vreg[VPT][4];
+    const int nstage = (p.M + STAGE_KEYS - 1) / STAGE_KEYS;
+    const int nfull = p.M / STAGE_KEYS;                 // stages without any key >= M
+
+    // prologue: stage 0 -> buffer 0, stage 1 -> registers
+    stage_load<T, KPT, VPT>(kreg, vreg, plan, Kp, Vp, p.k_sm, p.v_sm, 0, p.M);
+    stage_store<DT, KPT, VPT, true>(kreg, vreg, plan, smem, 0, p.M);
+    if (nstage > 1) stage_load<T, KPT, VPT>(kreg, vreg, plan, Kp, Vp, p.k_sm, p.v_sm, STAGE_KEYS, p.M);
+    __syncthreads();
+
+    int st = 0;
+    for (; st < nfull; ++st) {   // full stages: no key masking anywhere; ONE barrier per stage
+        char *cur = smem + (st & 1) * STAGE_BYTES;
+        char *nxt = smem + ((st & 1) ^ 1) * STAGE_BYTES;
+        // registers hold stage st+1: park it in the other buffer (its readers finished before the last
+        // barrier), then re-use the registers for stage st+2, whose loads fly during this stage's compute
+        if (st + 1 < nstage) stage_store<DT, KPT, VPT, true>(kreg, vreg, plan, nxt, (st + 1) * STAGE_KEYS, p.M);
+        if (st + 2 < nstage) stage_load<T, KPT, VPT>(kreg, vreg, plan, Kp, Vp, p.k_sm, p.v_sm, (st + 2) * STAGE_KEYS, p.M);
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub)
+            attn_tile<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES,
+                                                               cur + sub * SUB_BYTES + KT::BYTES, st * STAGE_KEYS + sub * KVBLK,
+                                                               p.M, l31, hi, bias_row, p.b_sm, coeff, c1, qvalid);
         __syncthreads();
-        if (t + 1 < ntiles) {  // in flight while this tile is computed
-            ktile_load<T, KS, NT, KPT>(kreg, Kp, p.k_sm, key0 + KVBLK, p.M, p.D, tid);
-            vtile_load<T, DT, NT, VPT>(vreg, Vp, p.v_sm, key0 + KVBLK, p.M, p.D, tid);
-        }
-
-        f32x16 s[2];
-        score_tile<T, KS>(s, qf, Ks, key0, p.M, l31, hi);
-
-        // logits in the log2 domain: (s + c*bias) * scale * log2(e); keys past M -> -inf
-        float tmax = -INFINITY;
+    }
+    if (st < nstage) {           // ragged tail stage (already in LDS: stored by the prologue or the last iteration)
+        char *cur = smem + (st & 1) * STAGE_BYTES;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key0 + key_of(kb, r, hi);
-                float x = s[kb][r] * c1;
-                if (has_bias) {
-                    float bv = 0.f;
-                    if (qvalid && key < p.M) bv = bias_row[(long)key * p.b_sm];
-                    x = fmaf(bv, cb, x);
-                }
-                x = key < p.M ? x : -INFINITY;
-                s[kb][r] = x;
-                tmax = fmaxf(tmax, x);
-            }
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run, tmax);  // finite: key0 < M so at least one key is live
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-
-        float psum = 0.f;
-        V8 pf[2][2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
-                psum += pv;
-                pf[kb][r >> 3][r & 7] = (T)pv;
-            }
-        }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
-
-        // O^T[d][row] += Vt[d][key] * P^T[key][row]
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            if (key0 + kb * 32 < p.M) {
-#pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) {
-                    const char *vbase = Vs + l31 * VT::STRIDE + (kb * 32 + k2 * 16 + hi * 8) * 2;
-#pragma unroll
-                    for (int dt = 0; dt < DT; ++dt) {
-                        const V8 vf = *reinterpret_cast<const V8 *>(vbase + dt * 32 * VT::STRIDE);
-                        oacc[dt] = mfma32(vf, pf[kb][k2], oacc[dt]);
-                    }
-                }
-            }
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int key0 = st * STAGE_KEYS + sub * KVBLK;
+            if (key0 < p.M)
+                attn_tile<T, KS, DT, HAS_BIAS, true, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES,
+                                                                  cur + sub * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, bias_row,
+                                                                  p.b_sm, coeff, c1, qvalid);
         }
     }
 
+    // softmax denominator
+    float l_tot;
+    if (ROWSUM_MFMA) {   // row D of O^T: tile DT-1, register (D % 32) / 2, held by the hi == 0 half
+        const int rl = p.D & 31;
+        const float lv = rl == 8 ? oacc[DT - 1][4] : rl == 16 ? oacc[DT - 1][8] : oacc[DT - 1][12];
+        const float other = __shfl_xor(lv, 32);
+        l_tot = hi ? other : lv;
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32);
+    }
     // epilogue: normalise and write O[row][d]; register r of tile dt is d = dt*32 + (r&3) + 8*(r>>2) + 4*hi
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.f / l_tot;
     if (qvalid) {
         T *orow = Op + (long)qrow * p.o_sn;
@@ -238,13 +363,16 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(const AttnParams p) {
 
 // ---- host dispatch ---------------------------------------------------------------------------
 
-template <typename T, int KS, int DT, int NW>
-static int launch_attn(const AttnParams &p, hipStream_t stream) {
-    constexpr size_t lds = KTile<KS>::BYTES + VTile<DT>::BYTES;
+template <typename T, int KS, int DT, int NW, bool HAS_BIAS, bool ROWSUM_MFMA>
+static int launch_attn_rs(const AttnParams &p, hipStream_t stream) {
+    // two 64-key sub-tiles per stage (one barrier per 128 keys) while the double buffer stays small enough
+    // for two workgroups per CU; the widest heads use single sub-tile stages
+    constexpr int NSUB = (2 * 2 * (KTile<KS>::BYTES + VTile<DT>::BYTES) <= 72 * 1024) ? 2 : 1;
+    constexpr size_t lds = 2 * NSUB * (KTile<KS>::BYTES + VTile<DT>::BYTES);
     const int qblocks = (p.N + NW * 32 - 1) / (NW * 32);
     const dim3 grid((unsigned)(qblocks * p.B * p.H));
-    auto kern = attn_fwd_kernel<T, KS, DT, NW>;
-    if (lds > 48 * 1024) {
+    auto kern = attn_fwd_kernel<T, KS, DT, NW, NSUB, HAS_BIAS, ROWSUM_MFMA>;
+    if (lds > 64 * 1024) {
         static thread_local bool done = false;
         if (!done) {
             if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -258,21 +386,29 @@ static int launch_attn(const AttnParams &p, hipStream_t stream) {
     return check_hip(hipGetLastError(), "attn_fwd_kernel launch");
 }
 
-template <typename T, int NW> static int dispatch_d(const AttnParams &p, hipStream_t s) {
+template <typename T, int KS, int DT, int NW, bool HAS_BIAS>
+static int launch_attn(const AttnParams &p, hipStream_t stream) {
+    // head dims with padding rows in the V^T tile get the row sum from the MFMA (self-attention path)
+    if (!HAS_BIAS && (p.D & 31) != 0) return launch_attn_rs<T, KS, DT, NW, HAS_BIAS, true>(p, stream);
+    return launch_attn_rs<T, KS, DT, NW, HAS_BIAS, false>(p, stream);
+}
+
+template <typename T, int NW, bool HAS_BIAS> static int dispatch_d(const AttnParams &p, hipStream_t s) {
     const int D = p.D;
-    if (D <= 48) return launch_attn<T, 3, 2, NW>(p, s);
-    if (D <= 64) return launch_attn<T, 4, 2, NW>(p, s);
-    if (D <= 80) return launch_attn<T, 5, 3, NW>(p, s);
-    if (D <= 96) return launch_attn<T, 6, 3, NW>(p, s);
-    if (D <= 128) return launch_attn<T, 8, 4, NW>(p, s);
-    return launch_attn<T, 10, 5, NW>(p, s);
+    if (D <= 48) return launch_attn<T, 3, 2, NW, HAS_BIAS>(p, s);
+    if (D <= 64) return launch_attn<T, 4, 2, NW, HAS_BIAS>(p, s);
+    if (D <= 80) return launch_attn<T, 5, 3, NW, HAS_BIAS>(p, s);
+    if (D <= 96) return launch_attn<T, 6, 3, NW, HAS_BIAS>(p, s);
+    if (D <= 128) return launch_attn<T, 8, 4, NW, HAS_BIAS>(p, s);
+    return launch_attn<T, 10, 5, NW, HAS_BIAS>(p, s);
 }
 
 template <typename T> static int dispatch_nw(const AttnParams &p, hipStream_t s) {
     // Fewer waves per workgroup when the problem is too small to give every CU a 4-wave block.
     const long rows32 = (long)((p.N + 31) / 32) * p.B * p.H;  // 32-row wave tasks
-    if (rows32 >= 4 * 256 && p.N >= 128) return dispatch_d<T, 4>(p, s);
-    return dispatch_d<T, 2>(p, s);
+    const bool wide = rows32 >= 4 * 256 && p.N >= 128;
+    if (p.bias) return wide ? dispatch_d<T, 4, true>(p, s) : dispatch_d<T, 2, true>(p, s);
+    return wide ? dispatch_d<T, 4, false>(p, s) : dispatch_d<T, 2, false>(p, s);
 }
 
 static bool aligned16(const void *ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
@@ -303,6 +439,7 @@ int attn_fwd(const void *q, const void *k, const void *v, void *o, const float *
         }
     }
     if ((long)d->B * d->H * ((d->N + 31) / 32) > 0x7fffffffL) { set_error("attn_fwd: grid too large"); return PWW_EINVAL; }
+    if (!(d->scale > 0.f)) { set_error("attn_fwd: scale must be positive (got %g)", (double)d->scale); return PWW_EINVAL; }
     if (!arch_ok()) return PWW_ENOTSUP;
 
     AttnParams p;

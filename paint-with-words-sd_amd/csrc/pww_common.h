@@ -13,6 +13,10 @@ typedef __bf16 bf16;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// 16-byte staging register. NOT HIP's uint4 (a struct): `cond ? a : b` on struct lvalues selects between
+// ADDRESSES and forces both operands into scratch memory; on a native vector it is a register select.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -30,7 +34,7 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
 }
 
 template <typename V8> __device__ __forceinline__ V8 zero8() {
-    uint4 z = make_uint4(0, 0, 0, 0);
+    const u32x4 z = {0u, 0u, 0u, 0u};
     return __builtin_bit_cast(V8, z);
 }
 

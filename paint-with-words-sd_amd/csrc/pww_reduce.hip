@@ -66,13 +66,13 @@ __global__ void __launch_bounds__(NW * 64) qk_reduce_kernel(const ReduceParams p
     load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qvalid, hi, p.D);
 
     float vmax = -INFINITY, vmin = INFINITY, vsum = 0.f, vsq = 0.f;
-    uint4 kreg[KPT];
+    u32x4 kreg[KPT];
     const int ntiles = (p.M + KVBLK - 1) / KVBLK;
     ktile_load<T, KS, NT, KPT>(kreg, Kp, p.k_sm, 0, p.M, p.D, tid);
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * KVBLK;
         __syncthreads();
-        ktile_store<KS, NT, KPT>(kreg, Ks, tid);
+        ktile_store<KS, NT, KPT>(kreg, Ks, tid, key0, p.M, p.D);
         __syncthreads();
         if (t + 1 < ntiles) ktile_load<T, KS, NT, KPT>(kreg, Kp, p.k_sm, key0 + KVBLK, p.M, p.D, tid);
         f32x16 s[2];

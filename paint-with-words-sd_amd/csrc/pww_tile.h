@@ -42,31 +42,31 @@ __device__ __forceinline__ void load_q_frags(typename Vec<T>::v8 (&qf)[KS], cons
 // Global -> registers for one K tile (keys key0 .. key0+63). Out-of-range keys and the head-dim
 // padding are zero-filled so the MFMA never sees uninitialised LDS.
 template <typename T, int KS, int NT, int KPT>
-__device__ __forceinline__ void ktile_load(uint4 (&kreg)[KPT], const T *Kp, long k_sm, int key0,
+__device__ __forceinline__ void ktile_load(u32x4 (&kreg)[KPT], const T *Kp, long k_sm, int key0,
                                            int M, int D, int tid) {
     typedef KTile<KS> KT;
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
         const int c = tid + i * NT;
-        uint4 val = make_uint4(0, 0, 0, 0);
-        if (c < KT::NCHUNK) {
-            const int key = c / KT::CHK, ch = c % KT::CHK;
-            const int gk = key0 + key, d0 = ch * 8;
-            if (gk < M && d0 < D) val = *reinterpret_cast<const uint4 *>(Kp + (long)gk * k_sm + d0);
-        }
-        kreg[i] = val;
+        // unconditional load from an always-valid address (clamped row, chunk 0 for padding): a load inside
+        // an `if` would get an s_waitcnt vmcnt(0) right behind it; out-of-range data is zeroed at store time
+        const int key = min(c / KT::CHK, KVBLK - 1), ch = c % KT::CHK;
+        const int gk = min(key0 + key, M - 1), d0 = ch * 8 < D ? ch * 8 : 0;
+        kreg[i] = *reinterpret_cast<const u32x4 *>(Kp + (long)gk * k_sm + d0);
     }
 }
 
 template <int KS, int NT, int KPT>
-__device__ __forceinline__ void ktile_store(const uint4 (&kreg)[KPT], char *Ks, int tid) {
+__device__ __forceinline__ void ktile_store(const u32x4 (&kreg)[KPT], char *Ks, int tid, int key0, int M, int D) {
     typedef KTile<KS> KT;
+    const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
         const int c = tid + i * NT;
         if (c < KT::NCHUNK) {
             const int key = c / KT::CHK, ch = c % KT::CHK;
-            *reinterpret_cast<uint4 *>(Ks + key * KT::STRIDE + ch * 16) = kreg[i];
+            const bool ok = key0 + key < M && ch * 8 < D;
+            *reinterpret_cast<u32x4 *>(Ks + key * KT::STRIDE + ch * 16) = ok ? kreg[i] : z;
         }
     }
 }

@@ -259,6 +259,7 @@ static void check_errors() {
 
 int main(int argc, char **argv) {
     const bool quick = argc > 1 && !strcmp(argv[1], "--quick");
+    const char *only = (argc > 2 && !strcmp(argv[1], "--only")) ? argv[2] : nullptr;
     char arch[64] = ""; int rc = pww_device_arch(arch, sizeof(arch));
     printf("libpww_hip version %d, device arch '%s' (rc=%d)\n", pww_version(), arch, rc);
     std::vector<Case> cases = {
@@ -285,11 +286,14 @@ int main(int argc, char **argv) {
     for (auto &c : cases) {
         const bool big = (long)c.N * c.M >= 1024L * 1024L || c.N >= 4096;
         if (quick && big) continue;
+        if (only && strcmp(only, c.name)) continue;
         run_case(c, big);
     }
-    check_mask();
-    check_cfg();
-    check_errors();
+    if (!only) {
+        check_mask();
+        check_cfg();
+        check_errors();
+    }
     printf("%s: %d failure(s)\n", g_fail ? "NATIVE CHECK FAILED" : "NATIVE CHECK OK", g_fail);
     return g_fail ? 1 : 0;
 }
