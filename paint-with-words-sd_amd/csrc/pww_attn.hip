@@ -333,9 +333,14 @@ __global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, HAS_BIAS>::value)) 
 
     // softmax denominator
     float l_tot;
-    if (ROWSUM_MFMA) {   // row D of O^T: tile DT-1, register (D % 32) / 2, held by the hi == 0 half
-        const int rl = p.D & 31;
-        const float lv = rl == 8 ? oacc[DT - 1][4] : rl == 16 ? oacc[DT - 1][8] : oacc[DT - 1][12];
+    if (ROWSUM_MFMA) {   // row D of O^T: tile D / 32, register (D % 32) / 2, held by the hi == 0 half
+        const int rl = p.D & 31, tl = p.D >> 5;
+        float lv = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const float c = rl == 8 ? oacc[dt][4] : rl == 16 ? oacc[dt][8] : oacc[dt][12];
+            lv = dt == tl ? c : lv;
+        }
         const float other = __shfl_xor(lv, 32);
         l_tot = hi ? other : lv;
     } else {

@@ -20,6 +20,7 @@ from . import ops
 from ._lib import PwwHipError
 
 _HALF = (torch.float16, torch.bfloat16)
+ROW_GATE = "_PWW_ROW_GATE"   # private context key: fp32 [B] per-row bias coefficient (see pww_hip/sampler.py)
 _warned = set()
 
 
@@ -225,7 +226,9 @@ def pww_attention(attn, hidden_states, context=None):
     query, key, value = _half(query, cdt), _half(key, cdt), _half(value, cdt)
 
     bias = None
+    gate = None
     if context is not None and is_dict:
+        gate = context.get(ROW_GATE)   # folded CFG batches: per-row coefficient (1 = cond row, 0 = uncond row)
         f = context["WEIGHT_FUNCTION"]
         n_img = query.shape[1]
         try:
@@ -247,7 +250,7 @@ def pww_attention(attn, hidden_states, context=None):
         # python scalar / 0-dim tensor: a constant added to every logit of a row cancels in softmax
         # (the unconditional pass returns 0.0, :493)
         bias = None
-    return ops.attention(query, key, value, attn.heads, attn.scale, bias=bias)
+    return ops.attention(query, key, value, attn.heads, attn.scale, bias=bias, bias_coeff=gate if bias is not None else None)
 
 
 def inj_forward(self, hidden_states, context=None, mask=None):

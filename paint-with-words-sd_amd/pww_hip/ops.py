@@ -34,18 +34,27 @@ def _rows_ok(t):
 
 
 def _desc(q, k, v, o, heads, scale):
+    if q.dim() != 3 or k.dim() != 3 or (v is not None and v.dim() != 3):
+        raise PwwHipError("q/k/v must be [batch, tokens, heads*dim] tensors")
     B, N, C = q.shape
     M = k.shape[1]
     if C % heads:
         raise PwwHipError("channels %d not divisible by heads %d" % (C, heads))
+    if k.shape[2] != C or k.shape[0] not in (1, B):
+        raise PwwHipError("key shape %s does not match query shape %s" % (tuple(k.shape), tuple(q.shape)))
+    if v is not None and tuple(v.shape) != tuple(k.shape):
+        raise PwwHipError("value shape %s differs from key shape %s" % (tuple(v.shape), tuple(k.shape)))
+    if M < 1 or N < 1 or B < 1:
+        raise PwwHipError("empty attention problem (B=%d N=%d M=%d)" % (B, N, M))
     D = C // heads
     d = AttnDesc()
     d.dtype = _DT[q.dtype]
     d.B, d.H, d.N, d.M, d.D = B, heads, N, M, D
     d.q_stride[:] = [q.stride(0), D, q.stride(1)]
-    d.k_stride[:] = [k.stride(0), D, k.stride(1)]
+    kb = k.stride(0) if k.shape[0] == B and B > 1 else 0     # a batch-1 context is shared by every image
+    d.k_stride[:] = [kb, D, k.stride(1)]
     if v is not None:
-        d.v_stride[:] = [v.stride(0), D, v.stride(1)]
+        d.v_stride[:] = [v.stride(0) if v.shape[0] == B and B > 1 else 0, D, v.stride(1)]
     if o is not None:
         d.o_stride[:] = [o.stride(0), D, o.stride(1)]
     d.scale = float(scale)

@@ -15,9 +15,7 @@ Three execution modes over the SAME arithmetic:
 import torch
 
 from . import ops
-from .attention import install
-
-ROW_GATE = "_PWW_ROW_GATE"
+from .attention import install, ROW_GATE
 
 
 def initial_latents(seed, in_channels, height, width, region_masks=None, extra_seeds=None, batch_seeds=None):

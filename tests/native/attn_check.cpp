@@ -282,6 +282,15 @@ int main(int argc, char **argv) {
         {"d96_n200_m130", PWW_DTYPE_F16, 1, 2, 200, 130, 96, 2, false, 1, 0.6f},
         {"d128_n130_m200", PWW_DTYPE_BF16, 1, 2, 130, 200, 128, 0, false, 1, 0.6f},
         {"d48_n33_m1", PWW_DTYPE_F16, 1, 1, 33, 1, 48, 0, false, 1, 1.0f},
+        {"d8_self_n300", PWW_DTYPE_F16, 2, 4, 300, 300, 8, 0, true, 1, 1.5f},
+        {"d16_self_n200", PWW_DTYPE_BF16, 1, 4, 200, 200, 16, 0, true, 1, 1.5f},
+        {"d24_cross_n130", PWW_DTYPE_F16, 1, 3, 130, 77, 24, 1, false, 1, 1.0f},
+        {"d32_self_n129", PWW_DTYPE_F16, 1, 4, 129, 129, 32, 0, true, 1, 1.0f},
+        {"d56_self_n257", PWW_DTYPE_BF16, 1, 2, 257, 257, 56, 0, true, 1, 1.0f},
+        {"d72_self_n192", PWW_DTYPE_F16, 1, 2, 192, 192, 72, 0, true, 1, 1.0f},
+        {"d88_self_n128", PWW_DTYPE_F16, 1, 2, 128, 128, 88, 0, true, 1, 1.0f},
+        {"d104_self_n128", PWW_DTYPE_BF16, 1, 2, 128, 128, 104, 0, true, 1, 1.0f},
+        {"d152_self_n128", PWW_DTYPE_F16, 1, 2, 128, 128, 152, 0, true, 1, 0.7f},
     };
     for (auto &c : cases) {
         const bool big = (long)c.N * c.M >= 1024L * 1024L || c.N >= 4096;

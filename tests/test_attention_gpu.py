@@ -21,6 +21,9 @@ SHAPES = [  # name, B, H, N, M, D
     ("sd15_self_64", 2, 8, 64, 64, 160), ("sd15_cross_64", 1, 8, 64, 77, 160),
     ("sd21_self_576", 1, 20, 576, 576, 64), ("sd21_cross_144", 2, 20, 144, 77, 64),
     ("ragged", 3, 3, 100, 65, 96), ("one_key", 1, 2, 33, 1, 48), ("d128", 1, 4, 200, 130, 128),
+    ("tiny_self_d8", 2, 4, 4096, 4096, 8), ("tiny_self_d16", 2, 4, 1024, 1024, 16), ("tiny_cross_d32", 2, 4, 256, 77, 32),
+    ("self_d24", 1, 2, 130, 130, 24), ("self_d56", 1, 2, 257, 257, 56), ("self_d72", 1, 2, 192, 192, 72),
+    ("self_d104", 1, 2, 128, 128, 104), ("self_d152", 1, 2, 128, 128, 152),
 ]
 
 
@@ -156,6 +159,35 @@ def test_batched_reduction_is_per_image(gpu_device):
             assert (batched[i:i + 1].float() - single.float()).abs().max() <= 2e-3 * single.float().abs().max()
 
 
+def test_folded_cfg_rows_are_gated(gpu_device):
+    """Folded CFG batch [cond rows; uncond rows]: cond rows get the PwW bias (with THEIR image's qk.max),
+    uncond rows get none -- each row must equal the corresponding separate batch-1 call of the reference."""
+    import pww_hip
+    from pww_hip.sampler import ROW_GATE
+    case = cases.make_attention_case("sd15_n1024", seed=6)
+    dev, dtype = gpu_device, torch.float16
+    mod = case["attn_cross"].to(dev, dtype)
+    g = torch.Generator().manual_seed(3)
+    hidden = (torch.randn(2, 1024, 640, generator=g) * torch.tensor([1.0, 1.7])[:, None, None]).to(dev, dtype)
+    ctx_c, ctx_u = torch.randn(1, 77, 768, generator=g).to(dev, dtype), torch.randn(1, 77, 768, generator=g).to(dev, dtype)
+    w = case["w"].to(dev)
+    sig = torch.tensor(6.0)
+    for wf in (cases.weight_fn_runner, cases.weight_fn_std):
+        folded = {"CONTEXT_TENSOR": torch.cat([ctx_c.expand(2, -1, -1), ctx_u.expand(2, -1, -1)]).contiguous(),
+                  "CROSS_ATTENTION_WEIGHT_1024": w, "SIGMA": sig, "WEIGHT_FUNCTION": wf,
+                  ROW_GATE: torch.tensor([1.0, 1.0, 0.0, 0.0], device=dev)}
+        y = pww_hip.inj_forward(mod, torch.cat([hidden, hidden]), folded).float()
+        for i in range(2):
+            yc = pww_hip.inj_forward(mod, hidden[i:i + 1], {"CONTEXT_TENSOR": ctx_c, "CROSS_ATTENTION_WEIGHT_1024": w, "SIGMA": sig,
+                                                            "WEIGHT_FUNCTION": wf}).float()
+            yu = pww_hip.inj_forward(mod, hidden[i:i + 1], {"CONTEXT_TENSOR": ctx_u, "CROSS_ATTENTION_WEIGHT_1024": 0, "SIGMA": sig,
+                                                            "WEIGHT_FUNCTION": lambda w, sigma, qk: 0.0}).float()
+            tol = 2e-3 * yc.abs().max().item()
+            assert (y[i:i + 1] - yc).abs().max().item() <= tol
+            assert (y[2 + i:3 + i] - yu).abs().max().item() <= tol
+            assert (yc - yu).abs().max().item() > 50 * tol      # the bias is far from a no-op here
+
+
 def test_exotic_weight_function_materializes(gpu_device):
     """A weight function that uses qk element-wise still works (QKProxy materialises Q K^T)."""
     import pww_hip
@@ -175,6 +207,24 @@ def test_exotic_weight_function_materializes(gpu_device):
     mod_cpu = case["attn_cross"].to("cpu", dtype).float()
     ref = O.inj_forward(mod_cpu, case["hidden"].to(dtype).float(), ctx_cpu)
     assert (y - ref).abs().max() <= 1e-2 * ref.abs().max()
+
+
+def test_shared_context_broadcast_and_shape_validation(gpu_device):
+    """A batch-1 key/value (one prompt, many images) is broadcast through a zero batch stride; any other
+    batch mismatch is rejected before a pointer reaches the kernel."""
+    import pww_hip
+    from pww_hip import ops
+    q, k, v = _inputs(3, 4, 96, 77, 40, torch.float16, 5)
+    dev = gpu_device
+    out = ops.attention(q.to(dev), k[:1].to(dev), v[:1].to(dev), 4, 40 ** -0.5)
+    ref, _ = _oracle(q, k[:1].expand(3, -1, -1), v[:1].expand(3, -1, -1), 4, 40 ** -0.5)
+    assert (out.float().cpu() - ref).abs().max() <= TOL[torch.float16] * ref.abs().max()
+    with pytest.raises(pww_hip.PwwHipError, match="does not match"):
+        ops.attention(q.to(dev), k[:2].to(dev), v[:2].to(dev), 4, 40 ** -0.5)
+    with pytest.raises(pww_hip.PwwHipError, match="differs"):
+        ops.attention(q.to(dev), k.to(dev), v[:, :50].to(dev), 4, 40 ** -0.5)
+    with pytest.raises(pww_hip.PwwHipError):
+        ops.attention(q.to(dev), k[:, :, :80].to(dev), v[:, :, :80].to(dev), 4, 40 ** -0.5)
 
 
 def test_error_behaviour(gpu_device):

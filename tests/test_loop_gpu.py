@@ -53,11 +53,9 @@ def test_tiny_loop_vs_reference(gpu_device, dtype, mode):
     base = _run(*args[:2], "eager", *args[3:], fused=False)
     d, d0 = rel_l2(lat, g["latents"]), rel_l2(base, g["latents"])
     print(f"tiny {dtype} {mode}: rel-L2 hip {d:.3e} unfused-torch {d0:.3e}")
-    if mode == "eager":   # same call pattern as the calibration path: drift must match it
-        assert d <= 1.5 * d0 + 2e-3
-    # folded / graph batch cond+uncond: GEMM/conv kernels pick batch-dependent tilings, and the tiny random
-    # UNet amplifies that rounding over 10 steps; correctness of the folding itself is pinned by
-    # test_folded_and_graph_match_eager_single_forward below.
+    # every mode computes the same arithmetic as the reference's two batch-1 calls: the drift against the
+    # fp32 CPU golden must match the drift of the unfused half-precision torch path on this GPU
+    assert d <= 1.5 * d0 + 2e-3
     assert d <= (2e-2 if dtype == torch.float16 else 1e-1)
 
 
@@ -83,21 +81,27 @@ def test_sd15_config1_final_latent(gpu_device, dtype, mode):
     assert d <= (1e-2 if dtype == torch.float16 else 5e-2)
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_folded_and_graph_match_eager_single_forward(gpu_device, dtype):
+def test_folded_and_graph_match_eager_single_forward(gpu_device):
     """One UNet evaluation: [cond; uncond] folded into one batch (row-gated bias, per-image qk.max) and its
-    hipGraph replay must equal the reference's two separate calls up to half-precision rounding."""
+    hipGraph replay must equal the reference's two separate calls.
+
+    The UNet runs in fp32 here (the attention plug rounds q/k/v to bf16 for the MFMA kernels, identically
+    in every path), so batch-size-dependent rounding of the library GEMM/conv kernels -- which in a half
+    precision model is amplified to ~1% by this tiny random UNet -- drops out and the comparison isolates
+    the folding / gating / per-image reduction / graph-capture logic."""
+    import warnings
     import pww_hip
     from pww_hip.conditioning import _encode_text_color_inputs
     from pww_hip.sampler import _fold_context, _GraphedUNet
-    vae, unet, text, tok, sch = cases.build_tools("tiny", dtype=dtype, device=gpu_device)
+    vae, unet, text, tok, sch = cases.build_tools("tiny", dtype=torch.float32, device=gpu_device)
     pww_hip.install(unet)
     try:
         _, _, cond, uncond = _encode_text_color_inputs(text, tok, gpu_device, cases.load_example_rgb(), dict(cases.RUNNER_CONTEXT),
-                                                       cases.RUNNER_PROMPT, "", dtype=dtype)
-        x = torch.randn(2, 4, 64, 64, generator=torch.Generator().manual_seed(0)).to(gpu_device, dtype)   # 2 images
+                                                       cases.RUNNER_PROMPT, "")
+        x = torch.randn(2, 4, 64, 64, generator=torch.Generator().manual_seed(0)).to(gpu_device)   # 2 images
         sigma, t = torch.tensor(7.84), torch.tensor(888.0)
-        with torch.no_grad():
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
             cond.update({"SIGMA": sigma, "WEIGHT_FUNCTION": cases.weight_fn_runner})
             uncond.update({"SIGMA": sigma, "WEIGHT_FUNCTION": lambda w, sigma, qk: 0.0})
             e_c = torch.cat([unet(x[i:i + 1], t, encoder_hidden_states=cond).sample for i in range(2)])
@@ -107,11 +111,13 @@ def test_folded_and_graph_match_eager_single_forward(gpu_device, dtype):
             out_f = unet(torch.cat([x, x]), t, encoder_hidden_states=folded).sample
             out_g = _GraphedUNet(unet)(0, torch.cat([x, x]), 888.0, folded).clone()
         ref = torch.cat([e_c, e_u]).float()
-        tol = (4e-3 if dtype == torch.float16 else 3e-2) * ref.abs().max().item()
-        assert (out_f.float() - ref).abs().max().item() <= tol
-        assert (out_g.float() - ref).abs().max().item() <= tol
-        # the bias matters: cond and uncond predictions differ by much more than the tolerance
-        assert (e_c.float() - e_u.float()).abs().max().item() > 5 * tol
+        scale = ref.abs().max().item()
+        err_f = (out_f.float() - ref).abs().max().item()
+        err_g = (out_g.float() - ref).abs().max().item()
+        gap = (e_c.float() - e_u.float()).abs().max().item()
+        print(f"fold check: folded {err_f:.3e}, graph {err_g:.3e}, max|eps| {scale:.3f}, cond-uncond gap {gap:.3e}")
+        assert err_f <= 2e-3 * scale and err_g <= 2e-3 * scale
+        assert gap > 20 * max(err_f, err_g)      # the bias matters: a gating bug would show up as O(gap)
     finally:
         uninstall_all()
 
