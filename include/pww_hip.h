@@ -108,12 +108,14 @@ int pww_cross_attn_fwd(const void *q, const void *k, const void *v, void *o,
 /*
  * Per-image global statistics of the raw score tensor S = Q K^T over all heads, rows and keys
  * (what weight_function reduces: qk.max(), qk.min(), qk.mean(), qk.std()).
- *   stats  double [B][4] = { max, min, sum, sum of squares } per image b.
- * The function first enqueues the initialisation of `stats`, then the reduction kernel.
+ *   stats      double [B][4] = { max, min, sum, sum of squares } per image b (fully overwritten).
+ *   workspace  caller-owned device scratch of at least pww_workspace_bytes(desc) bytes, 8-byte
+ *              aligned; contents need not be initialised (per-workgroup partials + arrival counters:
+ *              the last workgroup of each image folds the partials, no same-address atomics).
  * Only q/k strides, B/H/N/M/D and dtype of the descriptor are read.
  */
 int pww_qk_reduce(const void *q, const void *k, const pww_attn_desc_t *desc,
-                  double *stats, void *stream);
+                  double *stats, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Region table entry for pww_mask_build: one (color -> strength) pair of color_context
@@ -160,7 +162,8 @@ int pww_mask_build_f32(const float *masks, int32_t H, int32_t W, int32_t R,
 int pww_cfg_combine(const void *cond, const void *uncond, float guidance, float *out,
                     int64_t n, int32_t dtype, void *stream);
 
-/* Device workspace the library needs from the caller: currently 0 for every entry point. */
+/* Device workspace pww_qk_reduce needs from the caller for this problem (the attention entry points
+   need none). */
 size_t pww_workspace_bytes(const pww_attn_desc_t *desc);
 
 #ifdef __cplusplus

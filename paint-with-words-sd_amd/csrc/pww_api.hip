@@ -48,7 +48,9 @@ bool arch_ok() {
 
 int attn_fwd(const void *q, const void *k, const void *v, void *o, const float *bias, const float *bias_coeff,
              const pww_attn_desc_t *d, hipStream_t stream);
-int qk_reduce(const void *q, const void *k, const pww_attn_desc_t *d, double *stats, hipStream_t stream);
+int qk_reduce(const void *q, const void *k, const pww_attn_desc_t *d, double *stats, void *workspace,
+              size_t workspace_bytes, hipStream_t stream);
+size_t qk_reduce_workspace_bytes(const pww_attn_desc_t *d);
 int mask_build(const uint8_t *rgb, int H, int W, const pww_region_t *regions, int R, const int32_t *col_ptr,
                const int32_t *col_reg, int T, float *out8, float *out16, float *out32, float *out64,
                hipStream_t stream);
@@ -81,8 +83,9 @@ int pww_cross_attn_fwd(const void *q, const void *k, const void *v, void *o, con
     return pww::attn_fwd(q, k, v, o, bias, bias_coeff, desc, static_cast<hipStream_t>(stream));
 }
 
-int pww_qk_reduce(const void *q, const void *k, const pww_attn_desc_t *desc, double *stats, void *stream) {
-    return pww::qk_reduce(q, k, desc, stats, static_cast<hipStream_t>(stream));
+int pww_qk_reduce(const void *q, const void *k, const pww_attn_desc_t *desc, double *stats, void *workspace,
+                  size_t workspace_bytes, void *stream) {
+    return pww::qk_reduce(q, k, desc, stats, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int pww_mask_build(const uint8_t *rgb, int32_t H, int32_t W, const pww_region_t *regions, int32_t R,
@@ -108,6 +111,6 @@ int pww_cfg_combine(const void *cond, const void *uncond, float guidance, float 
     return pww::cfg_combine(cond, uncond, guidance, out, (long)n, dtype, static_cast<hipStream_t>(stream));
 }
 
-size_t pww_workspace_bytes(const pww_attn_desc_t *desc) { (void)desc; return 0; }
+size_t pww_workspace_bytes(const pww_attn_desc_t *desc) { return pww::qk_reduce_workspace_bytes(desc); }
 
 }  // extern "C"

@@ -18,26 +18,16 @@ struct ReduceParams {
     long q_sb, q_sh, q_sn;
     long k_sb, k_sh, k_sm;
     double *stats;  // [B][4] = max, min, sum, sumsq
+    double *partial;        // workspace: [B][blocks_per_image][4]
+    unsigned *ticket;       // workspace: [B] arrival counters (zeroed by the init kernel of every call)
+    int blocks_per_image;
 };
 
-__global__ void qk_stats_init_kernel(double *stats, int B) {
+// Re-initialise the arrival counters on the stream ahead of every reduction launch (a polled word must
+// be zeroed per call, never left to the previous launch -- guide G16).
+__global__ void qk_ticket_init_kernel(unsigned *ticket, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) {
-        stats[i * 4 + 0] = -INFINITY;
-        stats[i * 4 + 1] = INFINITY;
-        stats[i * 4 + 2] = 0.0;
-        stats[i * 4 + 3] = 0.0;
-    }
-}
-
-// Order-preserving atomic max/min on IEEE doubles via their integer images.
-__device__ __forceinline__ void atomic_max_f64(double *addr, double v) {
-    if (v >= 0.0) atomicMax(reinterpret_cast<long long *>(addr), __double_as_longlong(v));
-    else atomicMin(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(v));
-}
-__device__ __forceinline__ void atomic_min_f64(double *addr, double v) {
-    if (v >= 0.0) atomicMin(reinterpret_cast<long long *>(addr), __double_as_longlong(v));
-    else atomicMax(reinterpret_cast<unsigned long long *>(addr), (unsigned long long)__double_as_longlong(v));
+    if (i < B) ticket[i] = 0u;
 }
 
 template <typename T, int KS, int NW>
@@ -103,6 +93,15 @@ __global__ void __launch_bounds__(NW * 64) qk_reduce_kernel(const ReduceParams p
         red[wave * 4 + 2] = vsum; red[wave * 4 + 3] = vsq;
     }
     __syncthreads();
+    // Workgroup partial -> workspace; the LAST workgroup of the image to arrive folds all partials into
+    // stats[b]. (Four same-address fp64 atomics per workgroup serialise at L2: 512 workgroups x 4 cost
+    // ~25 us.) Hand-off = plain stores -> agent-scope release -> relaxed ticket; last arriver: agent-scope
+    // acquire -> plain loads: placement-independent (cdna_hip_programming.md, Guideline 16).
+    // (the flag lives in the dynamic LDS block: a static __shared__ object would shift the dynamic base
+    //  off its 16-byte alignment -- guide G17)
+    volatile int *is_last_p = reinterpret_cast<volatile int *>(red + NW * 4);
+#define is_last (*is_last_p)
+    const int blk = qb * p.H + h;   // index of this workgroup within image b
     if (tid == 0) {
         double dmax = -INFINITY, dmin = INFINITY, dsum = 0.0, dsq = 0.0;
         for (int w = 0; w < NW; ++w) {
@@ -111,18 +110,52 @@ __global__ void __launch_bounds__(NW * 64) qk_reduce_kernel(const ReduceParams p
             dsum += (double)red[w * 4 + 2];
             dsq += (double)red[w * 4 + 3];
         }
-        double *st = p.stats + b * 4;
-        if (dmax > -INFINITY) atomic_max_f64(st + 0, dmax);
-        if (dmin < INFINITY) atomic_min_f64(st + 1, dmin);
-        atomicAdd(st + 2, dsum);
-        atomicAdd(st + 3, dsq);
+        double *slot = p.partial + ((long)b * p.blocks_per_image + blk) * 4;
+        slot[0] = dmax; slot[1] = dmin; slot[2] = dsum; slot[3] = dsq;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned prev = __hip_atomic_fetch_add(p.ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = prev == (unsigned)(p.blocks_per_image - 1);
+        if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
+    __syncthreads();
+    if (is_last) {
+        double dmax = -INFINITY, dmin = INFINITY, dsum = 0.0, dsq = 0.0;
+        const double *base = p.partial + (long)b * p.blocks_per_image * 4;
+        for (int i = tid; i < p.blocks_per_image; i += NW * 64) {
+            dmax = fmax(dmax, base[i * 4 + 0]);
+            dmin = fmin(dmin, base[i * 4 + 1]);
+            dsum += base[i * 4 + 2];
+            dsq += base[i * 4 + 3];
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            dmax = fmax(dmax, __shfl_xor(dmax, off));
+            dmin = fmin(dmin, __shfl_xor(dmin, off));
+            dsum += __shfl_xor(dsum, off);
+            dsq += __shfl_xor(dsq, off);
+        }
+        double *fin = reinterpret_cast<double *>(smem);   // K tile no longer needed: [NW][4] doubles
+        __syncthreads();
+        if (lane == 0) { fin[wave * 4 + 0] = dmax; fin[wave * 4 + 1] = dmin; fin[wave * 4 + 2] = dsum; fin[wave * 4 + 3] = dsq; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < NW; ++w) {
+                dmax = fmax(dmax, fin[w * 4 + 0]); dmin = fmin(dmin, fin[w * 4 + 1]);
+                dsum += fin[w * 4 + 2]; dsq += fin[w * 4 + 3];
+            }
+            double *st = p.stats + b * 4;
+            st[0] = dmax; st[1] = dmin; st[2] = dsum; st[3] = dsq;
+        }
+    }
+#undef is_last
 }
 
 template <typename T, int KS, int NW>
-static int launch_reduce(const ReduceParams &p, hipStream_t stream) {
-    constexpr size_t lds = KTile<KS>::BYTES + NW * 4 * sizeof(float);
+static int launch_reduce(ReduceParams p, hipStream_t stream) {
+    constexpr size_t lds = KTile<KS>::BYTES + NW * 4 * sizeof(float) + 16;
     const int qblocks = (p.N + NW * 32 - 1) / (NW * 32);
+    p.blocks_per_image = qblocks * p.H;
     hipLaunchKernelGGL((qk_reduce_kernel<T, KS, NW>), dim3((unsigned)(qblocks * p.B * p.H)), dim3(NW * 64),
                        lds, stream, p);
     return check_hip(hipGetLastError(), "qk_reduce_kernel launch");
@@ -142,8 +175,21 @@ template <typename T> static int dispatch_reduce(const ReduceParams &p, hipStrea
 #undef PWW_RED
 }
 
-int qk_reduce(const void *q, const void *k, const pww_attn_desc_t *d, double *stats, hipStream_t stream) {
-    if (!d || !q || !k || !stats) { set_error("qk_reduce: null argument"); return PWW_EINVAL; }
+// blocks per image in the worst case (2-wave workgroups) -> workspace layout [B][max_blocks][4] doubles + [B] tickets
+static long reduce_max_blocks(const pww_attn_desc_t *d) { return (long)((d->N + 63) / 64) * d->H; }
+
+size_t qk_reduce_workspace_bytes(const pww_attn_desc_t *d) {
+    if (!d || d->B <= 0 || d->H <= 0 || d->N <= 0) return 0;
+    return (size_t)d->B * reduce_max_blocks(d) * 4 * sizeof(double) + (size_t)((d->B + 1) / 2) * 2 * sizeof(unsigned) + 64;
+}
+
+int qk_reduce(const void *q, const void *k, const pww_attn_desc_t *d, double *stats, void *workspace,
+              size_t workspace_bytes, hipStream_t stream) {
+    if (!d || !q || !k || !stats || !workspace) { set_error("qk_reduce: null argument"); return PWW_EINVAL; }
+    if (workspace_bytes < qk_reduce_workspace_bytes(d) || (reinterpret_cast<uintptr_t>(workspace) & 7)) {
+        set_error("qk_reduce: workspace too small or misaligned (need %zu bytes, 8-byte aligned)", qk_reduce_workspace_bytes(d));
+        return PWW_EINVAL;
+    }
     if (d->B <= 0 || d->H <= 0 || d->N <= 0 || d->M <= 0 || d->D <= 0) { set_error("qk_reduce: non-positive dimension"); return PWW_EINVAL; }
     if (d->D % 8 != 0 || d->D > PWW_MAX_HEAD_DIM) { set_error("qk_reduce: head dim %d unsupported", d->D); return PWW_ENOTSUP; }
     if (d->dtype != PWW_DTYPE_F16 && d->dtype != PWW_DTYPE_BF16) { set_error("qk_reduce: dtype %d unsupported", d->dtype); return PWW_ENOTSUP; }
@@ -158,8 +204,11 @@ int qk_reduce(const void *q, const void *k, const pww_attn_desc_t *d, double *st
     p.q_sb = d->q_stride[0]; p.q_sh = d->q_stride[1]; p.q_sn = d->q_stride[2];
     p.k_sb = d->k_stride[0]; p.k_sh = d->k_stride[1]; p.k_sm = d->k_stride[2];
     p.stats = stats;
-    hipLaunchKernelGGL(qk_stats_init_kernel, dim3((d->B + 63) / 64), dim3(64), 0, stream, stats, d->B);
-    if (int rc = check_hip(hipGetLastError(), "qk_stats_init_kernel launch")) return rc;
+    p.partial = reinterpret_cast<double *>(workspace);
+    p.ticket = reinterpret_cast<unsigned *>(p.partial + (long)d->B * reduce_max_blocks(d) * 4);
+    p.blocks_per_image = 0;
+    hipLaunchKernelGGL(qk_ticket_init_kernel, dim3((d->B + 63) / 64), dim3(64), 0, stream, p.ticket, d->B);
+    if (int rc = check_hip(hipGetLastError(), "qk_ticket_init_kernel launch")) return rc;
     return d->dtype == PWW_DTYPE_F16 ? dispatch_reduce<f16>(p, stream) : dispatch_reduce<bf16>(p, stream);
 }
 

@@ -57,7 +57,7 @@ def load():
     lib.pww_device_arch.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     lib.pww_self_attn_fwd.argtypes = [vp, vp, vp, vp, ctypes.POINTER(AttnDesc), vp]
     lib.pww_cross_attn_fwd.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.POINTER(AttnDesc), vp]
-    lib.pww_qk_reduce.argtypes = [vp, vp, ctypes.POINTER(AttnDesc), vp, vp]
+    lib.pww_qk_reduce.argtypes = [vp, vp, ctypes.POINTER(AttnDesc), vp, vp, ctypes.c_size_t, vp]
     lib.pww_mask_build.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.pww_mask_build_rgb.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, i32, vp, vp]
     lib.pww_mask_build_f32.argtypes = [vp, i32, i32, i32, vp, vp, i32, i32, vp, vp]

@@ -110,8 +110,11 @@ def qk_stats(q, k, heads):
     q, k = _prep(q), _prep(k)
     stats = torch.empty((q.shape[0], 4), dtype=torch.float64, device=q.device)
     d = _desc(q, k, None, None, heads, 1.0)
+    lib = _lib.load()
+    nbytes = int(lib.pww_workspace_bytes(ctypes.byref(d)))
+    ws = torch.empty(((nbytes + 7) // 8,), dtype=torch.float64, device=q.device)   # caching allocator: stream-ordered reuse
     with torch.cuda.device(q.device):
-        _lib.check(_lib.load().pww_qk_reduce(_ptr(q), _ptr(k), ctypes.byref(d), _ptr(stats), _stream()),
+        _lib.check(lib.pww_qk_reduce(_ptr(q), _ptr(k), ctypes.byref(d), _ptr(stats), _ptr(ws), ws.numel() * 8, _stream()),
                    "pww_qk_reduce")
     return stats
 

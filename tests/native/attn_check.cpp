@@ -73,11 +73,13 @@ static void run_case(const Case &c, bool timing) {
     if (!bias.empty()) { dbias = dalloc<float>(bias.size()); HIPCHECK(hipMemcpy(dbias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice)); }
     if (!coeff.empty()) { dcoeff = dalloc<float>(coeff.size()); HIPCHECK(hipMemcpy(dcoeff, coeff.data(), coeff.size() * 4, hipMemcpyHostToDevice)); }
     double *dstats = dalloc<double>(4 * B);
+    const size_t ws_bytes = pww_workspace_bytes(&d);
+    void *dws = dalloc<char>(ws_bytes + 8);
 
     int rc = c.bias_mode ? pww_cross_attn_fwd(dq, dk, dv, dout, dbias, dcoeff, &d, nullptr)
                          : pww_self_attn_fwd(dq, dk, dv, dout, &d, nullptr);
     if (rc) { printf("FAIL %-28s attn rc=%d err=%s\n", c.name, rc, pww_last_error()); g_fail++; return; }
-    rc = pww_qk_reduce(dq, dk, &d, dstats, nullptr);
+    rc = pww_qk_reduce(dq, dk, &d, dstats, dws, ws_bytes, nullptr);
     if (rc) { printf("FAIL %-28s reduce rc=%d err=%s\n", c.name, rc, pww_last_error()); g_fail++; return; }
     HIPCHECK(hipDeviceSynchronize());
     std::vector<uint16_t> out(q.size());
@@ -164,12 +166,12 @@ static void run_case(const Case &c, bool timing) {
         float ms = 0; HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / iters, flops = 4.0 * B * H * (double)N * M * D;
         HIPCHECK(hipEventRecord(e0, nullptr));
-        for (int i = 0; i < iters; ++i) pww_qk_reduce(dq, dk, &d, dstats, nullptr);
+        for (int i = 0; i < iters; ++i) pww_qk_reduce(dq, dk, &d, dstats, dws, ws_bytes, nullptr);
         HIPCHECK(hipEventRecord(e1, nullptr)); HIPCHECK(hipEventSynchronize(e1));
         float ms2 = 0; HIPCHECK(hipEventElapsedTime(&ms2, e0, e1));
         printf("TIME %-28s attn %.2f us/call  %.1f TFLOP/s (algorithmic 4BHNMD) | qk_reduce %.2f us/call\n", c.name, us, flops / us * 1e-6, ms2 * 1e3 / iters);
     }
-    hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dout); hipFree(dstats); if (dbias) hipFree(dbias); if (dcoeff) hipFree(dcoeff);
+    (void)hipFree(dws); hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dout); hipFree(dstats); if (dbias) hipFree(dbias); if (dcoeff) hipFree(dcoeff);
 }
 
 // ---- mask build ------------------------------------------------------------------------------
