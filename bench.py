@@ -56,22 +56,16 @@ def build_tools(device, dtype, scheduler_name, rank, world, inpaint=False):
     from pww_hip import dist as pdist
     cfg = SD15_INPAINT_CONFIG if inpaint else SD15_CONFIG
     t0 = time.time()
-    if rank == 0:
-        unet = build_unet(cfg, seed=1234, dtype=dtype, device=device, qk_gain=2.0)
-    else:   # structure only; values arrive by broadcast
-        with torch.device("meta"):
-            unet = UNet2DConditionModel(**cfg)
-        unet = unet.to_empty(device=device).to(dtype).eval().requires_grad_(False)
-    t1 = time.time()
-    nbytes = pdist.broadcast_module(unet, src=0)
+    unet, nbytes = pdist.build_and_broadcast(lambda: build_unet(cfg, seed=1234, dtype=dtype, device="cpu", qk_gain=2.0),
+                                             lambda: UNet2DConditionModel(**cfg), device, dtype, src=0)
     if world > 1:
         torch.cuda.synchronize()
-    t2 = time.time()
+    t1 = t2 = time.time()
     text = TinyTextEncoder(cfg["cross_attention_dim"], seed=1235).to(device=device, dtype=dtype)
     vae = TinyVAE(4, seed=1236).to(device=device, dtype=dtype)
     sched = (PLMSScheduler() if scheduler_name == "plms" else
              LMSDiscreteScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000))
-    info = {"build_s": round(t1 - t0, 2), "broadcast_s": round(t2 - t1, 4), "broadcast_bytes": int(nbytes)}
+    info = {"build_and_broadcast_s": round(t2 - t0, 2), "broadcast_bytes": int(nbytes)}
     return (vae, unet, text, HashTokenizer(), sched), info
 
 

@@ -165,12 +165,47 @@ def gen_loops(ref, full):
         print(f"loop_{name}: {dt:.1f}s latents std {lat.std():.4f} absmean {np.abs(lat).mean():.4f}")
 
 
+def gen_inpaint():
+    """paint_with_words_inpaint (reference paint_with_words_inpaint.py:137-270) on the tiny 9-channel UNet:
+    aurora_1.png color map, moon_mask.png, a seeded synthetic init image (BASELINE config 4 inputs, reduced UNet)."""
+    ref = ref_loader.load_reference_inpaint()
+    au = np.array(Image.open(os.path.join(ref_loader.REFERENCE_ROOT, "contents", "aurora_1.png")).convert("RGB"))
+    mask = Image.open(os.path.join(ref_loader.REFERENCE_ROOT, "contents", "moon_mask.png"))
+    mask.convert("L").save(os.path.join(GOLDEN, "moon_mask_L.png"), optimize=True)
+    init = cases.synthetic_init_image()
+    tools = cases.build_tools("tiny_inpaint")
+    for m in tools[1].modules():
+        if m.__class__.__name__ == "CrossAttention":
+            m.__class__.__call__ = ref["inj_forward"] if "inj_forward" in ref else ref_loader.load_reference()["inj_forward"]
+    captured = {}
+
+    def grab(vae, latents):
+        captured["latents"] = latents.detach().clone()
+        return [Image.new("RGB", (8, 8))]
+    ref["_pil_from_latents"] = grab
+    try:
+        ctx = {k: v for k, v in list(cases.AURORA_SEED_CONTEXT.items())[:4]}
+        ctx = {k: ",".join(v.split(",")[:2]) for k, v in ctx.items()}
+        ref["paint_with_words_inpaint"](color_context=dict(ctx), color_map_image=Image.fromarray(au), mask_image=Image.open(os.path.join(GOLDEN, "moon_mask_L.png")),
+                                        init_image=Image.fromarray(init), input_prompt=cases.AURORA_PROMPT, num_inference_steps=8,
+                                        guidance_scale=7.5, seed=81, device="cpu",
+                                        weight_function=lambda w, sigma, qk: 0.15 * w * math.log(1 + sigma) * qk.max(),
+                                        preloaded_utils=tools, strength=1.0)
+    finally:
+        from sd_standin import CrossAttention
+        if "__call__" in CrossAttention.__dict__:
+            del CrossAttention.__call__
+    lat = captured["latents"].numpy()
+    np.savez_compressed(os.path.join(GOLDEN, "loop_tiny_inpaint8.npz"), latents=lat)
+    print("loop_tiny_inpaint8: latents std %.4f" % lat.std())
+
+
 if __name__ == "__main__":
     assert ref_loader.available(), "reference not found at %s" % ref_loader.REFERENCE_ROOT
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     ref = ref_loader.load_reference()
-    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["kat", "masks", "attn", "loops"]
+    which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["kat", "masks", "attn", "loops", "inpaint"]
     if "kat" in which:
         gen_kat(ref)
     if "masks" in which:
@@ -179,3 +214,5 @@ if __name__ == "__main__":
         gen_attention(ref)
     if "loops" in which:
         gen_loops(ref, "--full" in sys.argv)
+    if "inpaint" in which:
+        gen_inpaint()

@@ -354,3 +354,41 @@ def nearest_resize(mask, out_h, out_w):
     ys = np.minimum(np.floor(np.arange(out_h, dtype=np.float32) * (np.float32(H) / np.float32(out_h))).astype(np.int64), H - 1)
     xs = np.minimum(np.floor(np.arange(out_w, dtype=np.float32) * (np.float32(W) / np.float32(out_w))).astype(np.int64), W - 1)
     return mask[..., ys, :][..., xs]
+
+
+def paint_with_words_inpaint_latents(color_context, color_map_rgb, mask_l, init_rgb, input_prompt, vae, unet, text_encoder,
+                                     tokenizer, scheduler, num_inference_steps=150, guidance_scale=7.5, seed=0,
+                                     weight_function=lambda w, sigma, qk: 0.1 * w * math.log(sigma + 1) * qk.max(),
+                                     strength=1.0):
+    """paint_with_words_inpaint.py:137-266 up to the final latent, for inputs already at the init image's size
+    (the reference's NEAREST resize of color map / mask, :172-173, is then the identity) and a side that is a
+    multiple of 32 (so `preprocess`, paint_with_words.py:28-35, does not resample)."""
+    H, W = init_rgb.shape[:2]
+    assert color_map_rgb.shape[:2] == (H, W) and mask_l.shape == (H, W) and H % 32 == 0 and W % 32 == 0
+    _, _, cond, uncond = encode_text_color_inputs(text_encoder, tokenizer, color_map_rgb, color_context, input_prompt, "")
+    mask, masked_image = prepare_mask_and_masked_image(init_rgb, mask_l)
+    scheduler.set_timesteps(num_inference_steps)
+    offset = scheduler.config.get("steps_offset", 0)
+    init_timestep = min(int(num_inference_steps * strength) + offset, num_inference_steps)
+    t_start = max(num_inference_steps - init_timestep + offset, 0)
+    timesteps = scheduler.timesteps[t_start:]
+    generator = torch.manual_seed(seed)
+    image = 2.0 * torch.from_numpy(init_rgb.astype(np.float32) / 255.0)[None].permute(0, 3, 1, 2) - 1.0
+    init_latents = 0.18215 * vae.encode(image).latent_dist.sample()
+    noise = torch.randn(init_latents.shape, generator=generator)
+    latents = scheduler.add_noise(init_latents, noise, timesteps[:1])
+    # :201-214: mask to latent resolution (nearest), masked image through the VAE encoder
+    mask_lat = torch.from_numpy(nearest_resize(mask.numpy(), H // 8, W // 8))
+    masked_latents = 0.18215 * vae.encode(masked_image).latent_dist.sample()
+    extra = torch.cat([mask_lat, masked_latents], dim=1)
+    assert latents.shape[1] + extra.shape[1] == unet.in_channels
+    for t in timesteps:
+        i = int((scheduler.timesteps == t).nonzero().item())
+        sigma = scheduler.sigmas[i]
+        x = torch.cat([scheduler.scale_model_input(latents, t), extra], dim=1)
+        cond.update({"SIGMA": sigma, "WEIGHT_FUNCTION": weight_function})
+        eps_c = unet(x, t, encoder_hidden_states=cond).sample
+        uncond.update({"SIGMA": sigma, "WEIGHT_FUNCTION": lambda w, sigma, qk: 0.0})
+        eps_u = unet(x, t, encoder_hidden_states=uncond).sample
+        latents = scheduler.step(cfg_combine(eps_c, eps_u, guidance_scale), t, latents).prev_sample
+    return latents

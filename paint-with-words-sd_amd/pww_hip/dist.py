@@ -65,6 +65,23 @@ def broadcast_module(module, src=0, group=None):
     return total
 
 
+def build_and_broadcast(build_fn, skeleton_fn, device, dtype, src=0, group=None):
+    """Model set-up for image-sharded inference: rank `src` builds the real module (`build_fn()`: seeded
+    random init or a checkpoint load), every other rank only allocates the structure (`skeleton_fn()` under
+    the meta device, then `to_empty`) and receives the values through ONE flat broadcast per dtype.
+    Returns (module, bytes_broadcast)."""
+    rank = dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
+    if rank == src:
+        module = build_fn().to(device=device, dtype=dtype)
+    else:
+        with torch.device("meta"):
+            module = skeleton_fn()
+        module = module.to_empty(device=device).to(dtype)
+    module = module.eval().requires_grad_(False)
+    nbytes = broadcast_module(module, src=src, group=group)
+    return module, nbytes
+
+
 def broadcast_request(payload, device, src=0, group=None):
     """Broadcast a request (color map uint8 array + python metadata) from `src`.
     payload on src: dict with 'rgb' (uint8 numpy [H,W,3]) and picklable metadata; None elsewhere."""

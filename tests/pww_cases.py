@@ -98,6 +98,28 @@ def load_aurora_rgb():
     return np.array(Image.open(os.path.join(GOLDEN, "aurora_1.png")).convert("RGB"))
 
 
+def synthetic_init_image(size=512, seed=81):
+    """BASELINE config 4: init image = randn-derived uint8 (the reference's aurora_1_output.png is a
+    real-weights artifact)."""
+    g = torch.Generator().manual_seed(seed)
+    low = torch.randn(1, 3, size // 16, size // 16, generator=g)
+    img = torch.nn.functional.interpolate(low, size=(size, size), mode="bilinear", align_corners=False)[0]
+    img = ((img * 0.25 + 0.5).clamp(0, 1) * 255).round().to(torch.uint8).permute(1, 2, 0).contiguous().numpy()
+    return img
+
+
+def load_moon_mask():
+    from PIL import Image
+    return Image.open(os.path.join(GOLDEN, "moon_mask_L.png"))
+
+
+def weight_fn_inpaint(w, sigma, qk):         # runner_inpaint.py:87
+    return 0.15 * w * math.log(1 + sigma) * qk.max()
+
+
+INPAINT_CONTEXT = {k: ",".join(v.split(",")[:2]) for k, v in list(AURORA_SEED_CONTEXT.items())[:4]}
+
+
 # ---- seeded attention-module cases (SURVEY.md section 8c pin (1)) -------------------------------
 # name: (N tokens, channels C, heads, ctx_dim)
 ATTN_SHAPES = {

@@ -34,6 +34,16 @@ def _worker(rank, world, port, out_dir):
     assert nbytes == sum(p.numel() * p.element_size() for p in ref.parameters())
     for a, b in zip(unet.parameters(), ref.parameters()):
         assert torch.equal(a, b)
+    # (a') what bench.py does: rank 0 builds, the others allocate a meta skeleton and receive the values
+    from sd_standin import UNet2DConditionModel
+    m2, nb2 = pdist.build_and_broadcast(lambda: build_unet(TINY_CONFIG, seed=77), lambda: UNet2DConditionModel(**TINY_CONFIG),
+                                        dev, torch.float32, src=0)
+    ref2 = build_unet(TINY_CONFIG, seed=77)
+    assert nb2 == nbytes and not any(p.is_meta for p in m2.parameters())
+    for a, b in zip(m2.parameters(), ref2.parameters()):
+        assert torch.equal(a, b)
+    x = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(1))
+    assert torch.equal(m2(x, torch.tensor(10.0), torch.zeros(1, 77, 64)).sample, ref2(x, torch.tensor(10.0), torch.zeros(1, 77, 64)).sample)
     # (b) request broadcast: color map + region table
     payload = None
     if rank == 0:

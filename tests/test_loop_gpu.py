@@ -122,6 +122,79 @@ def test_folded_and_graph_match_eager_single_forward(gpu_device):
         uninstall_all()
 
 
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_inpaint_loop_vs_reference(gpu_device, mode):
+    """Drop-in paint_with_words_inpaint (9-channel UNet input, reference paint_with_words_inpaint.py:137-270)
+    against the final latent the real reference produced."""
+    import importlib
+    import paint_with_words as pw
+    pww_mod = importlib.import_module("paint_with_words.paint_with_words")
+    inp_mod = importlib.import_module("paint_with_words.paint_with_words_inpaint")
+    g = np.load(os.path.join(cases.GOLDEN, "loop_tiny_inpaint8.npz"))
+    old = (pww_mod.DEFAULT_MODE, inp_mod.DEFAULT_MODE)
+    pww_mod.DEFAULT_MODE = inp_mod.DEFAULT_MODE = mode
+    try:
+        tools = cases.build_tools("tiny_inpaint", dtype=torch.float16, device=gpu_device)
+        lat = pw.paint_with_words_inpaint(
+            color_context=dict(cases.INPAINT_CONTEXT), color_map_image=Image.fromarray(cases.load_aurora_rgb()),
+            mask_image=cases.load_moon_mask(), init_image=Image.fromarray(cases.synthetic_init_image()),
+            input_prompt=cases.AURORA_PROMPT, num_inference_steps=8, guidance_scale=7.5, seed=81, device=str(gpu_device),
+            weight_function=cases.weight_fn_inpaint, preloaded_utils=tools, strength=1.0, return_latents=True)
+    finally:
+        pww_mod.DEFAULT_MODE, inp_mod.DEFAULT_MODE = old
+        uninstall_all()
+    d = rel_l2(lat, g["latents"])
+    print(f"inpaint tiny fp16 {mode}: rel-L2 {d:.3e}")
+    assert d <= 2e-2
+    with pytest.raises(ValueError, match="Incorrect configuration"):     # 4-channel UNet with the inpaint entry point (:220-227)
+        pw.paint_with_words_inpaint(color_context=dict(cases.INPAINT_CONTEXT), color_map_image=Image.fromarray(cases.load_aurora_rgb()),
+                                    mask_image=cases.load_moon_mask(), init_image=Image.fromarray(cases.synthetic_init_image()),
+                                    input_prompt=cases.AURORA_PROMPT, num_inference_steps=2, device=str(gpu_device),
+                                    preloaded_utils=cases.build_tools("tiny", dtype=torch.float16, device=gpu_device))
+    uninstall_all()
+
+
+def _plms_oracle(steps, seed):
+    from oracle import pww_oracle as O
+    vae, unet, text, tok, sch = cases.build_tools("tiny", scheduler="plms")
+    O.install_oracle_attention(unet)
+    try:
+        return O.paint_with_words_latents(dict(cases.RUNNER_CONTEXT), cases.load_example_rgb(), cases.RUNNER_PROMPT, unet, text, tok,
+                                          sch, num_inference_steps=steps, guidance_scale=7.5, seed=seed,
+                                          weight_function=cases.weight_fn_runner)
+    finally:
+        uninstall_all()
+
+
+def test_plms_loop_and_batched_images(gpu_device):
+    """The headline bench runs PLMS (sigma_t := sqrt((1-abar_t)/abar_t), step index = loop counter -- the
+    reference cannot run PNDM, SURVEY 8 a-note) on several images per GPU. (a) PLMS on the HIP path equals the
+    oracle's PLMS loop; (b) a 3-image folded+graph batch equals the three images generated one by one
+    (per-image qk.max, per-row gate, seeds by global index)."""
+    from pww_hip.conditioning import _encode_text_color_inputs
+    from pww_hip.sampler import PwWSampler, initial_latents
+    dev, dtype, steps = gpu_device, torch.float16, 8
+    vae, unet, text, tok, sch = cases.build_tools("tiny", dtype=dtype, device=dev, scheduler="plms")
+    try:
+        def run(mode, seeds):
+            _, _, cond, uncond = _encode_text_color_inputs(text, tok, dev, cases.load_example_rgb(), dict(cases.RUNNER_CONTEXT),
+                                                           cases.RUNNER_PROMPT, "", dtype=dtype)
+            sch.set_timesteps(steps)
+            lat = initial_latents(0, 4, 512, 512, batch_seeds=seeds).to(dev) * sch.init_noise_sigma
+            return PwWSampler(unet, sch, mode).sample(cond, uncond, lat, sch.timesteps, 7.5, cases.weight_fn_runner)
+        single = torch.cat([run("eager", [s]) for s in (5, 6, 7)])
+        batched = run("graph", [5, 6, 7])
+        ref5 = _plms_oracle(steps, 5)
+    finally:
+        uninstall_all()
+    d_ref = rel_l2(single[:1], ref5)
+    d_batch = rel_l2(batched, single)
+    print(f"PLMS tiny fp16: eager vs oracle {d_ref:.3e}; 3-image graph batch vs one-by-one {d_batch:.3e}")
+    assert d_ref <= 2e-2
+    assert d_batch <= 1e-2
+    assert rel_l2(batched[0:1], batched[1:2]) > 0.5     # different seeds give different images
+
+
 def test_repeat_calls_reuse_graphs(gpu_device):
     """Second image through the same tools replays the captured graphs and matches an eager run."""
     import paint_with_words as pw
