@@ -58,8 +58,7 @@ def build_tools(device, dtype, scheduler_name, rank, world, inpaint=False):
     t0 = time.time()
     unet, nbytes = pdist.build_and_broadcast(lambda: build_unet(cfg, seed=1234, dtype=dtype, device="cpu", qk_gain=2.0),
                                              lambda: UNet2DConditionModel(**cfg), device, dtype, src=0)
-    if world > 1:
-        torch.cuda.synchronize()
+    torch.cuda.synchronize()
     t1 = t2 = time.time()
     text = TinyTextEncoder(cfg["cross_attention_dim"], seed=1235).to(device=device, dtype=dtype)
     vae = TinyVAE(4, seed=1236).to(device=device, dtype=dtype)
@@ -92,6 +91,47 @@ class EventTimer:
         torch.cuda.synchronize()
         ts = [a.elapsed_time(b) * 1e3 for a, b, _ in self.pairs]
         return (sum(ts) / len(ts), len(ts), self.pairs[0][2]) if ts else (None, 0, 0)
+
+
+def measured_traffic(n_tok, d, b_rows):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/r01_attn_traffic.json,
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the same shape through the native harness); None if the shape differs."""
+    path = os.path.join(REPO, "profiles", "r01_attn_traffic.json")
+    if not (os.path.isfile(path) and n_tok == 4096 and d == 40 and b_rows == 2):
+        return None
+    return int(json.load(open(path))["hbm_bytes_per_launch"])
+
+
+def reference_ops_same_gpu(args, tools, rgb, context, prompt, device, dtype):
+    """The reference's op sequence as plain torch ops (materialised scores, half matmuls, fp32 softmax: what its
+    inj_forward does under autocast on a GPU) with its call pattern (eager, two batch-1 UNet calls per step) on
+    THIS GPU -- separates the fused-kernel / folding / graph gain from the CPU->GPU gain. One image, timed."""
+    from pww_hip.conditioning import _encode_text_color_inputs
+    from pww_hip.sampler import PwWSampler, initial_latents
+    import pww_hip.sampler as S
+    from gpu_util import install_unfused, uninstall_all
+    vae, unet, text, tok, sched = tools
+    orig_install = S.install
+    S.install = install_unfused
+    try:
+        sampler = PwWSampler(unet, sched, "eager")
+        times = []
+        for it in range(2):     # first pass warms the unfused kernels up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, _, cond, uncond = _encode_text_color_inputs(text, tok, device, rgb, dict(context), prompt, "", dtype=dtype)
+            sched.set_timesteps(args.denoise_steps)
+            lat = initial_latents(0, unet.in_channels, rgb.shape[0], rgb.shape[1], batch_seeds=[0]).to(device) * sched.init_noise_sigma
+            sampler.sample(cond, uncond, lat, sched.timesteps, args.guidance, weight_function)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    finally:
+        S.install = orig_install
+        uninstall_all()
+        import pww_hip
+        pww_hip.install(unet)
+    return {"value": round(1.0 / times[-1], 4), "unit": "images/s", "kind": "unfused torch ops, eager, 2 batch-1 UNet calls/step (the reference's GPU path)",
+            "s_per_image": round(times[-1], 3)}
 
 
 def cpu_baseline(args, rgb, context, prompt, n_denoise_steps):
@@ -144,6 +184,7 @@ def main():
     ap.add_argument("--guidance", type=float, default=7.5)
     ap.add_argument("--cpu-steps", type=int, default=2, help="denoise steps timed for the CPU baseline (0 = skip)")
     ap.add_argument("--no-roofline-pass", action="store_true")
+    ap.add_argument("--no-reference-ops", action="store_true", help="skip the unfused-torch-ops-on-this-GPU pass")
     args = ap.parse_args()
 
     from pww_hip import dist as pdist, ops
@@ -152,6 +193,8 @@ def main():
     from pww_hip.conditioning import _encode_text_color_inputs
     from pww_hip.sampler import PwWSampler, initial_latents
 
+    if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", ""):
+        os.environ["NCCL_DEBUG"] = "WARN"     # the pool exports NCCL_DEBUG=VERSION: RCCL would print a banner on stdout
     rank, world, local = pdist.init_from_env("cuda")
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     torch.cuda.set_device(local)
@@ -186,12 +229,12 @@ def main():
         one_step(w)
         torch.cuda.synchronize()
         log("warmup step", w, "done")
-    pdist.barrier()
+    pdist.barrier(device)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(args.steps):
         lat = one_step(args.warmup + s)
-    pdist.barrier()
+    pdist.barrier(device)
     torch.cuda.synchronize()
     elapsed = pdist.max_over_ranks(time.perf_counter() - t0, device)
     assert torch.isfinite(lat).all(), "non-finite latents"
@@ -232,12 +275,15 @@ def main():
             ach = flops / (us * 1e-6) / 1e12
             result["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel<%s, d=40> self-attention N=%d (B=%d rows folded)" % (args.dtype, n_tok, b_rows),
                                   "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                                  "traffic": None, "avg_us": round(us, 2), "launches": n_launch, "flops_per_launch": flops}
+                                  "traffic": measured_traffic(n_tok, d, b_rows), "algorithmic_bytes": 2 * (2 * b_rows * n_tok * heads * d) * 2, "avg_us": round(us, 2), "launches": n_launch, "flops_per_launch": flops}
+    if rank == 0 and world == 1 and not args.no_reference_ops:
+        result["reference_ops_same_gpu"] = reference_ops_same_gpu(args, tools, rgb, context, prompt, device, dtype)
+        log("reference-ops pass done", result["reference_ops_same_gpu"])
     if rank == 0 and world == 1 and args.cpu_steps > 0:
         result["cpu_baseline"] = cpu_baseline(args, rgb, context, prompt, args.denoise_steps)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

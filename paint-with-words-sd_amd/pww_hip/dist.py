@@ -21,13 +21,17 @@ def init_from_env(device_type="cuda"):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # under a launcher (RANK set) the group is created even for one rank, so a single-GPU torchrun
+    # exercises the same RCCL calls as an 8-GPU one
+    if (world > 1 or "RANK" in os.environ) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = "nccl" if device_type == "cuda" else "gloo"
         if device_type == "cuda":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
@@ -46,7 +50,7 @@ def image_seeds(base_seed, n_global, rank, world):
 
 def broadcast_module(module, src=0, group=None):
     """Make every rank's parameters and buffers equal to rank `src`'s with ONE broadcast per dtype."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return 0
     tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
     by_dtype = {}
@@ -85,7 +89,7 @@ def build_and_broadcast(build_fn, skeleton_fn, device, dtype, src=0, group=None)
 def broadcast_request(payload, device, src=0, group=None):
     """Broadcast a request (color map uint8 array + python metadata) from `src`.
     payload on src: dict with 'rgb' (uint8 numpy [H,W,3]) and picklable metadata; None elsewhere."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return payload
     rank = dist.get_rank(group)
     if rank == src:
@@ -114,7 +118,7 @@ def broadcast_request(payload, device, src=0, group=None):
 
 def gather_latents(latents, dst=0, group=None):
     """Gather every rank's final latents on `dst` (list in rank order there, None elsewhere)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return [latents]
     world = dist.get_world_size(group)
     counts = [torch.zeros(1, dtype=torch.int64, device=latents.device) for _ in range(world)]
@@ -130,7 +134,7 @@ def gather_latents(latents, dst=0, group=None):
 
 
 def max_over_ranks(value, device, group=None):
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
@@ -138,5 +142,8 @@ def max_over_ranks(value, device, group=None):
 
 
 def barrier(device=None, group=None):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.barrier(group=group)
+    if dist.is_available() and dist.is_initialized():
+        if device is not None and torch.device(device).type == "cuda":
+            dist.barrier(group=group, device_ids=[torch.device(device).index or 0])
+        else:
+            dist.barrier(group=group)
