@@ -21,6 +21,7 @@ from ._lib import PwwHipError
 
 _HALF = (torch.float16, torch.bfloat16)
 ROW_GATE = "_PWW_ROW_GATE"   # private context key: fp32 [B] per-row bias coefficient (see pww_hip/sampler.py)
+KV_CACHE = "_PWW_KV_CACHE"   # private context key: {id(attn): (attn, [B, 77, 2C] fused K|V projection)} for one request
 _warned = set()
 
 
@@ -198,6 +199,33 @@ def _half(t, like_dtype):
     return t.to(like_dtype)
 
 
+def _fused_weight(attn, names):
+    """Concatenated projection weight ([sum C_out, C_in]) of bias-free Linear layers, cached on the module and
+    rebuilt when any source weight changes (one GEMM instead of three / two)."""
+    mods = [getattr(attn, n) for n in names]
+    if any(getattr(m, "bias", None) is not None for m in mods):
+        return None
+    key = tuple((m.weight.data_ptr(), m.weight._version, m.weight.dtype, m.weight.device) for m in mods)
+    cache = attn.__dict__.setdefault("_pww_fused", {})
+    ent = cache.get(names)
+    if ent is None or ent[0] != key:
+        ent = (key, torch.cat([m.weight.detach() for m in mods], dim=0).contiguous())
+        cache[names] = ent
+    return ent[1]
+
+
+def refresh_kv_cache(context):
+    """Recompute every cached fused K|V projection of a request context IN PLACE (hipGraph mode: the captured
+    graphs read these tensors by address, and the context tensor was just overwritten with a new request)."""
+    cache = context.get(KV_CACHE)
+    if not cache:
+        return
+    ctx = context["CONTEXT_TENSOR"]
+    for attn, kv in cache.values():
+        w = _fused_weight(attn, ("to_k", "to_v"))
+        kv.copy_(F.linear(ctx.to(w.dtype), w))
+
+
 def pww_attention(attn, hidden_states, context=None):
     """Core of inj_forward (:63-118): projections -> [optional bias] -> fused attention, returning the
     merged-head [B, N, heads*D] tensor BEFORE the output projection."""
@@ -219,9 +247,26 @@ def pww_attention(attn, hidden_states, context=None):
         context_tensor = context_tensor.to(wdt)   # text encoder is fp32 in the reference (:171)
     if hidden_states.dtype != wdt and not torch.is_autocast_enabled():
         hidden_states = hidden_states.to(wdt)
-    query = attn.to_q(hidden_states)
-    key = attn.to_k(context_tensor)
-    value = attn.to_v(context_tensor)
+    C = attn.to_q.weight.shape[0]
+    fuse = not torch.is_autocast_enabled()
+    if context is None and fuse and (w_qkv := _fused_weight(attn, ("to_q", "to_k", "to_v"))) is not None:
+        qkv = F.linear(hidden_states, w_qkv)                    # self-attention: ONE GEMM, q/k/v are strided views
+        query, key, value = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    elif context is not None and fuse and (w_kv := _fused_weight(attn, ("to_k", "to_v"))) is not None:
+        query = attn.to_q(hidden_states)
+        kv_cache = context.get(KV_CACHE) if is_dict else None
+        ent = kv_cache.get(id(attn)) if kv_cache is not None else None
+        if ent is None:
+            kv = F.linear(context_tensor, w_kv)                 # cross-attention: K|V in one GEMM ...
+            if kv_cache is not None:
+                kv_cache[id(attn)] = (attn, kv)                 # ... and once per request: the prompt is constant over the steps
+        else:
+            kv = ent[1]
+        key, value = kv[..., :C], kv[..., C:]
+    else:
+        query = attn.to_q(hidden_states)
+        key = attn.to_k(context_tensor)
+        value = attn.to_v(context_tensor)
     cdt = query.dtype if query.dtype in _HALF else torch.bfloat16
     query, key, value = _half(query, cdt), _half(key, cdt), _half(value, cdt)
 

@@ -15,7 +15,7 @@ Three execution modes over the SAME arithmetic:
 import torch
 
 from . import ops
-from .attention import install, ROW_GATE
+from .attention import install, refresh_kv_cache, ROW_GATE, KV_CACHE
 
 
 def initial_latents(seed, in_channels, height, width, region_masks=None, extra_seeds=None, batch_seeds=None):
@@ -44,6 +44,7 @@ def _fold_context(cond, uncond, n_images, device):
     c = c.expand(n_images, -1, -1) if c.shape[0] == 1 else c
     u = u.expand(n_images, -1, -1) if u.shape[0] == 1 else u
     folded = dict(cond)
+    folded[KV_CACHE] = {}
     folded["CONTEXT_TENSOR"] = torch.cat([c, u], dim=0).contiguous()
     folded[ROW_GATE] = torch.cat([torch.ones(n_images), torch.zeros(n_images)]).to(device=device, dtype=torch.float32)
     return folded
@@ -113,6 +114,7 @@ class PwWSampler:
             for k, v in folded.items():
                 if torch.is_tensor(v):
                     self._static_folded[k].copy_(v)
+            refresh_kv_cache(self._static_folded)     # new prompt embedding -> new K|V, same addresses
         return self._static_folded
 
     def _sigma_and_index(self, i, t):
@@ -132,6 +134,9 @@ class PwWSampler:
         sch, unet, dev = self.scheduler, self.unet, latents.device
         n = latents.shape[0]
         udt = unet.dtype if hasattr(unet, "dtype") else next(unet.parameters()).dtype
+        if self.mode == "eager":   # per-request caches of the fused K|V projections (prompt constant over the steps)
+            cond.setdefault(KV_CACHE, {}).clear()
+            uncond.setdefault(KV_CACHE, {}).clear()
         folded = None
         if self.mode != "eager":
             folded = _fold_context(cond, uncond, n, dev)

@@ -188,6 +188,52 @@ def test_folded_cfg_rows_are_gated(gpu_device):
             assert (yc - yu).abs().max().item() > 50 * tol      # the bias is far from a no-op here
 
 
+def test_fused_projections_and_kv_cache(gpu_device):
+    """one fused QKV GEMM (self) / one fused K|V GEMM computed once per request (cross) must give
+    what the three separate nn.Linear calls of the reference (:76-79) give; the per-request cache must be
+    refreshed in place for a new prompt and invalidated when weights change."""
+    import pww_hip
+    from pww_hip import attention as A
+    case = cases.make_attention_case("sd15_n256", seed=8)
+    dev, dtype = gpu_device, torch.float16
+    mod_s, mod_c = case["attn_self"].to(dev, dtype), case["attn_cross"].to(dev, dtype)
+    hidden = case["hidden"].to(dev, dtype)
+    ctx1, ctx2 = case["ctx"].to(dev, dtype), (case["ctx"] * 0.5 + 0.3).to(dev, dtype)
+    with torch.autocast("cuda", enabled=False):
+        y_self = pww_hip.inj_forward(mod_s, hidden)
+    q, k, v = mod_s.to_q(hidden), mod_s.to_k(hidden), mod_s.to_v(hidden)
+    ref_self = mod_s.to_out[0](pww_hip.ops.attention(q, k, v, mod_s.heads, mod_s.scale))
+    assert (y_self.float() - ref_self.float()).abs().max() <= 2e-3 * ref_self.float().abs().max()
+
+    def ctx_dict(t, cache):
+        d = {"CONTEXT_TENSOR": t, "CROSS_ATTENTION_WEIGHT_256": case["w"].to(dev), "SIGMA": torch.tensor(4.0),
+             "WEIGHT_FUNCTION": cases.weight_fn_runner}
+        if cache is not None:
+            d[A.KV_CACHE] = cache
+        return d
+    cache = {}
+    d1 = ctx_dict(ctx1.clone(), cache)
+    y1 = pww_hip.inj_forward(mod_c, hidden, d1)
+    assert len(cache) == 1
+    y1_again = pww_hip.inj_forward(mod_c, hidden, d1)                    # served from the cache
+    assert torch.equal(y1, y1_again)
+    y1_nocache = pww_hip.inj_forward(mod_c, hidden, ctx_dict(ctx1, None))
+    assert (y1.float() - y1_nocache.float()).abs().max() <= 1e-3 * y1.float().abs().max()
+    # new prompt in the same (static) buffers: stale until refreshed
+    d1["CONTEXT_TENSOR"].copy_(ctx2)
+    A.refresh_kv_cache(d1)
+    y2 = pww_hip.inj_forward(mod_c, hidden, d1)
+    y2_ref = pww_hip.inj_forward(mod_c, hidden, ctx_dict(ctx2, None))
+    assert (y2.float() - y2_ref.float()).abs().max() <= 1e-3 * y2_ref.float().abs().max()
+    assert (y2.float() - y1.float()).abs().max() > 0.05 * y1.float().abs().max()
+    # weight update invalidates the fused weight
+    with torch.no_grad():
+        mod_s.to_k.weight.mul_(1.5)
+    y_self2 = pww_hip.inj_forward(mod_s, hidden)
+    ref2 = mod_s.to_out[0](pww_hip.ops.attention(mod_s.to_q(hidden), mod_s.to_k(hidden), mod_s.to_v(hidden), mod_s.heads, mod_s.scale))
+    assert (y_self2.float() - ref2.float()).abs().max() <= 2e-3 * ref2.float().abs().max()
+
+
 def test_exotic_weight_function_materializes(gpu_device):
     """A weight function that uses qk element-wise still works (QKProxy materialises Q K^T)."""
     import pww_hip
