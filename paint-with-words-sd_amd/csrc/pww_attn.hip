@@ -18,6 +18,7 @@
 //     tile, write them to LDS after the barrier), hiding HBM/L2 latency under the MFMAs.
 //   * blockIdx.x enumerates (b, h) fastest: with the observed block -> XCD round-robin every XCD's
 //     L2 keeps the K/V of a fixed subset of heads while all query blocks of those heads stream by.
+#include <stdlib.h>
 #include "pww_tile.h"
 
 namespace pww {
@@ -155,7 +156,7 @@ __device__ __forceinline__ float xhalf_max(float x) {
 // Waves per SIMD the register allocator must leave room for (2 => <= 256 VGPRs+AGPRs). The bias
 // variants (32 extra loads in flight per tile) and the widest heads keep the whole 512-entry file.
 template <int DT, int NW, bool HAS_BIAS> struct MinWaves {
-    static constexpr int value = (HAS_BIAS || DT >= 4 || (NW == 2 && DT >= 3)) ? 1 : 2;
+    static constexpr int value = (HAS_BIAS || DT >= 4 || (NW == 2 && DT >= 3)) ? 1 : (NW == 8 ? 1 : 2);
 };
 
 // One KV tile: scores -> (bias) -> online softmax -> PV. MASKED tiles (only the last one can be)
@@ -163,16 +164,31 @@ template <int DT, int NW, bool HAS_BIAS> struct MinWaves {
 // ROWSUM_MFMA: the head dim is not a multiple of 32, so the V^T tile has padding rows; row D holds
 // ones and the PV MFMA accumulates the softmax denominator there for free (no per-element adds).
 template <typename T, int KS, int DT, bool HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
+__device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[DT], float &m_run, float &l_run, const char *Vs,
+                                                int key0, int M, int l31, int hi, const float *bias_row, long b_sm,
+                                                float coeff, float c1, bool qvalid);
+
+template <typename T, int KS, int DT, bool HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
 __device__ __forceinline__ void attn_tile(f32x16 (&oacc)[DT], float &m_run, float &l_run,
                                           const typename Vec<T>::v8 (&qf)[KS], const char *Ks, const char *Vs,
                                           int key0, int M, int l31, int hi, const float *bias_row, long b_sm,
                                           float coeff, float c1, bool qvalid) {
-    typedef typename Vec<T>::v8 V8;
-    typedef VTile<DT> VT;
     f32x16 s[2];
     score_tile<T, KS>(s, qf, Ks, key0, MASKED ? M : 0x7fffffff, l31, hi);
+    attn_tile_sm_pv<T, KS, DT, HAS_BIAS, MASKED, ROWSUM_MFMA>(s, oacc, m_run, l_run, Vs, key0, M, l31, hi, bias_row, b_sm,
+                                                             coeff, c1, qvalid);
+}
+
+// scores (already in `s`) -> (bias) -> online softmax -> PV against the V^T tile at Vs
+template <typename T, int KS, int DT, bool HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
+__device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[DT], float &m_run, float &l_run, const char *Vs,
+                                                int key0, int M, int l31, int hi, const float *bias_row, long b_sm,
+                                                float coeff, float c1, bool qvalid) {
+    typedef typename Vec<T>::v8 V8;
+    typedef VTile<DT> VT;
 
     // raw-domain logits x = s + c*bias (scale > 0, so the row max commutes with the scaling)
+    // (a 4-way max tree and packed v_pk_fma_f32 for the exp arguments were measured: neutral to -3%)
     float tmax = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -366,13 +382,156 @@ __global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, HAS_BIAS>::value)) 
     }
 }
 
+// ---- software-pipelined variant -------------------------------------------------------------------
+// Same arithmetic, different schedule: 64-key stages in a THREE-deep LDS ring, one barrier per stage, and
+// the score MFMAs of tile t+1 are issued BEFORE the softmax of tile t, so inside one wave the matrix pipe
+// works on S(t+1) while the VALU does max/exp/convert of S(t). At 2 waves/SIMD (all a B=2 launch offers)
+// this ILP is what hides the MFMA latency; the ring keeps the hazards one barrier apart:
+//   iteration t: park tile t+2 (registers) in ring[(t+2)%3]   -- last read by PV(t-1), before barrier t-1
+//                issue the global loads of tile t+3
+//                S(t+1) = K(t+1) Q^T from ring[(t+1)%3]        -- written in iteration t-1, visible since barrier t-1
+//                softmax(S(t)), PV with V(t) from ring[t%3]
+//                barrier t
+template <typename T, int KS, int DT, int NW, bool HAS_BIAS, bool ROWSUM_MFMA>
+__global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, HAS_BIAS>::value)) attn_fwd_pipe_kernel(const AttnParams p) {
+    typedef typename Vec<T>::v8 V8;
+    typedef typename Vec<T>::v4 V4;
+    typedef KTile<KS> KT;
+    typedef VTile<DT> VT;
+    constexpr int NT = NW * 64;
+    constexpr int SUB_BYTES = KT::BYTES + VT::BYTES;
+    constexpr int KPT = (KT::NCHUNK + NT - 1) / NT;
+    constexpr int VPT = (VT::NUNIT + NT - 1) / NT;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // ring of three 64-key stages
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int BH = p.B * p.H;
+    const int bh = blockIdx.x % BH, qb = blockIdx.x / BH;
+    const int b = bh / p.H, h = bh - b * p.H;
+
+    const T *Qp = reinterpret_cast<const T *>(p.q) + b * p.q_sb + h * p.q_sh;
+    const T *Kp = reinterpret_cast<const T *>(p.k) + b * p.k_sb + h * p.k_sh;
+    const T *Vp = reinterpret_cast<const T *>(p.v) + b * p.v_sb + h * p.v_sh;
+    T *Op = reinterpret_cast<T *>(p.o) + b * p.o_sb + h * p.o_sh;
+
+    const int qrow = (qb * NW + wave) * 32 + l31;
+    const bool qvalid = qrow < p.N;
+
+    V8 qf[KS];
+    load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qvalid, hi, p.D);
+
+    const float *bias_row = nullptr;
+    float coeff = 1.f;
+    if (HAS_BIAS) {
+        bias_row = p.bias + b * p.b_sb + h * p.b_sh + (long)qrow * p.b_sn;
+        if (p.bias_coeff) coeff = p.bias_coeff[b];
+    }
+    const float c1 = p.scale_log2e;
+
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int i = tid * 16; i < 3 * SUB_BYTES; i += NT * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    if (ROWSUM_MFMA) {
+        const T one = (T)1.0f;
+        for (int i = tid; i < 3 * KVBLK; i += NT)
+            *reinterpret_cast<T *>(smem + (i >> 6) * SUB_BYTES + KT::BYTES + p.D * VT::STRIDE + (i & 63) * 2) = one;
+    }
+
+    StagePlan<KPT, VPT> plan;
+    make_plan<T, KS, DT, NT, 1, KPT, VPT>(plan, tid, p.D);
+    u32x4 kreg[KPT];
+    u32x4 vreg[VPT][4];
+    const int ntiles = (p.M + KVBLK - 1) / KVBLK;
+    const bool ragged = (p.M % KVBLK) != 0;
+
+    // prologue: tiles 0 and 1 into the ring, tile 2 into registers, S(0) computed
+    stage_load<T, KPT, VPT>(kreg, vreg, plan, Kp, Vp, p.k_sm, p.v_sm, 0, p.M);
+    stage_store<DT, KPT, VPT, true>(kreg, vreg, plan, smem, 0, p.M);
+    if (ntiles > 1) {
+        stage_load<T, KPT, VPT>(kreg, vreg, plan, Kp, Vp, p.k_sm, p.v_sm, KVBLK, p.M);
+        stage_store<DT, KPT, VPT, true>(kreg, vreg, plan, smem + SUB_BYTES, KVBLK, p.M);
+    }
+    if (ntiles > 2) stage_load<T, KPT, VPT>(kreg, vreg, plan, Kp, Vp, p.k_sm, p.v_sm, 2 * KVBLK, p.M);
+    __syncthreads();
+    f32x16 s_cur[2];
+    score_tile<T, KS>(s_cur, qf, smem, 0, p.M, l31, hi);
+
+    int slot = 0;   // ring slot of tile t
+    for (int t = 0; t + 1 < ntiles; ++t) {
+        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+        if (t + 2 < ntiles) stage_store<DT, KPT, VPT, true>(kreg, vreg, plan, smem + slot2 * SUB_BYTES, (t + 2) * KVBLK, p.M);
+        if (t + 3 < ntiles) stage_load<T, KPT, VPT>(kreg, vreg, plan, Kp, Vp, p.k_sm, p.v_sm, (t + 3) * KVBLK, p.M);
+        f32x16 s_next[2];
+        score_tile<T, KS>(s_next, qf, smem + slot1 * SUB_BYTES, (t + 1) * KVBLK, p.M, l31, hi);   // independent of the softmax below
+        attn_tile_sm_pv<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA>(s_cur, oacc, m_run, l_run, smem + slot * SUB_BYTES + KT::BYTES,
+                                                                t * KVBLK, p.M, l31, hi, bias_row, p.b_sm, coeff, c1, qvalid);
+        s_cur[0] = s_next[0];
+        s_cur[1] = s_next[1];
+        slot = slot1;
+        __syncthreads();
+    }
+    {   // last tile (the only one that can be ragged)
+        const int key0 = (ntiles - 1) * KVBLK;
+        const char *Vs = smem + slot * SUB_BYTES + KT::BYTES;
+        if (ragged)
+            attn_tile_sm_pv<T, KS, DT, HAS_BIAS, true, ROWSUM_MFMA>(s_cur, oacc, m_run, l_run, Vs, key0, p.M, l31, hi, bias_row,
+                                                                   p.b_sm, coeff, c1, qvalid);
+        else
+            attn_tile_sm_pv<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA>(s_cur, oacc, m_run, l_run, Vs, key0, p.M, l31, hi, bias_row,
+                                                                    p.b_sm, coeff, c1, qvalid);
+    }
+
+    float l_tot;
+    if (ROWSUM_MFMA) {
+        const int rl = p.D & 31, tl = p.D >> 5;
+        float lv = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const float c = rl == 8 ? oacc[dt][4] : rl == 16 ? oacc[dt][8] : oacc[dt][12];
+            lv = dt == tl ? c : lv;
+        }
+        const float other = __shfl_xor(lv, 32);
+        l_tot = hi ? other : lv;
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32);
+    }
+    const float inv = 1.f / l_tot;
+    if (qvalid) {
+        T *orow = Op + (long)qrow * p.o_sn;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + g * 8 + hi * 4;
+                if (d < p.D) {
+                    V4 out;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) out[j] = (T)(oacc[dt][g * 4 + j] * inv);
+                    *reinterpret_cast<V4 *>(orow + d) = out;
+                }
+            }
+        }
+    }
+}
+
 // ---- host dispatch ---------------------------------------------------------------------------
 
 template <typename T, int KS, int DT, int NW, bool HAS_BIAS, bool ROWSUM_MFMA>
 static int launch_attn_rs(const AttnParams &p, hipStream_t stream) {
     // two 64-key sub-tiles per stage (one barrier per 128 keys) while the double buffer stays small enough
     // for two workgroups per CU; the widest heads use single sub-tile stages
-    constexpr int NSUB = (2 * 2 * (KTile<KS>::BYTES + VTile<DT>::BYTES) <= 72 * 1024) ? 2 : 1;
+    // (an 8-wave workgroup owns its CU alone, so it can spend the LDS on 256-key stages: PWW_ATTN_NSUB4)
+    constexpr int SUBB = KTile<KS>::BYTES + VTile<DT>::BYTES;
+    constexpr int NSUB = (2 * 2 * SUBB <= 72 * 1024) ? 2 : 1;   // (256-key stages for NW == 8 measured no faster)
     constexpr size_t lds = 2 * NSUB * (KTile<KS>::BYTES + VTile<DT>::BYTES);
     const int qblocks = (p.N + NW * 32 - 1) / (NW * 32);
     const dim3 grid((unsigned)(qblocks * p.B * p.H));
@@ -391,8 +550,38 @@ static int launch_attn_rs(const AttnParams &p, hipStream_t stream) {
     return check_hip(hipGetLastError(), "attn_fwd_kernel launch");
 }
 
+static int pipe_mode() {   // PWW_ATTN_PIPE=0/1 overrides the default schedule choice (A/B testing)
+    static int mode = -2;
+    if (mode == -2) { const char *e = getenv("PWW_ATTN_PIPE"); mode = e ? atoi(e) : -1; }
+    return mode;
+}
+
+template <typename T, int KS, int DT, int NW, bool ROWSUM_MFMA>
+static int launch_attn_pipe(const AttnParams &p, hipStream_t stream) {
+    constexpr size_t lds = 3 * (KTile<KS>::BYTES + VTile<DT>::BYTES);
+    const int qblocks = (p.N + NW * 32 - 1) / (NW * 32);
+    auto kern = attn_fwd_pipe_kernel<T, KS, DT, NW, false, ROWSUM_MFMA>;
+    if (lds > 64 * 1024) {
+        static thread_local bool done = false;
+        if (!done) {
+            if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                          "hipFuncSetAttribute"))
+                return PWW_EHIP;
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(qblocks * p.B * p.H)), dim3(NW * 64), lds, stream, p);
+    return check_hip(hipGetLastError(), "attn_fwd_pipe_kernel launch");
+}
+
 template <typename T, int KS, int DT, int NW, bool HAS_BIAS>
 static int launch_attn(const AttnParams &p, hipStream_t stream) {
+    if constexpr (!HAS_BIAS && DT <= 3 && NW == 4) {
+        if (pipe_mode() == 1) {
+            if ((p.D & 31) != 0) return launch_attn_pipe<T, KS, DT, NW, true>(p, stream);
+            return launch_attn_pipe<T, KS, DT, NW, false>(p, stream);
+        }
+    }
     // head dims with padding rows in the V^T tile get the row sum from the MFMA (self-attention path)
     if (!HAS_BIAS && (p.D & 31) != 0) return launch_attn_rs<T, KS, DT, NW, HAS_BIAS, true>(p, stream);
     return launch_attn_rs<T, KS, DT, NW, HAS_BIAS, false>(p, stream);
@@ -402,10 +591,12 @@ template <typename T, int NW, bool HAS_BIAS> static int dispatch_d(const AttnPar
     const int D = p.D;
     if (D <= 48) return launch_attn<T, 3, 2, NW, HAS_BIAS>(p, s);
     if (D <= 64) return launch_attn<T, 4, 2, NW, HAS_BIAS>(p, s);
+    if constexpr (NW == 8) { set_error("attn_fwd: internal dispatch error"); return PWW_EINVAL; } else {
     if (D <= 80) return launch_attn<T, 5, 3, NW, HAS_BIAS>(p, s);
     if (D <= 96) return launch_attn<T, 6, 3, NW, HAS_BIAS>(p, s);
     if (D <= 128) return launch_attn<T, 8, 4, NW, HAS_BIAS>(p, s);
     return launch_attn<T, 10, 5, NW, HAS_BIAS>(p, s);
+    }
 }
 
 template <typename T> static int dispatch_nw(const AttnParams &p, hipStream_t s) {
@@ -413,6 +604,10 @@ template <typename T> static int dispatch_nw(const AttnParams &p, hipStream_t s)
     const long rows32 = (long)((p.N + 31) / 32) * p.B * p.H;  // 32-row wave tasks
     const bool wide = rows32 >= 4 * 256 && p.N >= 128;
     if (p.bias) return wide ? dispatch_d<T, 4, true>(p, s) : dispatch_d<T, 2, true>(p, s);
+    // 8-wave workgroups (256 query rows per K/V stage) once they still give every CU a workgroup
+    static int nw8 = -1;
+    if (nw8 < 0) { const char *e = getenv("PWW_ATTN_NW8"); nw8 = e ? atoi(e) : 1; }
+    if (nw8 && rows32 >= 8 * 256 && p.N >= 256 && p.D <= 64) return dispatch_d<T, 8, false>(p, s);
     return wide ? dispatch_d<T, 4, false>(p, s) : dispatch_d<T, 2, false>(p, s);
 }
 
