@@ -156,9 +156,14 @@ def gen_loops(ref, full):
     au = np.array(Image.open(os.path.join(ref_loader.REFERENCE_ROOT, "contents", "aurora_1.png")).convert("RGB"))
     todo = [("tiny_example_lms10", "tiny", 10, ex, cases.RUNNER_CONTEXT, cases.RUNNER_PROMPT, "runner", 0),
             ("tiny_aurora_seed_std6", "tiny", 6, au, cases.AURORA_SEED_CONTEXT, cases.AURORA_PROMPT, "std", 3)]
+    grid, gctx, gprompt = cases.grid_case(seeds=True)     # BASELINE config 5 inputs on the reduced SD2-style UNet
+    todo.append(("tiny_sd2_grid768_std5", "tiny_sd2", 5, grid, gctx, gprompt, "std", 11))
     if full:
         todo.append(("sd15_example_lms10", "sd15", 10, ex, cases.RUNNER_CONTEXT, cases.RUNNER_PROMPT, "runner", 0))
+    only = os.environ.get("PWW_GOLDEN_ONLY")
     for name, config, steps, img, ctx, prompt, wname, seed in todo:
+        if only and only not in name:
+            continue
         lat, dt = _run_loop(ref, config, steps, img, ctx, prompt, cases.WEIGHT_FUNCTIONS[wname], seed)
         np.savez_compressed(os.path.join(GOLDEN, f"loop_{name}.npz"), latents=lat, seconds=np.float64(dt),
                             steps=steps, threads=torch.get_num_threads())

@@ -230,6 +230,12 @@ class UpBlock(nn.Module):
         return x, skips
 
 
+# SD2.x-flavoured reduced config: head dim 64 everywhere (heads 1/2/4/4), linear projections, 768x768 -> sample 96
+TINY_SD2_CONFIG = dict(sample_size=96, in_channels=4, out_channels=4, block_out_channels=(64, 128, 256, 256),
+                       layers_per_block=1, attention_head_dim=(1, 2, 4, 4), cross_attention_dim=96,
+                       norm_num_groups=16, use_linear_projection=True)
+
+
 def timestep_embedding(timesteps, dim):
     """Sinusoidal embedding, flip_sin_to_cos=True, freq_shift=0 (the SD configuration)."""
     half = dim // 2

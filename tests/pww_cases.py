@@ -182,9 +182,9 @@ def subsample_rows(n):
 
 def build_tools(config_name="tiny", dtype=torch.float32, device="cpu", scheduler="lms", qk_gain=2.0):
     """(vae, unet, text_encoder, tokenizer, scheduler) stand-ins with the BASELINE seeds."""
-    from sd_standin import (build_unet, SD15_CONFIG, SD15_INPAINT_CONFIG, SD21_CONFIG, TINY_CONFIG, HashTokenizer,
-                            TinyTextEncoder, TinyVAE, LMSDiscreteScheduler, PLMSScheduler)
-    cfg = {"tiny": TINY_CONFIG, "sd15": SD15_CONFIG, "sd15_inpaint": SD15_INPAINT_CONFIG, "sd21": SD21_CONFIG,
+    from sd_standin import (build_unet, SD15_CONFIG, SD15_INPAINT_CONFIG, SD21_CONFIG, TINY_CONFIG, TINY_SD2_CONFIG,
+                            HashTokenizer, TinyTextEncoder, TinyVAE, LMSDiscreteScheduler, PLMSScheduler)
+    cfg = {"tiny": TINY_CONFIG, "tiny_sd2": TINY_SD2_CONFIG, "sd15": SD15_CONFIG, "sd15_inpaint": SD15_INPAINT_CONFIG, "sd21": SD21_CONFIG,
            "tiny_inpaint": dict(TINY_CONFIG, in_channels=9)}[config_name]
     unet = build_unet(cfg, seed=1234, dtype=dtype, device=device, qk_gain=qk_gain)
     text = TinyTextEncoder(cfg["cross_attention_dim"], seed=1235).to(device=device, dtype=dtype)
