@@ -51,17 +51,26 @@ __device__ __forceinline__ uint32_t half_of(const u32x4 v, int j) {   // j is a 
 
 // Loop-invariant part of a thread's share of the K/V staging: which 16-byte chunks it moves and where
 // they land in an LDS stage buffer. A stage = NSUB sub-tiles of 64 keys, each sub-tile = [K tile | Vt tile].
-// Per stage only the key offset changes, so the hot loop carries no divisions; out-of-range rows are
-// CLAMPED to the last valid key (always-legal address) and zeroed at store time.
+//
+// Global reads are BUFFER loads: a per-(b,h) resource descriptor (base = first key row of this head,
+// num_records = last valid byte + 1), a loop-invariant per-thread 32-bit byte offset, plus the stage's byte
+// offset. That keeps the hot loop free of 64-bit address arithmetic (v_mul_lo / v_mad_u64 are multi-cycle
+// VOP3 ops: ~70 of them per stage before), and rows past the last key are OUT OF RANGE for the descriptor,
+// so the hardware returns zeros for them -- no clamping, no selects, no special tail path. Idle threads and
+// head-dim padding chunks carry an offset >= 2^31 (never in range; the host checks the extent is < 2^31).
+constexpr unsigned OOB_OFF = 0x80000000u;
+
 template <int KPT, int VPT> struct StagePlan {
-    int k_row[KPT], k_d0[KPT], k_lds[KPT];
-    bool k_ok[KPT], k_wr[KPT];
-    int v_key[VPT], v_d0[VPT], v_lds[VPT];
+    unsigned k_off[KPT];
+    int k_lds[KPT];
+    bool k_ok[KPT];
+    unsigned v_off[VPT][4];
+    int v_lds[VPT];
     bool v_ok[VPT];
 };
 
 template <typename T, int KS, int DT, int NT, int NSUB, int KPT, int VPT>
-__device__ __forceinline__ void make_plan(StagePlan<KPT, VPT> &pl, int tid, int D) {
+__device__ __forceinline__ void make_plan(StagePlan<KPT, VPT> &pl, int tid, int D, long k_sm, long v_sm) {
     typedef KTile<KS> KT;
     typedef VTile<DT> VT;
     constexpr int SUB_BYTES = KT::BYTES + VT::BYTES;
@@ -69,78 +78,65 @@ __device__ __forceinline__ void make_plan(StagePlan<KPT, VPT> &pl, int tid, int 
     for (int i = 0; i < KPT; ++i) {
         const int c = tid + i * NT;
         const int key = c / KT::CHK, ch = c - key * KT::CHK;       // key in [0, 64*NSUB)
-        pl.k_row[i] = key;
-        pl.k_d0[i] = ch * 8 < D ? ch * 8 : 0;
+        pl.k_ok[i] = c < NSUB * KT::NCHUNK && ch * 8 < D;            // padding chunks stay at their initial zeros
+        pl.k_off[i] = pl.k_ok[i] ? (unsigned)((key * k_sm + ch * 8) * 2) : OOB_OFF;
         pl.k_lds[i] = (key >> 6) * SUB_BYTES + (key & 63) * KT::STRIDE + ch * 16;
-        pl.k_wr[i] = c < NSUB * KT::NCHUNK;                          // pad chunks are WRITTEN (as zeros)
-        pl.k_ok[i] = pl.k_wr[i] && ch * 8 < D;                       // ... but never loaded
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         const int u = tid + i * NT;
         const int kg = u % (16 * NSUB), dc = u / (16 * NSUB);        // key group (4 keys) over the whole stage
-        pl.v_key[i] = kg * 4;
-        pl.v_d0[i] = dc * 8 < D ? dc * 8 : 0;
+        pl.v_ok[i] = u < NSUB * VT::NUNIT && dc * 8 < D;             // padding rows are initialised once, never staged
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            pl.v_off[i][kk] = pl.v_ok[i] ? (unsigned)(((kg * 4 + kk) * v_sm + dc * 8) * 2) : OOB_OFF;
         pl.v_lds[i] = (kg >> 4) * SUB_BYTES + KT::BYTES + (dc * 8) * VT::STRIDE + (kg & 15) * 8;
-        pl.v_ok[i] = u < NSUB * VT::NUNIT && dc * 8 < D;             // pad rows are initialised once, never staged
     }
 }
 
-// Issue the global loads of the stage starting at key0. Nothing here CONSUMES the loaded registers, so
-// the loads stay in flight across the compute of the current stage.
-// NOTE: the loads are UNCONDITIONAL on purpose. A load inside an `if` makes hipcc place the phi copy of the
-// loop-carried staging register in the predicated block, i.e. an `s_waitcnt vmcnt(0)` right behind every
-// load (measured: 74% of wave cycles parked). Idle lanes / padding chunks read one fixed, always-valid
-// address instead (same cache line for the whole wave) and their value is dropped at store time.
-template <typename T, int KPT, int VPT>
+// Issue the global loads of the stage whose first key row sits `k_stage_off` / `v_stage_off` bytes into the
+// head's K / V. Nothing here consumes the loaded registers: the loads stay in flight across the compute of
+// the current stage. (Unconditional on purpose: a load inside an `if` gets an s_waitcnt vmcnt(0) behind it.)
+template <typename SRD, int KPT, int VPT>
 __device__ __forceinline__ void stage_load(u32x4 (&kreg)[KPT], u32x4 (&vreg)[VPT][4], const StagePlan<KPT, VPT> &pl,
-                                           const T *Kp, const T *Vp, long k_sm, long v_sm, int key0, int M) {
+                                           SRD srd_k, SRD srd_v, unsigned k_stage_off, unsigned v_stage_off) {
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-        const int gk = min(key0 + pl.k_row[i], M - 1);
-        const T *src = pl.k_ok[i] ? Kp + (long)gk * k_sm + pl.k_d0[i] : Kp;
-        kreg[i] = *reinterpret_cast<const u32x4 *>(src);
-    }
+    for (int i = 0; i < KPT; ++i) kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_k, pl.k_off[i] + k_stage_off, 0, 0);
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) {
+    for (int i = 0; i < VPT; ++i)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int gk = min(key0 + pl.v_key[i] + kk, M - 1);
-            const T *src = pl.v_ok[i] ? Vp + (long)gk * v_sm + pl.v_d0[i] : Vp;
-            vreg[i][kk] = *reinterpret_cast<const u32x4 *>(src);
-        }
-    }
+        for (int kk = 0; kk < 4; ++kk)
+            vreg[i][kk] = __builtin_amdgcn_raw_buffer_load_b128(srd_v, pl.v_off[i][kk] + v_stage_off, 0, 0);
 }
 
-// Registers -> LDS stage buffer. CHECK = the stage may contain keys >= M (tail): those rows become zeros.
-template <int DT, int KPT, int VPT, bool CHECK>
+// Registers -> LDS stage buffer (rows past the last key arrive as zeros from the buffer load).
+template <int DT, int KPT, int VPT>
 __device__ __forceinline__ void stage_store(const u32x4 (&kreg)[KPT], const u32x4 (&vreg)[VPT][4],
-                                            const StagePlan<KPT, VPT> &pl, char *buf, int key0, int M) {
+                                            const StagePlan<KPT, VPT> &pl, char *buf) {
     typedef VTile<DT> VT;
-    const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-        if (pl.k_wr[i]) {
-            const bool ok = pl.k_ok[i] && (!CHECK || key0 + pl.k_row[i] < M);
-            *reinterpret_cast<u32x4 *>(buf + pl.k_lds[i]) = ok ? kreg[i] : z;
-        }
-    }
+    for (int i = 0; i < KPT; ++i)
+        if (pl.k_ok[i]) *reinterpret_cast<u32x4 *>(buf + pl.k_lds[i]) = kreg[i];
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         if (pl.v_ok[i]) {   // 4 keys x 8 d -> eight 8-byte writes of (4 keys) at consecutive d rows
-            u32x4 r[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) r[kk] = (!CHECK || key0 + pl.v_key[i] + kk < M) ? vreg[i][kk] : z;
             char *dst = buf + pl.v_lds[i];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 u32x2 w;
-                w[0] = half_of(r[0], j) | (half_of(r[1], j) << 16);
-                w[1] = half_of(r[2], j) | (half_of(r[3], j) << 16);
+                w[0] = half_of(vreg[i][0], j) | (half_of(vreg[i][1], j) << 16);
+                w[1] = half_of(vreg[i][2], j) | (half_of(vreg[i][3], j) << 16);
                 *reinterpret_cast<u32x2 *>(dst + j * VT::STRIDE) = w;
             }
         }
     }
+}
+
+// Resource descriptor over one head's K or V rows: [base, base + (M-1)*row_stride + D) elements of T.
+template <typename T>
+__device__ __forceinline__ auto head_srd(const T *base, int M, long row_stride, int D) {
+    const unsigned bytes = (unsigned)(((long)(M - 1) * row_stride + D) * 2);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(base), 0, bytes, 0x00020000);
 }
 
 // max over both half-waves of a per-lane value (lanes l and l^32 hold the two halves of one query row)
@@ -248,13 +244,18 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
     }
 }
 
-template <typename T, int KS, int DT, int NW, int NSUB, bool HAS_BIAS, bool ROWSUM_MFMA>
-__global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, HAS_BIAS>::value)) attn_fwd_kernel(const AttnParams p) {
+// KG = key groups: with KG > 1 the workgroup has NW * KG waves; wave (rg, kg) owns query rows of row group rg and,
+// in every stage of KG sub-tiles, only sub-tile kg -- i.e. the KEYS of a stage are split over wave groups. This is
+// how a launch with few query rows (B = 2: two 32-row waves per SIMD) still fills 3 waves per SIMD; the KG partial
+// (m, O^T) states of a row group are merged once at the end through the (then free) LDS stage buffers.
+template <typename T, int KS, int DT, int NW, int NSUB, int KG, bool HAS_BIAS, bool ROWSUM_MFMA>
+__global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, HAS_BIAS>::value)) attn_fwd_kernel(const AttnParams p) {
     typedef typename Vec<T>::v8 V8;
     typedef typename Vec<T>::v4 V4;
     typedef KTile<KS> KT;
     typedef VTile<DT> VT;
-    constexpr int NT = NW * 64;
+    static_assert(KG == 1 || NSUB == KG, "key-split workgroups process one sub-tile per key group");
+    constexpr int NT = NW * KG * 64;
     constexpr int SUB_BYTES = KT::BYTES + VT::BYTES;     // one 64-key sub-tile: K rows, then V^T rows
     constexpr int STAGE_BYTES = NSUB * SUB_BYTES;
     constexpr int STAGE_KEYS = NSUB * KVBLK;
@@ -265,6 +266,7 @@ __global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, HAS_BIAS>::value)) 
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int rg = KG > 1 ? wave % NW : wave, kg = KG > 1 ? wave / NW : 0;
     const int hi = lane >> 5, l31 = lane & 31;
     const int BH = p.B * p.H;
     const int bh = blockIdx.x % BH, qb = blockIdx.x / BH;
@@ -275,7 +277,7 @@ __global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, HAS_BIAS>::value)) 
     const T *Vp = reinterpret_cast<const T *>(p.v) + b * p.v_sb + h * p.v_sh;
     T *Op = reinterpret_cast<T *>(p.o) + b * p.o_sb + h * p.o_sh;
 
-    const int qrow = (qb * NW + wave) * 32 + l31;
+    const int qrow = (qb * NW + rg) * 32 + l31;
     const bool qvalid = qrow < p.N;
 
     V8 qf[KS];
@@ -308,16 +310,19 @@ __global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, HAS_BIAS>::value)) 
     }
 
     StagePlan<KPT, VPT> plan;
-    make_plan<T, KS, DT, NT, NSUB, KPT, VPT>(plan, tid, p.D);
+    make_plan<T, KS, DT, NT, NSUB, KPT, VPT>(plan, tid, p.D, p.k_sm, p.v_sm);
+    const auto srd_k = head_srd(Kp, p.M, p.k_sm, p.D);
+    const auto srd_v = head_srd(Vp, p.M, p.v_sm, p.D);
+    const unsigned k_step = (unsigned)(STAGE_KEYS * p.k_sm * 2), v_step = (unsigned)(STAGE_KEYS * p.v_sm * 2);   // bytes per stage
     u32x4 kreg[KPT];
     u32x4 vreg[VPT][4];
     const int nstage = (p.M + STAGE_KEYS - 1) / STAGE_KEYS;
     const int nfull = p.M / STAGE_KEYS;                 // stages without any key >= M
 
     // prologue: stage 0 -> buffer 0, stage 1 -> registers
-    stage_load<T, KPT, VPT>(kreg, vreg, plan, Kp, Vp, p.k_sm, p.v_sm, 0, p.M);
-    stage_store<DT, KPT, VPT, true>(kreg, vreg, plan, smem, 0, p.M);
-    if (nstage > 1) stage_load<T, KPT, VPT>(kreg, vreg, plan, Kp, Vp, p.k_sm, p.v_sm, STAGE_KEYS, p.M);
+    stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);
+    stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
+    if (nstage > 1) stage_load(kreg, vreg, plan, srd_k, srd_v, k_step, v_step);
     __syncthreads();
 
     int st = 0;
@@ -326,24 +331,72 @@ __global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, HAS_BIAS>::value)) 
         char *nxt = smem + ((st & 1) ^ 1) * STAGE_BYTES;
         // registers hold stage st+1: park it in the other buffer (its readers finished before the last
         // barrier), then re-use the registers for stage st+2, whose loads fly during this stage's compute
-        if (st + 1 < nstage) stage_store<DT, KPT, VPT, true>(kreg, vreg, plan, nxt, (st + 1) * STAGE_KEYS, p.M);
-        if (st + 2 < nstage) stage_load<T, KPT, VPT>(kreg, vreg, plan, Kp, Vp, p.k_sm, p.v_sm, (st + 2) * STAGE_KEYS, p.M);
-#pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub)
-            attn_tile<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES,
-                                                               cur + sub * SUB_BYTES + KT::BYTES, st * STAGE_KEYS + sub * KVBLK,
+        if (st + 1 < nstage) stage_store<DT, KPT, VPT>(kreg, vreg, plan, nxt);
+        if (st + 2 < nstage) stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
+        if constexpr (KG > 1) {
+            attn_tile<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + kg * SUB_BYTES,
+                                                               cur + kg * SUB_BYTES + KT::BYTES, st * STAGE_KEYS + kg * KVBLK,
                                                                p.M, l31, hi, bias_row, p.b_sm, coeff, c1, qvalid);
+        } else {
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub)
+                attn_tile<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES,
+                                                                   cur + sub * SUB_BYTES + KT::BYTES, st * STAGE_KEYS + sub * KVBLK,
+                                                                   p.M, l31, hi, bias_row, p.b_sm, coeff, c1, qvalid);
+        }
         __syncthreads();
     }
     if (st < nstage) {           // ragged tail stage (already in LDS: stored by the prologue or the last iteration)
         char *cur = smem + (st & 1) * STAGE_BYTES;
-#pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub) {
-            const int key0 = st * STAGE_KEYS + sub * KVBLK;
+        if constexpr (KG > 1) {
+            const int key0 = st * STAGE_KEYS + kg * KVBLK;
             if (key0 < p.M)
-                attn_tile<T, KS, DT, HAS_BIAS, true, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES,
-                                                                  cur + sub * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, bias_row,
+                attn_tile<T, KS, DT, HAS_BIAS, true, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + kg * SUB_BYTES,
+                                                                  cur + kg * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, bias_row,
                                                                   p.b_sm, coeff, c1, qvalid);
+        } else {
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) {
+                const int key0 = st * STAGE_KEYS + sub * KVBLK;
+                if (key0 < p.M)
+                    attn_tile<T, KS, DT, HAS_BIAS, true, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES,
+                                                                      cur + sub * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, bias_row,
+                                                                      p.b_sm, coeff, c1, qvalid);
+            }
+        }
+    }
+
+    if constexpr (KG > 1) {
+        // merge the KG partial softmax states of each row group: key groups 1.. publish (m, l, O^T) in LDS,
+        // key group 0 folds them:  m = max m_i,  O = sum_i O_i * 2^((m_i - m) c1)  (the row-sum row included)
+        constexpr int REC = (DT * 16 + 2) * 64;           // floats per published wave state
+        float *xch = reinterpret_cast<float *>(smem);
+        __syncthreads();                                   // every wave is done with the stage buffers
+        if (kg > 0) {
+            float *rec = xch + ((kg - 1) * NW + rg) * REC;
+            rec[lane] = m_run;
+            rec[64 + lane] = l_run;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rec[(2 + dt * 16 + r) * 64 + lane] = oacc[dt][r];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int g = 1; g < KG; ++g) {
+            const float *rec = xch + ((g - 1) * NW + rg) * REC;
+            const float m_o = rec[lane];
+            const float m_n = fmaxf(m_run, m_o);
+            // a key group that saw no key (m = -inf, only possible for groups > 0 in a short sequence) contributes nothing
+            const float a_s = m_run == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m_run - m_n) * c1);
+            const float a_o = m_o == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m_o - m_n) * c1);
+            l_run = l_run * a_s + rec[64 + lane] * a_o;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] = oacc[dt][r] * a_s + rec[(2 + dt * 16 + r) * 64 + lane] * a_o;
+            m_run = m_n;
         }
     }
 
@@ -447,20 +500,23 @@ __global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, HAS_BIAS>::value)) 
     }
 
     StagePlan<KPT, VPT> plan;
-    make_plan<T, KS, DT, NT, 1, KPT, VPT>(plan, tid, p.D);
+    make_plan<T, KS, DT, NT, 1, KPT, VPT>(plan, tid, p.D, p.k_sm, p.v_sm);
+    const auto srd_k = head_srd(Kp, p.M, p.k_sm, p.D);
+    const auto srd_v = head_srd(Vp, p.M, p.v_sm, p.D);
+    const unsigned k_step = (unsigned)(KVBLK * p.k_sm * 2), v_step = (unsigned)(KVBLK * p.v_sm * 2);
     u32x4 kreg[KPT];
     u32x4 vreg[VPT][4];
     const int ntiles = (p.M + KVBLK - 1) / KVBLK;
     const bool ragged = (p.M % KVBLK) != 0;
 
     // prologue: tiles 0 and 1 into the ring, tile 2 into registers, S(0) computed
-    stage_load<T, KPT, VPT>(kreg, vreg, plan, Kp, Vp, p.k_sm, p.v_sm, 0, p.M);
-    stage_store<DT, KPT, VPT, true>(kreg, vreg, plan, smem, 0, p.M);
+    stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);
+    stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
     if (ntiles > 1) {
-        stage_load<T, KPT, VPT>(kreg, vreg, plan, Kp, Vp, p.k_sm, p.v_sm, KVBLK, p.M);
-        stage_store<DT, KPT, VPT, true>(kreg, vreg, plan, smem + SUB_BYTES, KVBLK, p.M);
+        stage_load(kreg, vreg, plan, srd_k, srd_v, k_step, v_step);
+        stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem + SUB_BYTES);
     }
-    if (ntiles > 2) stage_load<T, KPT, VPT>(kreg, vreg, plan, Kp, Vp, p.k_sm, p.v_sm, 2 * KVBLK, p.M);
+    if (ntiles > 2) stage_load(kreg, vreg, plan, srd_k, srd_v, 2 * k_step, 2 * v_step);
     __syncthreads();
     f32x16 s_cur[2];
     score_tile<T, KS>(s_cur, qf, smem, 0, p.M, l31, hi);
@@ -468,8 +524,8 @@ __global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, HAS_BIAS>::value)) 
     int slot = 0;   // ring slot of tile t
     for (int t = 0; t + 1 < ntiles; ++t) {
         const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
-        if (t + 2 < ntiles) stage_store<DT, KPT, VPT, true>(kreg, vreg, plan, smem + slot2 * SUB_BYTES, (t + 2) * KVBLK, p.M);
-        if (t + 3 < ntiles) stage_load<T, KPT, VPT>(kreg, vreg, plan, Kp, Vp, p.k_sm, p.v_sm, (t + 3) * KVBLK, p.M);
+        if (t + 2 < ntiles) stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem + slot2 * SUB_BYTES);
+        if (t + 3 < ntiles) stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(t + 3) * k_step, (unsigned)(t + 3) * v_step);
         f32x16 s_next[2];
         score_tile<T, KS>(s_next, qf, smem + slot1 * SUB_BYTES, (t + 1) * KVBLK, p.M, l31, hi);   // independent of the softmax below
         attn_tile_sm_pv<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA>(s_cur, oacc, m_run, l_run, smem + slot * SUB_BYTES + KT::BYTES,
@@ -535,7 +591,7 @@ static int launch_attn_rs(const AttnParams &p, hipStream_t stream) {
     constexpr size_t lds = 2 * NSUB * (KTile<KS>::BYTES + VTile<DT>::BYTES);
     const int qblocks = (p.N + NW * 32 - 1) / (NW * 32);
     const dim3 grid((unsigned)(qblocks * p.B * p.H));
-    auto kern = attn_fwd_kernel<T, KS, DT, NW, NSUB, HAS_BIAS, ROWSUM_MFMA>;
+    auto kern = attn_fwd_kernel<T, KS, DT, NW, NSUB, 1, HAS_BIAS, ROWSUM_MFMA>;
     if (lds > 64 * 1024) {
         static thread_local bool done = false;
         if (!done) {
@@ -548,6 +604,32 @@ static int launch_attn_rs(const AttnParams &p, hipStream_t stream) {
     }
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, p);
     return check_hip(hipGetLastError(), "attn_fwd_kernel launch");
+}
+
+// key-split workgroups: 4 row groups x 3 key groups = 12 waves, 192-key stages (self-attention, narrow heads)
+template <typename T, int KS, int DT, bool ROWSUM_MFMA>
+static int launch_attn_ksplit(const AttnParams &p, hipStream_t stream) {
+    constexpr int NW = 4, KG = 3;
+    constexpr size_t stage = KG * (KTile<KS>::BYTES + VTile<DT>::BYTES);
+    constexpr size_t merge = (size_t)(KG - 1) * NW * (DT * 16 + 2) * 64 * sizeof(float);
+    constexpr size_t lds = 2 * stage > merge ? 2 * stage : merge;
+    const int qblocks = (p.N + NW * 32 - 1) / (NW * 32);
+    auto kern = attn_fwd_kernel<T, KS, DT, NW, KG, KG, false, ROWSUM_MFMA>;
+    static thread_local bool done = false;
+    if (!done) {
+        if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                      "hipFuncSetAttribute"))
+            return PWW_EHIP;
+        done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(qblocks * p.B * p.H)), dim3(NW * KG * 64), lds, stream, p);
+    return check_hip(hipGetLastError(), "attn_fwd_kernel<key-split> launch");
+}
+
+static int ksplit_mode() {   // PWW_ATTN_KSPLIT=0/1 (A/B testing); default on
+    static int mode = -2;
+    if (mode == -2) { const char *e = getenv("PWW_ATTN_KSPLIT"); mode = e ? atoi(e) : 1; }
+    return mode;
 }
 
 static int pipe_mode() {   // PWW_ATTN_PIPE=0/1 overrides the default schedule choice (A/B testing)
@@ -576,6 +658,16 @@ static int launch_attn_pipe(const AttnParams &p, hipStream_t stream) {
 
 template <typename T, int KS, int DT, int NW, bool HAS_BIAS>
 static int launch_attn(const AttnParams &p, hipStream_t stream) {
+    if constexpr (!HAS_BIAS && DT <= 2 && NW == 4) {
+        // at most one 4-wave workgroup per CU (1 wave/SIMD) and a long key sequence: split the keys over 3 wave
+        // groups -> 3 waves/SIMD. (Measured N=4096 d=40: B=1 55.8 -> 51.6 us; with two workgroups per CU, B=2,
+        // the split LOSES, 101 -> 114 us, so it is limited to the under-filled case.)
+        const long wgs = (long)((p.N + 127) / 128) * p.B * p.H;
+        if (ksplit_mode() == 1 && wgs <= 256 && p.M >= 1024) {
+            if ((p.D & 31) != 0) return launch_attn_ksplit<T, KS, DT, true>(p, stream);
+            return launch_attn_ksplit<T, KS, DT, false>(p, stream);
+        }
+    }
     if constexpr (!HAS_BIAS && DT <= 3 && NW == 4) {
         if (pipe_mode() == 1) {
             if ((p.D & 31) != 0) return launch_attn_pipe<T, KS, DT, NW, true>(p, stream);
@@ -639,6 +731,11 @@ int attn_fwd(const void *q, const void *k, const void *v, void *o, const float *
         }
     }
     if ((long)d->B * d->H * ((d->N + 31) / 32) > 0x7fffffffL) { set_error("attn_fwd: grid too large"); return PWW_EINVAL; }
+    if (((long)d->M * d->k_stride[2] + d->D) * 2 >= (1L << 31) || ((long)d->M * d->v_stride[2] + d->D) * 2 >= (1L << 31) ||
+        d->k_stride[2] < d->D || d->v_stride[2] < d->D) {
+        set_error("attn_fwd: one head's K/V extent must be < 2 GiB and rows must not overlap (row stride >= D)");
+        return PWW_EINVAL;
+    }
     if (!(d->scale > 0.f)) { set_error("attn_fwd: scale must be positive (got %g)", (double)d->scale); return PWW_EINVAL; }
     if (!arch_ok()) return PWW_ENOTSUP;
 
