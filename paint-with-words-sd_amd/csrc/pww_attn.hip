@@ -152,34 +152,43 @@ __device__ __forceinline__ float xhalf_max(float x) {
 // Waves per SIMD the register allocator must leave room for (2 => <= 256 VGPRs+AGPRs). The bias
 // variants (32 extra loads in flight per tile) and the widest heads keep the whole 512-entry file.
 template <int DT, int NW, bool HAS_BIAS> struct MinWaves {
-    static constexpr int value = (HAS_BIAS || DT >= 4 || (NW == 2 && DT >= 3)) ? 1 : (NW == 8 ? 1 : 2);
+    static constexpr int value = (DT >= 4 || (NW == 2 && DT >= 3) || (HAS_BIAS && DT >= 3)) ? 1 : (NW == 8 ? 1 : 2);
 };
 
 // One KV tile: scores -> (bias) -> online softmax -> PV. MASKED tiles (only the last one can be)
 // additionally kill keys >= M; full tiles skip every key compare.
 // ROWSUM_MFMA: the head dim is not a multiple of 32, so the V^T tile has padding rows; row D holds
 // ones and the PV MFMA accumulates the softmax denominator there for free (no per-element adds).
+// Bias addressing for one lane: a buffer descriptor over this (b, h) slice of the bias, the byte offset of the
+// lane's query row (>= 2^31, i.e. out of range -> zeros, for rows past N) and the key stride in bytes. With a unit
+// key stride (the PwW [N, 77] maps) every bias load is `row offset + immediate`: one VGPR for all 32 loads of a tile.
+struct BiasRef {
+    __amdgpu_buffer_rsrc_t srd;
+    unsigned row_off;
+    unsigned key_stride;   // bytes
+    bool unit;             // key_stride == 4
+};
+
 template <typename T, int KS, int DT, bool HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
 __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[DT], float &m_run, float &l_run, const char *Vs,
-                                                int key0, int M, int l31, int hi, const float *bias_row, long b_sm,
-                                                float coeff, float c1, bool qvalid);
+                                                int key0, int M, int l31, int hi, const BiasRef &bias,
+                                                float coeff, float c1);
 
 template <typename T, int KS, int DT, bool HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
 __device__ __forceinline__ void attn_tile(f32x16 (&oacc)[DT], float &m_run, float &l_run,
                                           const typename Vec<T>::v8 (&qf)[KS], const char *Ks, const char *Vs,
-                                          int key0, int M, int l31, int hi, const float *bias_row, long b_sm,
-                                          float coeff, float c1, bool qvalid) {
+                                          int key0, int M, int l31, int hi, const BiasRef &bias,
+                                          float coeff, float c1) {
     f32x16 s[2];
     score_tile<T, KS>(s, qf, Ks, key0, MASKED ? M : 0x7fffffff, l31, hi);
-    attn_tile_sm_pv<T, KS, DT, HAS_BIAS, MASKED, ROWSUM_MFMA>(s, oacc, m_run, l_run, Vs, key0, M, l31, hi, bias_row, b_sm,
-                                                             coeff, c1, qvalid);
+    attn_tile_sm_pv<T, KS, DT, HAS_BIAS, MASKED, ROWSUM_MFMA>(s, oacc, m_run, l_run, Vs, key0, M, l31, hi, bias, coeff, c1);
 }
 
 // scores (already in `s`) -> (bias) -> online softmax -> PV against the V^T tile at Vs
 template <typename T, int KS, int DT, bool HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
 __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[DT], float &m_run, float &l_run, const char *Vs,
-                                                int key0, int M, int l31, int hi, const float *bias_row, long b_sm,
-                                                float coeff, float c1, bool qvalid) {
+                                                int key0, int M, int l31, int hi, const BiasRef &bias,
+                                                float coeff, float c1) {
     typedef typename Vec<T>::v8 V8;
     typedef VTile<DT> VT;
 
@@ -192,9 +201,9 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
         for (int r = 0; r < 16; ++r) {
             const int key = key0 + key_of(kb, r, hi);
             float x = s[kb][r];
-            if (HAS_BIAS) {
-                float bv = 0.f;
-                if (qvalid && (!MASKED || key < M)) bv = bias_row[(long)key * b_sm];
+            if (HAS_BIAS) {   // keys >= M of a ragged tile read a neighbouring (in-range) value; they are masked below
+                const unsigned off = bias.unit ? bias.row_off + (unsigned)key * 4u : bias.row_off + (unsigned)key * bias.key_stride;
+                const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bias.srd, off, 0, 0));
                 x = fmaf(bv, coeff, x);
             }
             if (MASKED) x = key < M ? x : -INFINITY;
@@ -283,10 +292,15 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
     V8 qf[KS];
     load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qvalid, hi, p.D);
 
-    const float *bias_row = nullptr;
+    BiasRef bias;
     float coeff = 1.f;
-    if (HAS_BIAS) {
-        bias_row = p.bias + b * p.b_sb + h * p.b_sh + (long)qrow * p.b_sn;
+    if (HAS_BIAS) {   // descriptor over this (b, h) slice; the host guarantees its extent is < 2^31 bytes
+        const float *bbase = p.bias + b * p.b_sb + h * p.b_sh;
+        const unsigned bytes = (unsigned)((((long)(p.N - 1) * p.b_sn + (long)(p.M - 1) * p.b_sm) + 1) * 4);
+        bias.srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bbase), 0, bytes, 0x00020000);
+        bias.row_off = qvalid ? (unsigned)((long)qrow * p.b_sn * 4) : OOB_OFF;
+        bias.key_stride = (unsigned)(p.b_sm * 4);
+        bias.unit = p.b_sm == 1;
         if (p.bias_coeff) coeff = p.bias_coeff[b];
     }
     const float c1 = p.scale_log2e;
@@ -336,13 +350,13 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
         if constexpr (KG > 1) {
             attn_tile<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + kg * SUB_BYTES,
                                                                cur + kg * SUB_BYTES + KT::BYTES, st * STAGE_KEYS + kg * KVBLK,
-                                                               p.M, l31, hi, bias_row, p.b_sm, coeff, c1, qvalid);
+                                                               p.M, l31, hi, bias, coeff, c1);
         } else {
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub)
                 attn_tile<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES,
                                                                    cur + sub * SUB_BYTES + KT::BYTES, st * STAGE_KEYS + sub * KVBLK,
-                                                                   p.M, l31, hi, bias_row, p.b_sm, coeff, c1, qvalid);
+                                                                   p.M, l31, hi, bias, coeff, c1);
         }
         __syncthreads();
     }
@@ -352,16 +366,14 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
             const int key0 = st * STAGE_KEYS + kg * KVBLK;
             if (key0 < p.M)
                 attn_tile<T, KS, DT, HAS_BIAS, true, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + kg * SUB_BYTES,
-                                                                  cur + kg * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, bias_row,
-                                                                  p.b_sm, coeff, c1, qvalid);
+                                                                  cur + kg * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
         } else {
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) {
                 const int key0 = st * STAGE_KEYS + sub * KVBLK;
                 if (key0 < p.M)
                     attn_tile<T, KS, DT, HAS_BIAS, true, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES,
-                                                                      cur + sub * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, bias_row,
-                                                                      p.b_sm, coeff, c1, qvalid);
+                                                                      cur + sub * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
             }
         }
     }
@@ -476,10 +488,15 @@ __global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, HAS_BIAS>::value)) 
     V8 qf[KS];
     load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qvalid, hi, p.D);
 
-    const float *bias_row = nullptr;
+    BiasRef bias;
     float coeff = 1.f;
-    if (HAS_BIAS) {
-        bias_row = p.bias + b * p.b_sb + h * p.b_sh + (long)qrow * p.b_sn;
+    if (HAS_BIAS) {   // descriptor over this (b, h) slice; the host guarantees its extent is < 2^31 bytes
+        const float *bbase = p.bias + b * p.b_sb + h * p.b_sh;
+        const unsigned bytes = (unsigned)((((long)(p.N - 1) * p.b_sn + (long)(p.M - 1) * p.b_sm) + 1) * 4);
+        bias.srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bbase), 0, bytes, 0x00020000);
+        bias.row_off = qvalid ? (unsigned)((long)qrow * p.b_sn * 4) : OOB_OFF;
+        bias.key_stride = (unsigned)(p.b_sm * 4);
+        bias.unit = p.b_sm == 1;
         if (p.bias_coeff) coeff = p.bias_coeff[b];
     }
     const float c1 = p.scale_log2e;
@@ -529,7 +546,7 @@ __global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, HAS_BIAS>::value)) 
         f32x16 s_next[2];
         score_tile<T, KS>(s_next, qf, smem + slot1 * SUB_BYTES, (t + 1) * KVBLK, p.M, l31, hi);   // independent of the softmax below
         attn_tile_sm_pv<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA>(s_cur, oacc, m_run, l_run, smem + slot * SUB_BYTES + KT::BYTES,
-                                                                t * KVBLK, p.M, l31, hi, bias_row, p.b_sm, coeff, c1, qvalid);
+                                                                t * KVBLK, p.M, l31, hi, bias, coeff, c1);
         s_cur[0] = s_next[0];
         s_cur[1] = s_next[1];
         slot = slot1;
@@ -539,11 +556,9 @@ __global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, HAS_BIAS>::value)) 
         const int key0 = (ntiles - 1) * KVBLK;
         const char *Vs = smem + slot * SUB_BYTES + KT::BYTES;
         if (ragged)
-            attn_tile_sm_pv<T, KS, DT, HAS_BIAS, true, ROWSUM_MFMA>(s_cur, oacc, m_run, l_run, Vs, key0, p.M, l31, hi, bias_row,
-                                                                   p.b_sm, coeff, c1, qvalid);
+            attn_tile_sm_pv<T, KS, DT, HAS_BIAS, true, ROWSUM_MFMA>(s_cur, oacc, m_run, l_run, Vs, key0, p.M, l31, hi, bias, coeff, c1);
         else
-            attn_tile_sm_pv<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA>(s_cur, oacc, m_run, l_run, Vs, key0, p.M, l31, hi, bias_row,
-                                                                    p.b_sm, coeff, c1, qvalid);
+            attn_tile_sm_pv<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA>(s_cur, oacc, m_run, l_run, Vs, key0, p.M, l31, hi, bias, coeff, c1);
     }
 
     float l_tot;
@@ -694,7 +709,9 @@ template <typename T, int NW, bool HAS_BIAS> static int dispatch_d(const AttnPar
 template <typename T> static int dispatch_nw(const AttnParams &p, hipStream_t s) {
     // Fewer waves per workgroup when the problem is too small to give every CU a 4-wave block.
     const long rows32 = (long)((p.N + 31) / 32) * p.B * p.H;  // 32-row wave tasks
-    const bool wide = rows32 >= 4 * 256 && p.N >= 128;
+    // 4-wave workgroups for big launches and always for the widest heads (2-wave groups would need > 512
+    // registers per lane for their share of the d=160 K/V staging)
+    const bool wide = (rows32 >= 4 * 256 && p.N >= 128) || p.D > 96;
     if (p.bias) return wide ? dispatch_d<T, 4, true>(p, s) : dispatch_d<T, 2, true>(p, s);
     // 8-wave workgroups (256 query rows per K/V stage) once they still give every CU a workgroup
     static int nw8 = -1;
