@@ -21,6 +21,7 @@ from ._lib import PwwHipError
 
 _HALF = (torch.float16, torch.bfloat16)
 ROW_GATE = "_PWW_ROW_GATE"   # private context key: fp32 [B] per-row bias coefficient (see pww_hip/sampler.py)
+_LAZY_W = True               # hand weight_function a ScaledW instead of the raw map (see ScaledW)
 KV_CACHE = "_PWW_KV_CACHE"   # private context key: {id(attn): (attn, [B, 77, 2C] fused K|V projection)} for one request
 _warned = set()
 
@@ -178,6 +179,71 @@ class _AbsQK:
         return getattr(self._p._materialize().abs(), name)
 
 
+class ScaledW:
+    """Lazy ``coeff * w`` handed to ``weight_function`` in place of the weight map ``w`` (:94, :106).
+
+    Every shipped weight function is ``c0 * w * g(sigma) * reduce(qk)`` -- scalar (or per-image) factors times
+    the constant map. Multiplying / dividing a ScaledW by Python numbers, 0-dim tensors or per-image
+    ``[B,1,1,1]`` tensors only updates the coefficient; the fused kernel then receives the ORIGINAL map plus
+    the coefficient vector (``bias_coeff``), so the [N, 77] product is never materialised (3-4 tiny elementwise
+    launches per cross-attention layer and step saved). Any other use -- addition, indexing, torch functions,
+    attribute access -- materialises the real tensor and the computation continues on it, unchanged.
+    """
+    __slots__ = ("w", "coeff")
+
+    def __init__(self, w, coeff=1.0):
+        self.w, self.coeff = w, coeff
+
+    @staticmethod
+    def _is_factor(x):
+        if isinstance(x, (int, float)):
+            return True
+        return torch.is_tensor(x) and (x.dim() == 0 or (x.dim() == 4 and x.shape[1:] == (1, 1, 1)))
+
+    def _scaled(self, factor, divide=False):
+        if not self._is_factor(factor):
+            return None
+        if torch.is_tensor(factor):
+            factor = factor.to(torch.float32)
+        c = self.coeff / factor if divide else self.coeff * factor
+        return ScaledW(self.w, c)
+
+    def __mul__(self, other):
+        r = self._scaled(other)
+        return r if r is not None else self.materialize() * other
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, other):
+        r = self._scaled(other, divide=True)
+        return r if r is not None else self.materialize() / other
+
+    def __neg__(self):
+        return ScaledW(self.w, -self.coeff if not torch.is_tensor(self.coeff) else -self.coeff)
+
+    def materialize(self):
+        return self.w * self.coeff
+
+    # everything else behaves like the tensor it stands for
+    def __add__(self, other): return self.materialize() + other
+    def __radd__(self, other): return other + self.materialize()
+    def __sub__(self, other): return self.materialize() - other
+    def __rsub__(self, other): return other - self.materialize()
+    def __rtruediv__(self, other): return other / self.materialize()
+    def __pow__(self, other): return self.materialize() ** other
+    def __getitem__(self, idx): return self.materialize()[idx]
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        conv = lambda a: a.materialize() if isinstance(a, ScaledW) else a  # noqa: E731
+        return func(*[conv(a) for a in args], **{k: conv(v) for k, v in (kwargs or {}).items()})
+
+
 def _orig_weight_to_tokens(w_orig, n_tokens):
     """The reference's fallback when no CROSS_ATTENTION_WEIGHT_<N> key exists (:96-101): bilinear
     (align_corners=True) by 1/sqrt(H*W/N), then 1-D nearest to N. Rare (sizes not divisible by 64),
@@ -287,8 +353,22 @@ def pww_attention(attn, hidden_states, context=None):
                 w = cache[n_img]
             else:
                 w = 0
-        bias = f(w, context["SIGMA"], QKProxy(query, key, attn.heads))
+        lazy_w = ScaledW(w) if torch.is_tensor(w) and _LAZY_W else w
+        bias = f(lazy_w, context["SIGMA"], QKProxy(query, key, attn.heads))
 
+    coeff = None
+    if isinstance(bias, ScaledW):      # coeff * w: keep the map, pass the coefficient to the kernel
+        c = bias.coeff
+        B = query.shape[0]
+        if torch.is_tensor(c):
+            coeff = c.reshape(-1).to(torch.float32)
+            coeff = coeff.expand(B) if coeff.numel() == 1 else coeff
+        else:
+            coeff = torch.full((B,), float(c), dtype=torch.float32, device=query.device)
+        if gate is not None:
+            coeff = coeff * gate
+        gate = coeff
+        bias = bias.w
     if isinstance(bias, QKProxy):
         bias = bias._materialize()
     if not torch.is_tensor(bias) or bias.dim() == 0:

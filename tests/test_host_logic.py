@@ -1,6 +1,7 @@
 """CPU tests of the host logic and the C-ABI boundary (no compute calls: there is no GPU here)."""
 import ctypes
 import json
+import math
 import os
 import re
 
@@ -142,3 +143,24 @@ def test_qk_proxy_reductions_with_injected_stats(monkeypatch):
     assert p1.max().dim() == 0                       # batch 1: a 0-dim tensor, like torch's qk.max()
     bias = cases.weight_fn_runner(torch.ones(N, M), torch.tensor(3.0), p1)
     assert bias.shape == (N, M)
+
+
+def test_scaled_w_algebra():
+    """ScaledW (lazy coeff * w): scalar / per-image factors fold into the coefficient, anything else falls back to
+    the real tensor with identical values."""
+    from pww_hip.attention import ScaledW
+    w = torch.rand(6, 5)
+    qmax1, qmaxB = torch.tensor(3.0), torch.tensor([2.0, 4.0]).reshape(2, 1, 1, 1)
+    r = 0.4 * ScaledW(w) * math.log(1 + 7.0) * qmax1
+    assert isinstance(r, ScaledW) and r.w is w
+    assert torch.allclose(r.materialize(), 0.4 * w * math.log(8.0) * qmax1)
+    rb = cases.weight_fn_runner(ScaledW(w), torch.tensor(7.0), type("Q", (), {"max": lambda self: qmaxB})())
+    assert isinstance(rb, ScaledW) and rb.coeff.shape == (2, 1, 1, 1)
+    assert torch.allclose(rb.materialize(), cases.weight_fn_runner(w, torch.tensor(7.0), type("Q", (), {"max": lambda self: qmaxB})()))
+    assert isinstance(ScaledW(w) / 2.0, ScaledW) and torch.allclose((ScaledW(w) / 2.0).materialize(), w / 2)
+    # non-linear uses materialise
+    assert torch.is_tensor(ScaledW(w, 2.0) + 1.0) and torch.allclose(ScaledW(w, 2.0) + 1.0, 2 * w + 1)
+    assert torch.allclose(torch.tanh(ScaledW(w, 2.0)), torch.tanh(2 * w))
+    assert torch.allclose(ScaledW(w, 2.0) * torch.ones(6, 5), 2 * w)
+    assert ScaledW(w, 2.0).shape == w.shape and torch.allclose(ScaledW(w, 3.0)[1], 3 * w[1])
+    assert torch.allclose((ScaledW(w, 2.0) ** 2), (2 * w) ** 2) and torch.allclose(1.0 - ScaledW(w), 1.0 - w)
