@@ -297,9 +297,9 @@ def pww_attention(attn, hidden_states, context=None):
     merged-head [B, N, heads*D] tensor BEFORE the output projection."""
     is_dict = True
     if context is not None:
-        try:
+        if isinstance(context, dict) or hasattr(context, "keys"):
             context_tensor = context["CONTEXT_TENSOR"]
-        except Exception:   # plain tensor context: vanilla pipelines keep working (:65-69)
+        else:               # plain tensor context: vanilla pipelines keep working (the reference's try/except, :65-69)
             context_tensor = context
             is_dict = False
     else:

@@ -234,6 +234,33 @@ def test_fused_projections_and_kv_cache(gpu_device):
     assert (y_self2.float() - ref2.float()).abs().max() <= 2e-3 * ref2.float().abs().max()
 
 
+def test_attn_processor_plug_matches_class_patch(gpu_device):
+    """The attention-processor plug point (diffusers >= 0.12 `Attention` modules) computes the same op as the
+    class-level `CrossAttention.__call__` patch of the reference (:193-195)."""
+    import pww_hip
+    case = cases.make_attention_case("sd15_n256", seed=9)
+    dev, dtype = gpu_device, torch.float16
+    mod = case["attn_cross"].to(dev, dtype)
+    mod.norm_cross = None                      # attributes a diffusers `Attention` module carries
+    mod.residual_connection = False
+    mod.rescale_output_factor = 1.0
+    hidden = case["hidden"].to(dev, dtype)
+    ctx = {"CONTEXT_TENSOR": case["ctx"].to(dev, dtype), "CROSS_ATTENTION_WEIGHT_256": case["w"].to(dev), "SIGMA": torch.tensor(3.0),
+           "WEIGHT_FUNCTION": cases.weight_fn_runner}
+    proc = pww_hip.PwWAttnProcessor()
+    y_proc = proc(mod, hidden, encoder_hidden_states=ctx)
+    y_patch = pww_hip.inj_forward(mod, hidden, ctx)
+    assert torch.equal(y_proc, y_patch)
+    y_self = proc(mod_self := case["attn_self"].to(dev, dtype), hidden)
+    assert torch.equal(y_self, pww_hip.inj_forward(mod_self, hidden))
+    # 4-D (spatial) hidden states, as newer UNet blocks may pass them
+    sp = hidden.transpose(1, 2).reshape(1, 1280, 16, 16).contiguous()
+    mod_self.norm_cross, mod_self.residual_connection, mod_self.rescale_output_factor = None, True, 2.0
+    y_sp = proc(mod_self, sp)
+    want = (pww_hip.inj_forward(mod_self, hidden).transpose(1, 2).reshape(1, 1280, 16, 16) + sp) / 2.0
+    assert (y_sp.float() - want.float()).abs().max() <= 1e-3 * want.float().abs().max()
+
+
 def test_exotic_weight_function_materializes(gpu_device):
     """A weight function that uses qk element-wise still works (QKProxy materialises Q K^T)."""
     import pww_hip

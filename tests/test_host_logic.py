@@ -164,3 +164,38 @@ def test_scaled_w_algebra():
     assert torch.allclose(ScaledW(w, 2.0) * torch.ones(6, 5), 2 * w)
     assert ScaledW(w, 2.0).shape == w.shape and torch.allclose(ScaledW(w, 3.0)[1], 3 * w[1])
     assert torch.allclose((ScaledW(w, 2.0) ** 2), (2 * w) ** 2) and torch.allclose(1.0 - ScaledW(w), 1.0 - w)
+
+
+def test_public_api_matches_reference_signatures():
+    """Drop-in surface: what runner.py / runner_inpaint.py import must exist, and the function API must take the
+    reference's parameters with the reference's defaults (paint_with_words.py:393-413, :128-140;
+    paint_with_words_inpaint.py:139-157). Extra keyword-only-in-practice extensions must come last."""
+    import inspect
+    import paint_with_words as pw
+    from paint_with_words import (paint_with_words, PaintWithWord_StableDiffusionPipeline,            # runner.py:7
+                                  paint_with_words_inpaint, PaintWithWord_StableDiffusionInpaintPipeline,  # runner_inpaint.py:6
+                                  pww_load_tools, fig_from_settings)                                  # __init__.py:1-3
+    sig = inspect.signature(paint_with_words)
+    ref = [("color_context", {}), ("color_map_image", None), ("input_prompt", ""), ("num_inference_steps", 30),
+           ("guidance_scale", 7.5), ("seed", 0), ("scheduler_type", None), ("device", "cuda:0"), ("weight_function", None),
+           ("local_model_path", None), ("hf_model_path", "CompVis/stable-diffusion-v1-4"), ("preloaded_utils", None),
+           ("unconditional_input_prompt", ""), ("model_token", None), ("init_image", None), ("strength", 0.5)]
+    names = list(sig.parameters)
+    assert names[: len(ref)] == [n for n, _ in ref]
+    for n, dflt in ref:
+        if n not in ("scheduler_type", "weight_function"):
+            assert sig.parameters[n].default == dflt, n
+    assert sig.parameters["scheduler_type"].default.__name__ == "LMSDiscreteScheduler"
+    wf = sig.parameters["weight_function"].default                       # 0.1 * w * log(sigma + 1) * qk.max()
+    assert abs(float(wf(torch.tensor(2.0), torch.tensor(3.0), torch.tensor([1.0, 5.0]))) - 0.1 * 2 * math.log(4.0) * 5) < 1e-6
+    sig_i = inspect.signature(paint_with_words_inpaint)
+    ref_i = ["color_context", "color_map_image", "mask_image", "init_image", "input_prompt", "num_inference_steps", "guidance_scale",
+             "seed", "scheduler_type", "device", "weight_function", "local_model_path", "hf_model_path", "preloaded_utils",
+             "unconditional_input_prompt", "model_token", "strength"]
+    assert list(sig_i.parameters)[: len(ref_i)] == ref_i
+    assert sig_i.parameters["num_inference_steps"].default == 150 and sig_i.parameters["strength"].default == 1.0
+    assert sig_i.parameters["hf_model_path"].default == "runwayml/stable-diffusion-inpainting"
+    assert list(inspect.signature(pww_load_tools).parameters) == ["device", "scheduler_type", "local_model_path", "hf_model_path", "model_token"]
+    assert list(inspect.signature(pw.inj_forward).parameters) == ["self", "hidden_states", "context", "mask"]
+    with pytest.raises(AssertionError):
+        pww_load_tools(device="cpu")          # reference :142-144: a model path is required
