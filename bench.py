@@ -273,7 +273,7 @@ def main():
             heads, n_tok, d = 8, (H // 8) * (W // 8), 40
             flops = 4.0 * b_rows * heads * n_tok * n_tok * d      # algorithmic: QK^T + PV
             ach = flops / (us * 1e-6) / 1e12
-            result["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_kernel<%s, d=40> self-attention N=%d (B=%d rows folded)" % (args.dtype, n_tok, b_rows),
+            result["roofline"] = {"bound": "mfma", "kernel": "attn_fwd_fold_kernel<%s, d=40> self-attention N=%d (B=%d rows folded)" % (args.dtype, n_tok, b_rows),
                                   "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                                   "traffic": measured_traffic(n_tok, d, b_rows), "algorithmic_bytes": 2 * (2 * b_rows * n_tok * heads * d) * 2, "avg_us": round(us, 2), "launches": n_launch, "flops_per_launch": flops}
     if rank == 0 and world == 1 and not args.no_reference_ops:

@@ -123,9 +123,10 @@ __device__ __forceinline__ void stage_store(const u32x4 (&kreg)[KPT], const u32x
             char *dst = buf + pl.v_lds[i];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                u32x2 w;
-                w[0] = half_of(vreg[i][0], j) | (half_of(vreg[i][1], j) << 16);
-                w[1] = half_of(vreg[i][2], j) | (half_of(vreg[i][3], j) << 16);
+                u32x2 w;   // element j of four consecutive keys: one v_perm_b32 per output word
+                const unsigned sel = (j & 1) ? 0x07060302u : 0x05040100u;
+                w[0] = __builtin_amdgcn_perm(vreg[i][1][j >> 1], vreg[i][0][j >> 1], sel);
+                w[1] = __builtin_amdgcn_perm(vreg[i][3][j >> 1], vreg[i][2][j >> 1], sel);
                 *reinterpret_cast<u32x2 *>(dst + j * VT::STRIDE) = w;
             }
         }
@@ -195,6 +196,30 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
     // raw-domain logits x = s + c*bias (scale > 0, so the row max commutes with the scaling)
     // (a 4-way max tree and packed v_pk_fma_f32 for the exp arguments were measured: neutral to -3%)
     float tmax = -INFINITY;
+    if (HAS_BIAS && bias.unit) {
+        // unit key stride (the PwW [N, 77] maps): a lane's 8 consecutive keys of each (block, half) are 32 contiguous
+        // bytes of its bias row -> two 16-byte loads instead of eight 4-byte ones (the row stride makes every lane hit
+        // its own cache line either way, so the texture-address work per tile drops 4x). Dword-aligned only, which
+        // buffer loads allow; the range check is per dword, so a row tail never zeroes its in-range neighbours.
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const unsigned off = bias.row_off + (unsigned)(key0 + kb * 32 + 16 * g + 8 * hi) * 4u;
+                const u32x4 b0 = __builtin_amdgcn_raw_buffer_load_b128(bias.srd, off, 0, 0);
+                const u32x4 b1 = __builtin_amdgcn_raw_buffer_load_b128(bias.srd, off + 16u, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = g * 8 + j;
+                    const float bv = __builtin_bit_cast(float, j < 4 ? b0[j] : b1[j - 4]);
+                    float x = fmaf(bv, coeff, s[kb][r]);
+                    if (MASKED) x = key0 + key_of(kb, r, hi) < M ? x : -INFINITY;
+                    s[kb][r] = x;
+                    tmax = fmaxf(tmax, x);
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -202,7 +227,7 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
             const int key = key0 + key_of(kb, r, hi);
             float x = s[kb][r];
             if (HAS_BIAS) {   // keys >= M of a ragged tile read a neighbouring (in-range) value; they are masked below
-                const unsigned off = bias.unit ? bias.row_off + (unsigned)key * 4u : bias.row_off + (unsigned)key * bias.key_stride;
+                const unsigned off = bias.row_off + (unsigned)key * bias.key_stride;
                 const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bias.srd, off, 0, 0));
                 x = fmaf(bv, coeff, x);
             }
@@ -210,6 +235,7 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
             s[kb][r] = x;
             tmax = fmaxf(tmax, x);
         }
+    }
     }
     tmax = xhalf_max(tmax);
     const float m_new = fmaxf(m_run, tmax);   // finite: key0 < M, so at least one key of the tile is live
@@ -447,28 +473,131 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
     }
 }
 
-// ---- software-pipelined variant -------------------------------------------------------------------
-// Same arithmetic, different schedule: 64-key stages in a THREE-deep LDS ring, one barrier per stage, and
-// the score MFMAs of tile t+1 are issued BEFORE the softmax of tile t, so inside one wave the matrix pipe
-// works on S(t+1) while the VALU does max/exp/convert of S(t). At 2 waves/SIMD (all a B=2 launch offers)
-// this ILP is what hides the MFMA latency; the ring keeps the hazards one barrier apart:
-//   iteration t: park tile t+2 (registers) in ring[(t+2)%3]   -- last read by PV(t-1), before barrier t-1
-//                issue the global loads of tile t+3
-//                S(t+1) = K(t+1) Q^T from ring[(t+1)%3]        -- written in iteration t-1, visible since barrier t-1
-//                softmax(S(t)), PV with V(t) from ring[t%3]
-//                barrier t
-template <typename T, int KS, int DT, int NW, bool HAS_BIAS, bool ROWSUM_MFMA>
-__global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, HAS_BIAS>::value)) attn_fwd_pipe_kernel(const AttnParams p) {
+// ---- folded-reference variant (head dims with D % 16 == 8: SD1.x's d = 40) -----------------------------
+// For d = 40 the kernel is bound by the VALU side of the softmax, not by the matrix pipe
+// (profiles/r01_valu_ubench.md), so this variant removes VALU work and serialisation from the tile loop:
+//   * Q is pre-multiplied by scale*log2(e) once, and the head-dim padding column d = D of the K tile holds 1.0
+//     while the same column of the lane's Q fragment holds -m_ref: the score MFMA then delivers
+//     x = (q.k) scale log2(e) - m_ref directly -- no per-score subtract/multiply (32 v_fma per 64-key tile).
+//   * m_ref is a LAZY reference, not the exact running max: it is only raised (and O^T rescaled) when a score
+//     exceeds it by more than 2^FOLD_TAU; until then P = exp2(x) <= 2^FOLD_TAU is harmless in f16/bf16 and the
+//     final division by the row sum (accumulated from the same P by the ones row of V^T) makes the result
+//     independent of the reference. m_ref is always exactly representable in T, so the folded column is exact.
+//   * both 64-key sub-tiles of a stage are scored before one joint max / (rare) re-reference, so the exp / convert
+//     work of one sub-tile has independent MFMAs (scores of the other, PV of the previous) to run beside.
+constexpr float FOLD_TAU = 6.f;
+
+template <typename T, int KS>
+__device__ __forceinline__ void fold_set_ref(typename Vec<T>::v8 (&qf)[KS], float mref, int hi, int D) {
+    const T v = (T)(-mref);           // exact: mref is a T value
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)    // column D = k-step D/16, upper half (D % 16 == 8), element 0
+        if (ks == (D >> 4) && hi) qf[ks][0] = v;
+}
+
+// Raise the reference of the rows that need it (all rows on the very first tile, where m_ref is still 0 and may be
+// far ABOVE the scores as well), shift the pending scores and rescale O^T accordingly. Wave-uniform, rare.
+template <typename T, int KS, int DT, int NS>
+__device__ __forceinline__ void fold_rereference(f32x16 (&s)[NS][2], f32x16 (&oacc)[DT], float &mref,
+                                                 typename Vec<T>::v8 (&qf)[KS], float tmax, bool first, int hi, int D) {
+    const float mnew = (first || tmax > FOLD_TAU) ? (float)(T)(mref + tmax) : mref;
+    const float delta = mnew - mref;                                   // exact in fp32
+    const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);  // O^T is still zero on the first tile
+#pragma unroll
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[n][kb][r] -= delta;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+    mref = mnew;
+    fold_set_ref<T, KS>(qf, mref, hi, D);
+}
+
+// P = exp2(x) -> T, then O^T += V^T P^T for one 64-key sub-tile
+template <typename T, int DT, bool MASKED>
+__device__ __forceinline__ void fold_exp_pv(const f32x16 (&s)[2], f32x16 (&oacc)[DT], const char *Vs, int key0, int M,
+                                            int l31, int hi) {
+    typedef typename Vec<T>::v8 V8;
+    typedef VTile<DT> VT;
+    V8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pf[kb][r >> 3][r & 7] = (T)__builtin_amdgcn_exp2f(s[kb][r]);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        if (!MASKED || key0 + kb * 32 < M) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const char *vbase = Vs + l31 * VT::STRIDE + (kb * 32 + k2 * 16 + hi * 8) * 2;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const V8 vf = *reinterpret_cast<const V8 *>(vbase + dt * 32 * VT::STRIDE);
+                    oacc[dt] = mfma32(vf, pf[kb][k2], oacc[dt]);
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float max32(const f32x16 (&s)[2], float m) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kb][r]);
+    return m;
+}
+
+// one (possibly ragged) 64-key sub-tile
+template <typename T, int KS, int DT, bool MASKED>
+__device__ __forceinline__ void fold_tile(f32x16 (&oacc)[DT], float &mref, bool first, typename Vec<T>::v8 (&qf)[KS],
+                                          const char *Ks, const char *Vs, int key0, int M, int l31, int hi, int D) {
+    f32x16 s[1][2];
+    score_tile<T, KS>(s[0], qf, Ks, key0, MASKED ? M : 0x7fffffff, l31, hi);
+    if (MASKED) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[0][kb][r] = key0 + key_of(kb, r, hi) < M ? s[0][kb][r] : -INFINITY;
+    }
+    const float tmax = xhalf_max(max32(s[0], -INFINITY));   // finite: key0 < M
+    if (first || !__all(tmax <= FOLD_TAU)) fold_rereference<T, KS, DT, 1>(s, oacc, mref, qf, tmax, first, hi, D);
+    fold_exp_pv<T, DT, MASKED>(s[0], oacc, Vs, key0, M, l31, hi);
+}
+
+// one full 128-key stage: both sub-tiles scored first, one joint reference check
+template <typename T, int KS, int DT, int SUB_BYTES>
+__device__ __forceinline__ void fold_stage2(f32x16 (&oacc)[DT], float &mref, bool first, typename Vec<T>::v8 (&qf)[KS],
+                                            const char *cur, int key0, int l31, int hi, int D) {
+    typedef KTile<KS> KT;
+    f32x16 s[2][2];
+    score_tile<T, KS>(s[0], qf, cur, key0, 0x7fffffff, l31, hi);
+    score_tile<T, KS>(s[1], qf, cur + SUB_BYTES, key0 + KVBLK, 0x7fffffff, l31, hi);
+    const float tmax = xhalf_max(max32(s[1], max32(s[0], -INFINITY)));
+    if (first || !__all(tmax <= FOLD_TAU)) fold_rereference<T, KS, DT, 2>(s, oacc, mref, qf, tmax, first, hi, D);
+    fold_exp_pv<T, DT, false>(s[0], oacc, cur + KT::BYTES, key0, 0x7fffffff, l31, hi);
+    fold_exp_pv<T, DT, false>(s[1], oacc, cur + SUB_BYTES + KT::BYTES, key0 + KVBLK, 0x7fffffff, l31, hi);
+}
+
+template <typename T, int KS, int DT, int NW>
+__global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, false>::value)) attn_fwd_fold_kernel(const AttnParams p) {
     typedef typename Vec<T>::v8 V8;
     typedef typename Vec<T>::v4 V4;
     typedef KTile<KS> KT;
     typedef VTile<DT> VT;
+    constexpr int NSUB = 2;
     constexpr int NT = NW * 64;
     constexpr int SUB_BYTES = KT::BYTES + VT::BYTES;
-    constexpr int KPT = (KT::NCHUNK + NT - 1) / NT;
-    constexpr int VPT = (VT::NUNIT + NT - 1) / NT;
+    constexpr int STAGE_BYTES = NSUB * SUB_BYTES;
+    constexpr int STAGE_KEYS = NSUB * KVBLK;
+    constexpr int KPT = (NSUB * KT::NCHUNK + NT - 1) / NT;
+    constexpr int VPT = (NSUB * VT::NUNIT + NT - 1) / NT;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // ring of three 64-key stages
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // two stage buffers (double buffering)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -487,95 +616,82 @@ __global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, HAS_BIAS>::value)) 
 
     V8 qf[KS];
     load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qvalid, hi, p.D);
-
-    BiasRef bias;
-    float coeff = 1.f;
-    if (HAS_BIAS) {   // descriptor over this (b, h) slice; the host guarantees its extent is < 2^31 bytes
-        const float *bbase = p.bias + b * p.b_sb + h * p.b_sh;
-        const unsigned bytes = (unsigned)((((long)(p.N - 1) * p.b_sn + (long)(p.M - 1) * p.b_sm) + 1) * 4);
-        bias.srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bbase), 0, bytes, 0x00020000);
-        bias.row_off = qvalid ? (unsigned)((long)qrow * p.b_sn * 4) : OOB_OFF;
-        bias.key_stride = (unsigned)(p.b_sm * 4);
-        bias.unit = p.b_sm == 1;
-        if (p.bias_coeff) coeff = p.bias_coeff[b];
-    }
-    const float c1 = p.scale_log2e;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)          // scores come out of the MFMA in the exp2 domain
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[ks][j] = (T)((float)qf[ks][j] * p.scale_log2e);
 
     f32x16 oacc[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    // static priority for the later-dispatched half of an 8-wave workgroup: it otherwise loses every VALU
+    // arbitration against its older SIMD partner (guide: "two waves per SIMD"); measured +1 %
+    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+    float mref = 0.f;      // softmax reference of the lane's row (exp2 domain), identical in both half-waves
+    bool first = true;     // no tile processed yet: m_ref not established
 
-    for (int i = tid * 16; i < 3 * SUB_BYTES; i += NT * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0u, 0u, 0u, 0u};
+    // padding is never staged: zero both buffers once, then row D of every V^T tile = ones (softmax denominator
+    // from the PV MFMA) and column D of every K row = one (the folded -m_ref term of the score MFMA)
+    for (int i = tid * 16; i < 2 * STAGE_BYTES; i += NT * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
-    if (ROWSUM_MFMA) {
+    {
         const T one = (T)1.0f;
-        for (int i = tid; i < 3 * KVBLK; i += NT)
+        for (int i = tid; i < 2 * NSUB * KVBLK; i += NT) {
             *reinterpret_cast<T *>(smem + (i >> 6) * SUB_BYTES + KT::BYTES + p.D * VT::STRIDE + (i & 63) * 2) = one;
+            *reinterpret_cast<T *>(smem + (i >> 6) * SUB_BYTES + (i & 63) * KT::STRIDE + p.D * 2) = one;
+        }
     }
 
     StagePlan<KPT, VPT> plan;
-    make_plan<T, KS, DT, NT, 1, KPT, VPT>(plan, tid, p.D, p.k_sm, p.v_sm);
+    make_plan<T, KS, DT, NT, NSUB, KPT, VPT>(plan, tid, p.D, p.k_sm, p.v_sm);
     const auto srd_k = head_srd(Kp, p.M, p.k_sm, p.D);
     const auto srd_v = head_srd(Vp, p.M, p.v_sm, p.D);
-    const unsigned k_step = (unsigned)(KVBLK * p.k_sm * 2), v_step = (unsigned)(KVBLK * p.v_sm * 2);
+    const unsigned k_step = (unsigned)(STAGE_KEYS * p.k_sm * 2), v_step = (unsigned)(STAGE_KEYS * p.v_sm * 2);
     u32x4 kreg[KPT];
     u32x4 vreg[VPT][4];
-    const int ntiles = (p.M + KVBLK - 1) / KVBLK;
-    const bool ragged = (p.M % KVBLK) != 0;
+    const int nstage = (p.M + STAGE_KEYS - 1) / STAGE_KEYS;
+    const int nfull = p.M / STAGE_KEYS;
 
-    // prologue: tiles 0 and 1 into the ring, tile 2 into registers, S(0) computed
     stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);
     stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
-    if (ntiles > 1) {
-        stage_load(kreg, vreg, plan, srd_k, srd_v, k_step, v_step);
-        stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem + SUB_BYTES);
-    }
-    if (ntiles > 2) stage_load(kreg, vreg, plan, srd_k, srd_v, 2 * k_step, 2 * v_step);
+    stage_load(kreg, vreg, plan, srd_k, srd_v, k_step, v_step);     // past the last key: zeros (out of range)
     __syncthreads();
-    f32x16 s_cur[2];
-    score_tile<T, KS>(s_cur, qf, smem, 0, p.M, l31, hi);
 
-    int slot = 0;   // ring slot of tile t
-    for (int t = 0; t + 1 < ntiles; ++t) {
-        const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
-        if (t + 2 < ntiles) stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem + slot2 * SUB_BYTES);
-        if (t + 3 < ntiles) stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(t + 3) * k_step, (unsigned)(t + 3) * v_step);
-        f32x16 s_next[2];
-        score_tile<T, KS>(s_next, qf, smem + slot1 * SUB_BYTES, (t + 1) * KVBLK, p.M, l31, hi);   // independent of the softmax below
-        attn_tile_sm_pv<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA>(s_cur, oacc, m_run, l_run, smem + slot * SUB_BYTES + KT::BYTES,
-                                                                t * KVBLK, p.M, l31, hi, bias, coeff, c1);
-        s_cur[0] = s_next[0];
-        s_cur[1] = s_next[1];
-        slot = slot1;
+    int st = 0;
+    for (; st < nfull; ++st) {   // full stages; ONE barrier per stage. Store / load are unconditional (stages past the
+        char *cur = smem + (st & 1) * STAGE_BYTES;                  // end read zeros and land in a buffer nobody reads),
+        char *nxt = smem + ((st & 1) ^ 1) * STAGE_BYTES;            // so the whole body up to the reference check is one block
+        stage_store<DT, KPT, VPT>(kreg, vreg, plan, nxt);
+        stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
+        fold_stage2<T, KS, DT, SUB_BYTES>(oacc, mref, first, qf, cur, st * STAGE_KEYS, l31, hi, p.D);
+        first = false;
         __syncthreads();
     }
-    {   // last tile (the only one that can be ragged)
-        const int key0 = (ntiles - 1) * KVBLK;
-        const char *Vs = smem + slot * SUB_BYTES + KT::BYTES;
-        if (ragged)
-            attn_tile_sm_pv<T, KS, DT, HAS_BIAS, true, ROWSUM_MFMA>(s_cur, oacc, m_run, l_run, Vs, key0, p.M, l31, hi, bias, coeff, c1);
-        else
-            attn_tile_sm_pv<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA>(s_cur, oacc, m_run, l_run, Vs, key0, p.M, l31, hi, bias, coeff, c1);
+    if (st < nstage) {           // ragged tail stage (already in LDS)
+        char *cur = smem + (st & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int key0 = st * STAGE_KEYS + sub * KVBLK;
+            if (key0 < p.M) {
+                fold_tile<T, KS, DT, true>(oacc, mref, first, qf, cur + sub * SUB_BYTES, cur + sub * SUB_BYTES + KT::BYTES,
+                                           key0, p.M, l31, hi, p.D);
+                first = false;
+            }
+        }
     }
 
-    float l_tot;
-    if (ROWSUM_MFMA) {
-        const int rl = p.D & 31, tl = p.D >> 5;
-        float lv = 0.f;
+    // softmax denominator: row D of O^T (tile D / 32, register (D % 32) / 2, held by the hi == 0 half)
+    const int rl = p.D & 31, tl = p.D >> 5;
+    float lv = 0.f;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const float c = rl == 8 ? oacc[dt][4] : rl == 16 ? oacc[dt][8] : oacc[dt][12];
-            lv = dt == tl ? c : lv;
-        }
-        const float other = __shfl_xor(lv, 32);
-        l_tot = hi ? other : lv;
-    } else {
-        l_tot = l_run + __shfl_xor(l_run, 32);
+    for (int dt = 0; dt < DT; ++dt) {
+        const float c = rl == 8 ? oacc[dt][4] : oacc[dt][12];
+        lv = dt == tl ? c : lv;
     }
-    const float inv = 1.f / l_tot;
+    const float other = __shfl_xor(lv, 32);
+    const float inv = 1.f / (hi ? other : lv);
     if (qvalid) {
         T *orow = Op + (long)qrow * p.o_sn;
 #pragma unroll
@@ -621,10 +737,10 @@ static int launch_attn_rs(const AttnParams &p, hipStream_t stream) {
     return check_hip(hipGetLastError(), "attn_fwd_kernel launch");
 }
 
-// key-split workgroups: 4 row groups x 3 key groups = 12 waves, 192-key stages (self-attention, narrow heads)
-template <typename T, int KS, int DT, bool ROWSUM_MFMA>
+// key-split workgroups: NW row groups x KG key groups, KG*64-key stages (self-attention launches too small to give
+// every SIMD a wave otherwise): d <= 64 uses 4 x 3 = 12 waves, d = 80/96 uses 2 x 2 = 4 waves
+template <typename T, int KS, int DT, int NW, int KG, bool ROWSUM_MFMA>
 static int launch_attn_ksplit(const AttnParams &p, hipStream_t stream) {
-    constexpr int NW = 4, KG = 3;
     constexpr size_t stage = KG * (KTile<KS>::BYTES + VTile<DT>::BYTES);
     constexpr size_t merge = (size_t)(KG - 1) * NW * (DT * 16 + 2) * 64 * sizeof(float);
     constexpr size_t lds = 2 * stage > merge ? 2 * stage : merge;
@@ -647,17 +763,17 @@ static int ksplit_mode() {   // PWW_ATTN_KSPLIT=0/1 (A/B testing); default on
     return mode;
 }
 
-static int pipe_mode() {   // PWW_ATTN_PIPE=0/1 overrides the default schedule choice (A/B testing)
+static int fold_mode() {   // PWW_ATTN_FOLD=0 disables the folded-reference variant (A/B testing); default on
     static int mode = -2;
-    if (mode == -2) { const char *e = getenv("PWW_ATTN_PIPE"); mode = e ? atoi(e) : -1; }
+    if (mode == -2) { const char *e = getenv("PWW_ATTN_FOLD"); mode = e ? atoi(e) : 1; }
     return mode;
 }
 
-template <typename T, int KS, int DT, int NW, bool ROWSUM_MFMA>
-static int launch_attn_pipe(const AttnParams &p, hipStream_t stream) {
-    constexpr size_t lds = 3 * (KTile<KS>::BYTES + VTile<DT>::BYTES);
+template <typename T, int KS, int DT, int NW>
+static int launch_attn_fold(const AttnParams &p, hipStream_t stream) {
+    constexpr size_t lds = 2 * 2 * (KTile<KS>::BYTES + VTile<DT>::BYTES);
     const int qblocks = (p.N + NW * 32 - 1) / (NW * 32);
-    auto kern = attn_fwd_pipe_kernel<T, KS, DT, NW, false, ROWSUM_MFMA>;
+    auto kern = attn_fwd_fold_kernel<T, KS, DT, NW>;
     if (lds > 64 * 1024) {
         static thread_local bool done = false;
         if (!done) {
@@ -668,7 +784,7 @@ static int launch_attn_pipe(const AttnParams &p, hipStream_t stream) {
         }
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(qblocks * p.B * p.H)), dim3(NW * 64), lds, stream, p);
-    return check_hip(hipGetLastError(), "attn_fwd_pipe_kernel launch");
+    return check_hip(hipGetLastError(), "attn_fwd_fold_kernel launch");
 }
 
 template <typename T, int KS, int DT, int NW, bool HAS_BIAS>
@@ -679,18 +795,27 @@ static int launch_attn(const AttnParams &p, hipStream_t stream) {
         // the split LOSES, 101 -> 114 us, so it is limited to the under-filled case.)
         const long wgs = (long)((p.N + 127) / 128) * p.B * p.H;
         if (ksplit_mode() == 1 && wgs <= 256 && p.M >= 1024) {
-            if ((p.D & 31) != 0) return launch_attn_ksplit<T, KS, DT, true>(p, stream);
-            return launch_attn_ksplit<T, KS, DT, false>(p, stream);
+            if ((p.D & 31) != 0) return launch_attn_ksplit<T, KS, DT, 4, 3, true>(p, stream);
+            return launch_attn_ksplit<T, KS, DT, 4, 3, false>(p, stream);
         }
     }
-    if constexpr (!HAS_BIAS && DT <= 3 && NW == 4) {
-        if (pipe_mode() == 1) {
-            if ((p.D & 31) != 0) return launch_attn_pipe<T, KS, DT, NW, true>(p, stream);
-            return launch_attn_pipe<T, KS, DT, NW, false>(p, stream);
+    if constexpr (!HAS_BIAS && DT == 3 && NW == 2) {
+        // d = 80 / 96 with at most one 2-wave workgroup per CU (SD1.5 N = 1024 at B <= 2): two key groups -> a wave on
+        // every SIMD and half the serial stage count
+        const long wgs = (long)((p.N + 63) / 64) * p.B * p.H;
+        if (ksplit_mode() == 1 && wgs <= 256 && p.M >= 512) {
+            if ((p.D & 31) != 0) return launch_attn_ksplit<T, KS, DT, 2, 2, true>(p, stream);
+            return launch_attn_ksplit<T, KS, DT, 2, 2, false>(p, stream);
         }
+    }
+    if constexpr (!HAS_BIAS && KS == 3 && DT == 2) {
+        // d = 40 (and 8, 24): a free head-dim padding column in the K tile -> folded-reference softmax
+        if ((p.D & 15) == 8 && fold_mode() == 1) return launch_attn_fold<T, KS, DT, NW>(p, stream);
     }
     // head dims with padding rows in the V^T tile get the row sum from the MFMA (self-attention path)
-    if (!HAS_BIAS && (p.D & 31) != 0) return launch_attn_rs<T, KS, DT, NW, HAS_BIAS, true>(p, stream);
+    if constexpr (!HAS_BIAS) {
+        if ((p.D & 31) != 0) return launch_attn_rs<T, KS, DT, NW, false, true>(p, stream);
+    }
     return launch_attn_rs<T, KS, DT, NW, HAS_BIAS, false>(p, stream);
 }
 
@@ -701,8 +826,10 @@ template <typename T, int NW, bool HAS_BIAS> static int dispatch_d(const AttnPar
     if constexpr (NW == 8) { set_error("attn_fwd: internal dispatch error"); return PWW_EINVAL; } else {
     if (D <= 80) return launch_attn<T, 5, 3, NW, HAS_BIAS>(p, s);
     if (D <= 96) return launch_attn<T, 6, 3, NW, HAS_BIAS>(p, s);
+    if constexpr (NW == 2) { set_error("attn_fwd: internal dispatch error"); return PWW_EINVAL; } else {   // D > 96 always gets 4 waves
     if (D <= 128) return launch_attn<T, 8, 4, NW, HAS_BIAS>(p, s);
     return launch_attn<T, 10, 5, NW, HAS_BIAS>(p, s);
+    }
     }
 }
 

@@ -293,6 +293,14 @@ int main(int argc, char **argv) {
         {"d88_self_n128", PWW_DTYPE_F16, 1, 2, 128, 128, 88, 0, true, 1, 1.0f},
         {"d104_self_n128", PWW_DTYPE_BF16, 1, 2, 128, 128, 104, 0, true, 1, 1.0f},
         {"d152_self_n128", PWW_DTYPE_F16, 1, 2, 128, 128, 152, 0, true, 1, 0.7f},
+        // folded-reference variant (D % 16 == 8): ragged tails, every workgroup width, and logit spreads wide enough
+        // that the lazy reference has to be raised many times per row (gain 4: logits ~ N(0, 4^2) * log2 e)
+        {"d40_self_n300_f16", PWW_DTYPE_F16, 2, 4, 300, 300, 40, 0, true, 1, 1.0f},
+        {"d40_self_n300_bf16_hot", PWW_DTYPE_BF16, 2, 4, 300, 300, 40, 0, true, 1, 4.0f},
+        {"d40_n1000_m1000_hot", PWW_DTYPE_F16, 2, 8, 1000, 1000, 40, 0, true, 7, 4.0f},
+        {"d40_n520_m129_cold", PWW_DTYPE_F16, 1, 8, 520, 129, 40, 0, false, 3, 0.05f},
+        {"d40_n2048_b4_bf16", PWW_DTYPE_BF16, 4, 8, 2048, 2048, 40, 0, true, 61, 2.0f},
+        {"d24_self_n200", PWW_DTYPE_BF16, 1, 4, 200, 200, 24, 0, true, 1, 2.0f},
     };
     for (auto &c : cases) {
         const bool big = (long)c.N * c.M >= 1024L * 1024L || c.N >= 4096;
