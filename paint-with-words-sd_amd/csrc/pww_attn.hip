@@ -544,12 +544,18 @@ __device__ __forceinline__ void fold_exp_pv(const f32x16 (&s)[2], f32x16 (&oacc)
     }
 }
 
+// max of 32 scores and m: four independent chains (a dependent VALU op issues only every ~12 cycles for one wave,
+// so one serial v_max3 chain over a stage's 64 scores costs ~390 cycles by itself -- profiles/r01_attn_phases.md)
 __device__ __forceinline__ float max32(const f32x16 (&s)[2], float m) {
+    float m0 = m, m1 = s[0][0], m2 = s[1][0], m3 = s[1][8];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kb][r]);
-    return m;
+    for (int r = 0; r < 8; ++r) {
+        m0 = fmaxf(m0, s[0][r]);
+        m1 = fmaxf(m1, s[0][8 + r]);
+        m2 = fmaxf(m2, s[1][r]);
+        m3 = fmaxf(m3, s[1][8 + r]);
+    }
+    return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
 }
 
 // one (possibly ragged) 64-key sub-tile
@@ -569,18 +575,91 @@ __device__ __forceinline__ void fold_tile(f32x16 (&oacc)[DT], float &mref, bool 
     fold_exp_pv<T, DT, MASKED>(s[0], oacc, Vs, key0, M, l31, hi);
 }
 
-// one full 128-key stage: both sub-tiles scored first, one joint reference check
+// MFMA operand fragments of one 64-key sub-tile, requested from LDS ahead of their use: a ds_read_b128 issued
+// right before its MFMA exposes the LDS latency (100+ cycles with 8 waves queueing) on every k-step.
+template <typename T, int KS>
+__device__ __forceinline__ void load_kfrags(typename Vec<T>::v8 (&kf)[2][KS], const char *Ks, int l31, int hi) {
+    typedef typename Vec<T>::v8 V8;
+    typedef KTile<KS> KT;
+    const char *base = Ks + swap23(l31) * KT::STRIDE + hi * 16;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[kb][ks] = *reinterpret_cast<const V8 *>(base + kb * 32 * KT::STRIDE + ks * 32);
+}
+
+template <typename T, int DT>
+__device__ __forceinline__ void load_vfrags(typename Vec<T>::v8 (&vf)[2][2][DT], const char *Vs, int l31, int hi) {
+    typedef typename Vec<T>::v8 V8;
+    typedef VTile<DT> VT;
+    const char *base = Vs + l31 * VT::STRIDE + hi * 16;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+                vf[kb][k2][dt] = *reinterpret_cast<const V8 *>(base + (kb * 32 + k2 * 16) * 2 + dt * 32 * VT::STRIDE);
+}
+
+template <typename T, int KS>
+__device__ __forceinline__ void score_frags(f32x16 (&s)[2], const typename Vec<T>::v8 (&kf)[2][KS],
+                                            const typename Vec<T>::v8 (&qf)[KS]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = mfma32(kf[kb][ks], qf[ks], acc);
+        s[kb] = acc;
+    }
+}
+
+// O^T += V^T P^T with both operands in registers
+template <typename T, int DT>
+__device__ __forceinline__ void pv_frags(const typename Vec<T>::v8 (&pf)[2][2], f32x16 (&oacc)[DT],
+                                         const typename Vec<T>::v8 (&vf)[2][2][DT]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) oacc[dt] = mfma32(vf[kb][k2][dt], pf[kb][k2], oacc[dt]);
+}
+
+template <typename T>
+__device__ __forceinline__ void exp_tile(typename Vec<T>::v8 (&pf)[2][2], const f32x16 (&s)[2]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pf[kb][r >> 3][r & 7] = (T)__builtin_amdgcn_exp2f(s[kb][r]);
+}
+
+// one full 128-key stage: all K fragments and the first sub-tile's V fragments are requested up front, both
+// sub-tiles are scored, one joint reference check, then exp / PV per sub-tile
 template <typename T, int KS, int DT, int SUB_BYTES>
 __device__ __forceinline__ void fold_stage2(f32x16 (&oacc)[DT], float &mref, bool first, typename Vec<T>::v8 (&qf)[KS],
                                             const char *cur, int key0, int l31, int hi, int D) {
+    typedef typename Vec<T>::v8 V8;
     typedef KTile<KS> KT;
+    V8 k0[2][KS], k1[2][KS], v0[2][2][DT], v1[2][2][DT];
+    load_kfrags<T, KS>(k0, cur, l31, hi);
+    load_kfrags<T, KS>(k1, cur + SUB_BYTES, l31, hi);
+    load_vfrags<T, DT>(v0, cur + KT::BYTES, l31, hi);
+    __builtin_amdgcn_sched_barrier(0);          // keep the requests ahead of the MFMAs (hipcc sinks them otherwise)
     f32x16 s[2][2];
-    score_tile<T, KS>(s[0], qf, cur, key0, 0x7fffffff, l31, hi);
-    score_tile<T, KS>(s[1], qf, cur + SUB_BYTES, key0 + KVBLK, 0x7fffffff, l31, hi);
+    score_frags<T, KS>(s[0], k0, qf);
+    score_frags<T, KS>(s[1], k1, qf);
+    load_vfrags<T, DT>(v1, cur + SUB_BYTES + KT::BYTES, l31, hi);   // lands during the max / check below
+    __builtin_amdgcn_sched_barrier(0);
     const float tmax = xhalf_max(max32(s[1], max32(s[0], -INFINITY)));
     if (first || !__all(tmax <= FOLD_TAU)) fold_rereference<T, KS, DT, 2>(s, oacc, mref, qf, tmax, first, hi, D);
-    fold_exp_pv<T, DT, false>(s[0], oacc, cur + KT::BYTES, key0, 0x7fffffff, l31, hi);
-    fold_exp_pv<T, DT, false>(s[1], oacc, cur + SUB_BYTES + KT::BYTES, key0 + KVBLK, 0x7fffffff, l31, hi);
+    V8 pf[2][2];
+    exp_tile<T>(pf, s[0]);
+    pv_frags<T, DT>(pf, oacc, v0);
+    exp_tile<T>(pf, s[1]);
+    pv_frags<T, DT>(pf, oacc, v1);
 }
 
 template <typename T, int KS, int DT, int NW>
@@ -771,6 +850,7 @@ static int fold_mode() {   // PWW_ATTN_FOLD=0 disables the folded-reference vari
 
 template <typename T, int KS, int DT, int NW>
 static int launch_attn_fold(const AttnParams &p, hipStream_t stream) {
+
     constexpr size_t lds = 2 * 2 * (KTile<KS>::BYTES + VTile<DT>::BYTES);
     const int qblocks = (p.N + NW * 32 - 1) / (NW * 32);
     auto kern = attn_fwd_fold_kernel<T, KS, DT, NW>;
@@ -789,6 +869,11 @@ static int launch_attn_fold(const AttnParams &p, hipStream_t stream) {
 
 template <typename T, int KS, int DT, int NW, bool HAS_BIAS>
 static int launch_attn(const AttnParams &p, hipStream_t stream) {
+    if constexpr (!HAS_BIAS && KS == 3 && DT == 2) {
+        // d = 40 (and 8, 24): a free head-dim padding column in the K tile -> folded-reference softmax
+        // (also beats the key-split variant below at B = 1, N = 4096: 47 vs 52 us)
+        if ((p.D & 15) == 8 && fold_mode() == 1) return launch_attn_fold<T, KS, DT, NW>(p, stream);
+    }
     if constexpr (!HAS_BIAS && DT <= 2 && NW == 4) {
         // at most one 4-wave workgroup per CU (1 wave/SIMD) and a long key sequence: split the keys over 3 wave
         // groups -> 3 waves/SIMD. (Measured N=4096 d=40: B=1 55.8 -> 51.6 us; with two workgroups per CU, B=2,
@@ -807,10 +892,6 @@ static int launch_attn(const AttnParams &p, hipStream_t stream) {
             if ((p.D & 31) != 0) return launch_attn_ksplit<T, KS, DT, 2, 2, true>(p, stream);
             return launch_attn_ksplit<T, KS, DT, 2, 2, false>(p, stream);
         }
-    }
-    if constexpr (!HAS_BIAS && KS == 3 && DT == 2) {
-        // d = 40 (and 8, 24): a free head-dim padding column in the K tile -> folded-reference softmax
-        if ((p.D & 15) == 8 && fold_mode() == 1) return launch_attn_fold<T, KS, DT, NW>(p, stream);
     }
     // head dims with padding rows in the V^T tile get the row sum from the MFMA (self-attention path)
     if constexpr (!HAS_BIAS) {
