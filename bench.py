@@ -13,6 +13,8 @@ Workload = BASELINE.json configs[1]: SD1.5 topology random-init (seed 1234) bf16
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   "roofline"     dominant kernel (self-attention N=4096 d=40) TFLOP/s vs the dense bf16 MFMA peak,
                  timed live with HIP events on the launch stream in an instrumented pass;
+  "kernels"      the same pass's table for EVERY pww launch class (self / cross attention per resolution, the
+                 score reduction): average duration, algorithmic TFLOP/s and GB/s, bounding roofline and fraction;
   "cpu_baseline" the CPU oracle (port of the reference path) timed on this box's host cores on a
                  bounded sample (rank 0, N=1 only).
 """
@@ -69,28 +71,60 @@ def build_tools(device, dtype, scheduler_name, rank, world, inpaint=False):
 
 
 class EventTimer:
-    """HIP-event timing of selected kernel launches on the stream they are launched on."""
+    """HIP-event timing of every pww kernel launch on the stream it is launched on (instrumented pass only)."""
 
     def __init__(self):
-        self.pairs = []
+        self.pairs = {}
 
-    def wrap(self, fn, select):
+    def _timed(self, key, fn, *a, **kw):
+        s = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        out = fn(*a, **kw)
+        e1.record(s)
+        self.pairs.setdefault(key, []).append((e0, e1))
+        return out
+
+    def wrap_attention(self, fn):
         def wrapped(q, k, v, heads, scale, bias=None, bias_coeff=None):
-            if not select(q, k, bias):
-                return fn(q, k, v, heads, scale, bias=bias, bias_coeff=bias_coeff)
-            s = torch.cuda.current_stream()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(s)
-            out = fn(q, k, v, heads, scale, bias=bias, bias_coeff=bias_coeff)
-            e1.record(s)
-            self.pairs.append((e0, e1, q.shape[0]))
-            return out
+            key = ("cross" if bias is not None else ("self" if k.shape[1] == q.shape[1] else "cross-nobias"),
+                   q.shape[0], q.shape[1], k.shape[1], q.shape[2] // heads, heads, k.shape[0])
+            return self._timed(key, fn, q, k, v, heads, scale, bias=bias, bias_coeff=bias_coeff)
         return wrapped
 
-    def mean_us(self):
+    def wrap_stats(self, fn):
+        def wrapped(q, k, heads):
+            key = ("qk_reduce", q.shape[0], q.shape[1], k.shape[1], q.shape[2] // heads, heads, k.shape[0])
+            return self._timed(key, fn, q, k, heads)
+        return wrapped
+
+    def table(self, elem_bytes):
+        """Per launch class: average duration, algorithmic FLOPs / bytes and the roofline fraction."""
         torch.cuda.synchronize()
-        ts = [a.elapsed_time(b) * 1e3 for a, b, _ in self.pairs]
-        return (sum(ts) / len(ts), len(ts), self.pairs[0][2]) if ts else (None, 0, 0)
+        rows = []
+        for key, pairs in self.pairs.items():
+            kind, B, N, M, D, Hh, Bk = key
+            us = sum(a.elapsed_time(b) for a, b in pairs) * 1e3 / len(pairs)
+            C = Hh * D
+            if kind == "qk_reduce":
+                flops = 2.0 * B * Hh * N * M * D
+                nbytes = elem_bytes * (B * N * C + Bk * M * C)
+            else:
+                flops = 4.0 * B * Hh * N * M * D
+                nbytes = elem_bytes * (2 * B * N * C + 2 * Bk * M * C) + (N * M * 4 if kind == "cross" else 0)
+            tf, gbs = flops / us / 1e6, nbytes / us / 1e3
+            bound = "mfma" if flops / nbytes > MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS else "hbm"
+            rows.append({"kernel": kind, "B": B, "N": N, "M": M, "D": D, "launches": len(pairs), "avg_us": round(us, 2),
+                         "tflops": round(tf, 1), "gbs": round(gbs, 1), "bound": bound,
+                         "frac": round(tf / MFMA_PEAK_TFLOPS if bound == "mfma" else gbs / HBM_PEAK_GBS, 4)})
+        rows.sort(key=lambda r: -r["avg_us"] * r["launches"])
+        return rows
+
+    def mean_us(self, pred):
+        torch.cuda.synchronize()
+        sel = [(k, v) for k, v in self.pairs.items() if pred(k)]
+        ts = [a.elapsed_time(b) * 1e3 for _, v in sel for a, b in v]
+        return (sum(ts) / len(ts), len(ts), sel[0][0][1]) if ts else (None, 0, 0)
 
 
 def measured_traffic(n_tok, d, b_rows):
@@ -257,8 +291,8 @@ def main():
         # instrumented pass (same workload, folded mode so single launches can be bracketed by HIP events
         # on the launch stream): dominant kernel = self-attention at N = 4096, d = 40
         timer = EventTimer()
-        orig = ops.attention
-        ops.attention = timer.wrap(orig, lambda q, k, bias: bias is None and q.shape[1] == (H // 8) * (W // 8) and k.shape[1] == q.shape[1])
+        orig, orig_stats = ops.attention, ops.qk_stats
+        ops.attention, ops.qk_stats = timer.wrap_attention(orig), timer.wrap_stats(orig_stats)
         try:
             s2 = PwWSampler(unet, sched, "folded")
             _, _, cond, uncond = _encode_text_color_inputs(text, tok, device, rgb, dict(context), prompt, "", dtype=dtype)
@@ -266,8 +300,10 @@ def main():
             lat0 = initial_latents(0, unet.in_channels, H, W, batch_seeds=list(range(args.batch))).to(device) * sched.init_noise_sigma
             s2.sample(cond, uncond, lat0, sched.timesteps, args.guidance, weight_function)
         finally:
-            ops.attention = orig
-        us, n_launch, b_rows = timer.mean_us()
+            ops.attention, ops.qk_stats = orig, orig_stats
+        n_dom = (H // 8) * (W // 8)
+        us, n_launch, b_rows = timer.mean_us(lambda k: k[0] == "self" and k[2] == n_dom)
+        result["kernels"] = timer.table(2)
         log("roofline pass done", us, n_launch)
         if us:
             heads, n_tok, d = 8, (H // 8) * (W // 8), 40
