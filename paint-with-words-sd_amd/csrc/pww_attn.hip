@@ -11,9 +11,10 @@
 //   * scores are computed transposed (S^T = K Q^T) so a lane owns one query row: the row max/sum
 //     need a single cross-half exchange, the rescale factor is lane-local, and the exponentiated
 //     P^T registers are already in MFMA B-operand order for O^T = V^T P^T.
-//   * V is stored transposed in LDS (Vt[d][key]) by the staging pass, so the A operand of the PV
-//     MFMA is one ds_read_b128 per lane; K keeps its row-major image. Both row strides are padded
-//     by 16 B, which makes every ds_read_b128 lane group hit 16 distinct bank slots.
+//   * K and V both keep their row-major image in LDS (16-byte global loads, 16-byte LDS stores, no staging
+//     arithmetic); the PV MFMA's A operand V^T[d][8 keys] comes out of the hardware transpose read
+//     ds_read_b64_tr_b16 (two per fragment). Row strides are chosen so that every lane group of a ds_read_b128
+//     (K) / every 32-lane half of a transpose read (V) hits distinct banks.
 //   * global->LDS staging is split (issue the next tile's loads before computing the current
 //     tile, write them to LDS after the barrier), hiding HBM/L2 latency under the MFMAs.
 //   * blockIdx.x enumerates (b, h) fastest: with the observed block -> XCD round-robin every XCD's
@@ -37,16 +38,40 @@ struct AttnParams {
     float scale_log2e;  // scale * log2(e): softmax runs in the exp2 domain
 };
 
+// V tile as staged in LDS: ROW-MAJOR like K, [64 keys][DT*32 d], and transposed by the READ: gfx950's
+// ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a 4-row x 16-column block whose rows are supplied,
+// four 8-byte pieces each, by lanes 4r..4r+3 (probed on hardware: tools/tr_probe.cpp). So the PV MFMA's A operand
+// (V^T[d = lane & 31][8 consecutive keys]) is two such reads, and staging V costs what staging K costs: 16-byte
+// global loads and 16-byte LDS stores, no per-element transposition work (16 v_perm + 8 ds_write_b64 per 4x8 block
+// before, carried by 3 of 8 waves -- the stragglers every barrier waited for; profiles/r01_attn_phases.md 2b).
+// Row stride = 64 or 192 (mod 256) bytes, so the four rows a 32-lane half reads in one LDS cycle (64 bytes each)
+// fall into disjoint bank ranges.
 template <int DT> struct VTile {
-    static constexpr int ROWS = DT * 32;               // head dim padded to the MFMA M granularity
-    static constexpr int STRIDE = KVBLK * 2 + 16;      // bytes per d-row (64 keys + pad)
-    static constexpr int BYTES = ROWS * STRIDE;
-    static constexpr int NUNIT = (KVBLK / 4) * (ROWS / 8);  // (4 keys x 8 d) transpose units
+    static constexpr int COLS = DT * 32;               // head dim padded to the MFMA M granularity
+    static constexpr int CHK = COLS / 8;               // 16-byte chunks per key row (those with d < D are staged)
+    static constexpr int STRIDE = (DT & 1) ? DT * 64 : DT * 64 + 64;   // bytes per key row: 64 / 192 / 192 / 320 / 320
+    static constexpr int BYTES = KVBLK * STRIDE;
+    static constexpr int NCHUNK = KVBLK * CHK;
 };
 
-__device__ __forceinline__ uint32_t half_of(const u32x4 v, int j) {   // j is a compile-time constant at every call
-    const uint32_t w = v[j >> 1];
-    return (j & 1) ? (w >> 16) : (w & 0xffffu);
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// byte offset, inside a V tile, of the 8-byte piece lane l supplies for keys 0..3 / d-tile 0 of its fragment
+template <int DT> __device__ __forceinline__ int vfrag_lane_off(int lane) {
+    return ((lane >> 5) * 8 + ((lane & 15) >> 2)) * VTile<DT>::STRIDE + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+}
+
+// A-operand fragment of the PV MFMA: V[key0 .. key0+7][d = dt*32 + (lane & 31)] with key0 = kb*32 + k2*16 + 8*(lane>>5).
+// `vl` = tile base + vfrag_lane_off(lane); the rest are compile-time immediates.
+template <typename T, int DT>
+__device__ __forceinline__ typename Vec<T>::v8 load_vfrag(const char *vl, int kb, int k2, int dt) {
+    typedef __attribute__((address_space(3))) s16x4 *lds_p;
+    const char *a = vl + (kb * 32 + k2 * 16) * VTile<DT>::STRIDE + dt * 64;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a + 4 * VTile<DT>::STRIDE));
+    const s16x8 v = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(typename Vec<T>::v8, v);
 }
 
 // Loop-invariant part of a thread's share of the K/V staging: which 16-byte chunks it moves and where
@@ -64,7 +89,7 @@ template <int KPT, int VPT> struct StagePlan {
     unsigned k_off[KPT];
     int k_lds[KPT];
     bool k_ok[KPT];
-    unsigned v_off[VPT][4];
+    unsigned v_off[VPT];
     int v_lds[VPT];
     bool v_ok[VPT];
 };
@@ -84,13 +109,11 @@ __device__ __forceinline__ void make_plan(StagePlan<KPT, VPT> &pl, int tid, int 
     }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-        const int u = tid + i * NT;
-        const int kg = u % (16 * NSUB), dc = u / (16 * NSUB);        // key group (4 keys) over the whole stage
-        pl.v_ok[i] = u < NSUB * VT::NUNIT && dc * 8 < D;             // padding rows are initialised once, never staged
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-            pl.v_off[i][kk] = pl.v_ok[i] ? (unsigned)(((kg * 4 + kk) * v_sm + dc * 8) * 2) : OOB_OFF;
-        pl.v_lds[i] = (kg >> 4) * SUB_BYTES + KT::BYTES + (dc * 8) * VT::STRIDE + (kg & 15) * 8;
+        const int c = tid + i * NT;
+        const int key = c / VT::CHK, ch = c - key * VT::CHK;
+        pl.v_ok[i] = c < NSUB * VT::NCHUNK && ch * 8 < D;            // padding columns are initialised once, never staged
+        pl.v_off[i] = pl.v_ok[i] ? (unsigned)((key * v_sm + ch * 8) * 2) : OOB_OFF;
+        pl.v_lds[i] = (key >> 6) * SUB_BYTES + KT::BYTES + (key & 63) * VT::STRIDE + ch * 16;
     }
 }
 
@@ -98,39 +121,24 @@ __device__ __forceinline__ void make_plan(StagePlan<KPT, VPT> &pl, int tid, int 
 // head's K / V. Nothing here consumes the loaded registers: the loads stay in flight across the compute of
 // the current stage. (Unconditional on purpose: a load inside an `if` gets an s_waitcnt vmcnt(0) behind it.)
 template <typename SRD, int KPT, int VPT>
-__device__ __forceinline__ void stage_load(u32x4 (&kreg)[KPT], u32x4 (&vreg)[VPT][4], const StagePlan<KPT, VPT> &pl,
+__device__ __forceinline__ void stage_load(u32x4 (&kreg)[KPT], u32x4 (&vreg)[VPT], const StagePlan<KPT, VPT> &pl,
                                            SRD srd_k, SRD srd_v, unsigned k_stage_off, unsigned v_stage_off) {
 #pragma unroll
     for (int i = 0; i < KPT; ++i) kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_k, pl.k_off[i] + k_stage_off, 0, 0);
 #pragma unroll
-    for (int i = 0; i < VPT; ++i)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-            vreg[i][kk] = __builtin_amdgcn_raw_buffer_load_b128(srd_v, pl.v_off[i][kk] + v_stage_off, 0, 0);
+    for (int i = 0; i < VPT; ++i) vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_v, pl.v_off[i] + v_stage_off, 0, 0);
 }
 
 // Registers -> LDS stage buffer (rows past the last key arrive as zeros from the buffer load).
 template <int DT, int KPT, int VPT>
-__device__ __forceinline__ void stage_store(const u32x4 (&kreg)[KPT], const u32x4 (&vreg)[VPT][4],
+__device__ __forceinline__ void stage_store(const u32x4 (&kreg)[KPT], const u32x4 (&vreg)[VPT],
                                             const StagePlan<KPT, VPT> &pl, char *buf) {
-    typedef VTile<DT> VT;
 #pragma unroll
     for (int i = 0; i < KPT; ++i)
         if (pl.k_ok[i]) *reinterpret_cast<u32x4 *>(buf + pl.k_lds[i]) = kreg[i];
 #pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-        if (pl.v_ok[i]) {   // 4 keys x 8 d -> eight 8-byte writes of (4 keys) at consecutive d rows
-            char *dst = buf + pl.v_lds[i];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                u32x2 w;   // element j of four consecutive keys: one v_perm_b32 per output word
-                const unsigned sel = (j & 1) ? 0x07060302u : 0x05040100u;
-                w[0] = __builtin_amdgcn_perm(vreg[i][1][j >> 1], vreg[i][0][j >> 1], sel);
-                w[1] = __builtin_amdgcn_perm(vreg[i][3][j >> 1], vreg[i][2][j >> 1], sel);
-                *reinterpret_cast<u32x2 *>(dst + j * VT::STRIDE) = w;
-            }
-        }
-    }
+    for (int i = 0; i < VPT; ++i)
+        if (pl.v_ok[i]) *reinterpret_cast<u32x4 *>(buf + pl.v_lds[i]) = vreg[i];
 }
 
 // Resource descriptor over one head's K or V rows: [base, base + (M-1)*row_stride + D) elements of T.
@@ -158,7 +166,7 @@ template <int DT, int NW, bool HAS_BIAS> struct MinWaves {
 
 // One KV tile: scores -> (bias) -> online softmax -> PV. MASKED tiles (only the last one can be)
 // additionally kill keys >= M; full tiles skip every key compare.
-// ROWSUM_MFMA: the head dim is not a multiple of 32, so the V^T tile has padding rows; row D holds
+// ROWSUM_MFMA: the head dim is not a multiple of 32, so the V tile has padding columns; column D holds
 // ones and the PV MFMA accumulates the softmax denominator there for free (no per-element adds).
 // Bias addressing for one lane: a buffer descriptor over this (b, h) slice of the bias, the byte offset of the
 // lane's query row (>= 2^31, i.e. out of range -> zeros, for rows past N) and the key stride in bytes. With a unit
@@ -191,7 +199,7 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
                                                 int key0, int M, int l31, int hi, const BiasRef &bias,
                                                 float coeff, float c1) {
     typedef typename Vec<T>::v8 V8;
-    typedef VTile<DT> VT;
+    const char *vl = Vs + vfrag_lane_off<DT>(hi * 32 + l31);
 
     // raw-domain logits x = s + c*bias (scale > 0, so the row max commutes with the scaling)
     // (a 4-way max tree and packed v_pk_fma_f32 for the exp arguments were measured: neutral to -3%)
@@ -268,10 +276,9 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
         if (!MASKED || key0 + kb * 32 < M) {
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
-                const char *vbase = Vs + l31 * VT::STRIDE + (kb * 32 + k2 * 16 + hi * 8) * 2;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const V8 vf = *reinterpret_cast<const V8 *>(vbase + dt * 32 * VT::STRIDE);
+                    const V8 vf = load_vfrag<T, DT>(vl, kb, k2, dt);
                     oacc[dt] = mfma32(vf, pf[kb][k2], oacc[dt]);
                 }
             }
@@ -291,11 +298,11 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
     typedef VTile<DT> VT;
     static_assert(KG == 1 || NSUB == KG, "key-split workgroups process one sub-tile per key group");
     constexpr int NT = NW * KG * 64;
-    constexpr int SUB_BYTES = KT::BYTES + VT::BYTES;     // one 64-key sub-tile: K rows, then V^T rows
+    constexpr int SUB_BYTES = KT::BYTES + VT::BYTES;     // one 64-key sub-tile: K rows, then V rows
     constexpr int STAGE_BYTES = NSUB * SUB_BYTES;
     constexpr int STAGE_KEYS = NSUB * KVBLK;
     constexpr int KPT = (NSUB * KT::NCHUNK + NT - 1) / NT;
-    constexpr int VPT = (NSUB * VT::NUNIT + NT - 1) / NT;
+    constexpr int VPT = (NSUB * VT::NCHUNK + NT - 1) / NT;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];   // two stage buffers (double buffering)
 
@@ -339,14 +346,14 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
     float m_run = -INFINITY;  // running row max of the raw logits, identical in both half-waves
     float l_run = 0.f;        // running row sum (VALU path only), PARTIAL per half-wave
 
-    // V^T rows of the head-dim padding are never staged: zero both buffers once; with ROWSUM_MFMA row D
-    // of every V^T tile is all ones (the PV MFMA then accumulates the softmax denominator in O^T row D)
+    // head-dim padding columns are never staged: zero both buffers once; with ROWSUM_MFMA column D of every
+    // V row is one (the PV MFMA then accumulates the softmax denominator in O^T row D)
     for (int i = tid * 16; i < 2 * STAGE_BYTES; i += NT * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
     if (ROWSUM_MFMA) {
         const T one = (T)1.0f;
         for (int i = tid; i < 2 * NSUB * KVBLK; i += NT)
-            *reinterpret_cast<T *>(smem + (i >> 6) * SUB_BYTES + KT::BYTES + p.D * VT::STRIDE + (i & 63) * 2) = one;
+            *reinterpret_cast<T *>(smem + (i >> 6) * SUB_BYTES + KT::BYTES + (i & 63) * VT::STRIDE + p.D * 2) = one;
     }
 
     StagePlan<KPT, VPT> plan;
@@ -355,7 +362,7 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
     const auto srd_v = head_srd(Vp, p.M, p.v_sm, p.D);
     const unsigned k_step = (unsigned)(STAGE_KEYS * p.k_sm * 2), v_step = (unsigned)(STAGE_KEYS * p.v_sm * 2);   // bytes per stage
     u32x4 kreg[KPT];
-    u32x4 vreg[VPT][4];
+    u32x4 vreg[VPT];
     const int nstage = (p.M + STAGE_KEYS - 1) / STAGE_KEYS;
     const int nfull = p.M / STAGE_KEYS;                 // stages without any key >= M
 
@@ -481,7 +488,7 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
 //     x = (q.k) scale log2(e) - m_ref directly -- no per-score subtract/multiply (32 v_fma per 64-key tile).
 //   * m_ref is a LAZY reference, not the exact running max: it is only raised (and O^T rescaled) when a score
 //     exceeds it by more than 2^FOLD_TAU; until then P = exp2(x) <= 2^FOLD_TAU is harmless in f16/bf16 and the
-//     final division by the row sum (accumulated from the same P by the ones row of V^T) makes the result
+//     final division by the row sum (accumulated from the same P by the ones column of V) makes the result
 //     independent of the reference. m_ref is always exactly representable in T, so the folded column is exact.
 //   * both 64-key sub-tiles of a stage are scored before one joint max / (rare) re-reference, so the exp / convert
 //     work of one sub-tile has independent MFMAs (scores of the other, PV of the previous) to run beside.
@@ -522,7 +529,7 @@ template <typename T, int DT, bool MASKED>
 __device__ __forceinline__ void fold_exp_pv(const f32x16 (&s)[2], f32x16 (&oacc)[DT], const char *Vs, int key0, int M,
                                             int l31, int hi) {
     typedef typename Vec<T>::v8 V8;
-    typedef VTile<DT> VT;
+    const char *vl = Vs + vfrag_lane_off<DT>(hi * 32 + l31);
     V8 pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -533,10 +540,9 @@ __device__ __forceinline__ void fold_exp_pv(const f32x16 (&s)[2], f32x16 (&oacc)
         if (!MASKED || key0 + kb * 32 < M) {
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
-                const char *vbase = Vs + l31 * VT::STRIDE + (kb * 32 + k2 * 16 + hi * 8) * 2;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const V8 vf = *reinterpret_cast<const V8 *>(vbase + dt * 32 * VT::STRIDE);
+                    const V8 vf = load_vfrag<T, DT>(vl, kb, k2, dt);
                     oacc[dt] = mfma32(vf, pf[kb][k2], oacc[dt]);
                 }
             }
@@ -590,16 +596,13 @@ __device__ __forceinline__ void load_kfrags(typename Vec<T>::v8 (&kf)[2][KS], co
 
 template <typename T, int DT>
 __device__ __forceinline__ void load_vfrags(typename Vec<T>::v8 (&vf)[2][2][DT], const char *Vs, int l31, int hi) {
-    typedef typename Vec<T>::v8 V8;
-    typedef VTile<DT> VT;
-    const char *base = Vs + l31 * VT::STRIDE + hi * 16;
+    const char *vl = Vs + vfrag_lane_off<DT>(hi * 32 + l31);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-                vf[kb][k2][dt] = *reinterpret_cast<const V8 *>(base + (kb * 32 + k2 * 16) * 2 + dt * 32 * VT::STRIDE);
+            for (int dt = 0; dt < DT; ++dt) vf[kb][k2][dt] = load_vfrag<T, DT>(vl, kb, k2, dt);
 }
 
 template <typename T, int KS>
@@ -663,7 +666,7 @@ __device__ __forceinline__ void fold_stage2(f32x16 (&oacc)[DT], float &mref, boo
 }
 
 template <typename T, int KS, int DT, int NW>
-__global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, false>::value)) attn_fwd_fold_kernel(const AttnParams p) {
+__global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false>::value)) attn_fwd_fold_kernel(const AttnParams p) {
     typedef typename Vec<T>::v8 V8;
     typedef typename Vec<T>::v4 V4;
     typedef KTile<KS> KT;
@@ -674,7 +677,7 @@ __global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, false>::value)) att
     constexpr int STAGE_BYTES = NSUB * SUB_BYTES;
     constexpr int STAGE_KEYS = NSUB * KVBLK;
     constexpr int KPT = (NSUB * KT::NCHUNK + NT - 1) / NT;
-    constexpr int VPT = (NSUB * VT::NUNIT + NT - 1) / NT;
+    constexpr int VPT = (NSUB * VT::NCHUNK + NT - 1) / NT;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];   // two stage buffers (double buffering)
 
@@ -711,14 +714,14 @@ __global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, false>::value)) att
     float mref = 0.f;      // softmax reference of the lane's row (exp2 domain), identical in both half-waves
     bool first = true;     // no tile processed yet: m_ref not established
 
-    // padding is never staged: zero both buffers once, then row D of every V^T tile = ones (softmax denominator
+    // padding is never staged: zero both buffers once, then column D of every V row = one (softmax denominator
     // from the PV MFMA) and column D of every K row = one (the folded -m_ref term of the score MFMA)
     for (int i = tid * 16; i < 2 * STAGE_BYTES; i += NT * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
     {
         const T one = (T)1.0f;
         for (int i = tid; i < 2 * NSUB * KVBLK; i += NT) {
-            *reinterpret_cast<T *>(smem + (i >> 6) * SUB_BYTES + KT::BYTES + p.D * VT::STRIDE + (i & 63) * 2) = one;
+            *reinterpret_cast<T *>(smem + (i >> 6) * SUB_BYTES + KT::BYTES + (i & 63) * VT::STRIDE + p.D * 2) = one;
             *reinterpret_cast<T *>(smem + (i >> 6) * SUB_BYTES + (i & 63) * KT::STRIDE + p.D * 2) = one;
         }
     }
@@ -729,7 +732,7 @@ __global__ void __launch_bounds__(NW * 64, (MinWaves<DT, NW, false>::value)) att
     const auto srd_v = head_srd(Vp, p.M, p.v_sm, p.D);
     const unsigned k_step = (unsigned)(STAGE_KEYS * p.k_sm * 2), v_step = (unsigned)(STAGE_KEYS * p.v_sm * 2);
     u32x4 kreg[KPT];
-    u32x4 vreg[VPT][4];
+    u32x4 vreg[VPT];
     const int nstage = (p.M + STAGE_KEYS - 1) / STAGE_KEYS;
     const int nfull = p.M / STAGE_KEYS;
 
@@ -797,7 +800,7 @@ static int launch_attn_rs(const AttnParams &p, hipStream_t stream) {
     // for two workgroups per CU; the widest heads use single sub-tile stages
     // (an 8-wave workgroup owns its CU alone, so it can spend the LDS on 256-key stages: PWW_ATTN_NSUB4)
     constexpr int SUBB = KTile<KS>::BYTES + VTile<DT>::BYTES;
-    constexpr int NSUB = (2 * 2 * SUBB <= 72 * 1024) ? 2 : 1;   // (256-key stages for NW == 8 measured no faster)
+    constexpr int NSUB = (2 * 2 * SUBB <= 80 * 1024) ? 2 : 1;   // (256-key stages for NW == 8 measured no faster)
     constexpr size_t lds = 2 * NSUB * (KTile<KS>::BYTES + VTile<DT>::BYTES);
     const int qblocks = (p.N + NW * 32 - 1) / (NW * 32);
     const dim3 grid((unsigned)(qblocks * p.B * p.H));
