@@ -171,7 +171,8 @@ static void run_case(const Case &c, bool timing) {
         float ms2 = 0; HIPCHECK(hipEventElapsedTime(&ms2, e0, e1));
         printf("TIME %-28s attn %.2f us/call  %.1f TFLOP/s (algorithmic 4BHNMD) | qk_reduce %.2f us/call\n", c.name, us, flops / us * 1e-6, ms2 * 1e3 / iters);
     }
-    (void)hipFree(dws); hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dout); hipFree(dstats); if (dbias) hipFree(dbias); if (dcoeff) hipFree(dcoeff);
+    for (void *ptr : {(void *)dws, (void *)dq, (void *)dk, (void *)dv, (void *)dout, (void *)dstats, (void *)dbias, (void *)dcoeff})
+        if (ptr) (void)hipFree(ptr);
 }
 
 // ---- mask build ------------------------------------------------------------------------------
@@ -256,7 +257,7 @@ static void check_errors() {
     const bool ok = rc1 == PWW_ENOTSUP && rc2 == PWW_ENOTSUP && rc3 == PWW_EINVAL && rc4 == PWW_ENOTSUP && strlen(pww_last_error()) > 0;
     printf("%s error codes: %d %d %d %d last='%s'\n", ok ? "PASS" : "FAIL", rc1, rc2, rc3, rc4, pww_last_error());
     if (!ok) g_fail++;
-    hipFree(p);
+    (void)hipFree(p);
 }
 
 int main(int argc, char **argv) {
