@@ -161,7 +161,7 @@ __device__ __forceinline__ float xhalf_max(float x) {
 // Waves per SIMD the register allocator must leave room for (2 => <= 256 VGPRs+AGPRs). The bias
 // variants (32 extra loads in flight per tile) and the widest heads keep the whole 512-entry file.
 template <int DT, int NW, bool HAS_BIAS> struct MinWaves {
-    static constexpr int value = (DT >= 4 || (NW == 2 && DT >= 3) || (HAS_BIAS && DT >= 3)) ? 1 : (NW == 8 ? 1 : 2);
+    static constexpr int value = (DT >= 4 || (NW == 2 && DT >= 3) || (HAS_BIAS && DT >= 3)) ? 1 : 2;   // (an 8-wave workgroup needs 2 waves per SIMD to fit at all)
 };
 
 // One KV tile: scores -> (bias) -> online softmax -> PV. MASKED tiles (only the last one can be)
