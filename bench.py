@@ -91,10 +91,10 @@ class EventTimer:
         return out
 
     def wrap_attention(self, fn):
-        def wrapped(q, k, v, heads, scale, bias=None, bias_coeff=None):
+        def wrapped(q, k, v, heads, scale, bias=None, **kw):
             key = ("cross" if bias is not None else ("self" if k.shape[1] == q.shape[1] else "cross-nobias"),
                    q.shape[0], q.shape[1], k.shape[1], q.shape[2] // heads, heads, k.shape[0])
-            return self._timed(key, fn, (q, k, v, heads, scale), dict(bias=bias, bias_coeff=bias_coeff))
+            return self._timed(key, fn, (q, k, v, heads, scale), dict(bias=bias, **kw))
         return wrapped
 
     def wrap_stats(self, fn):

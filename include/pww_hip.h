@@ -12,6 +12,7 @@
  *                        (same, plus the `+ cross_attention_weight` term of :112)
  *   pww_qk_reduce        the global reductions weight_function applies to `qk`
  *                        (paint_with_words.py:402-405 qk.max(); README.md:152 qk.std())
+ *   pww_cross_attn_fwd_stat  pww_cross_attn_fwd with `c0 * g(sigma) * reduce(qk)` formed in the kernel
  *   pww_mask_build       paint_with_words/paint_with_words.py:207-276
  *                        (_image_context_seperator + _tokens_img_attention_weight +
  *                         _img_importance_flatten for ratios 8/16/32/64)
@@ -104,6 +105,29 @@ int pww_self_attn_fwd(const void *q, const void *k, const void *v, void *o,
 int pww_cross_attn_fwd(const void *q, const void *k, const void *v, void *o,
                        const float *bias, const float *bias_coeff,
                        const pww_attn_desc_t *desc, void *stream);
+
+/* Which statistic of pww_qk_reduce's stats[b][4] scales the bias in pww_cross_attn_fwd_stat. */
+#define PWW_STAT_NONE 0   /* 1.0 */
+#define PWW_STAT_MAX 1    /* qk.max()                       (paint_with_words.py:402-405, runner.py:104) */
+#define PWW_STAT_MIN 2    /* qk.min() */
+#define PWW_STAT_MEAN 3   /* qk.mean()  = sum / count */
+#define PWW_STAT_STD 4    /* qk.std()   = unbiased, like torch.std (README.md:152) */
+#define PWW_STAT_ABSMAX 5 /* qk.abs().max() */
+
+/*
+ * pww_cross_attn_fwd with the per-image bias coefficient formed INSIDE the kernel:
+ *   c[b] = coeff_scalar * stat(stats[b]) * (gate ? gate[b] : 1)
+ * i.e. the whole of `c0 * g(sigma) * qk.max()` (or .std() ...) times the CFG row gate, without the three or four
+ * [B]-sized elementwise launches the host would otherwise spend per cross-attention layer and step.
+ *   stats       double [B][4] as written by pww_qk_reduce for the same q/k (device pointer; NULL only with
+ *               stat_kind == PWW_STAT_NONE)
+ *   stat_count  number of score elements per image (H*N*M), used by MEAN / STD
+ *   gate        fp32 [B] device array or NULL
+ * The products are taken in fp32 in the order written above (the same values the host path produces).
+ */
+int pww_cross_attn_fwd_stat(const void *q, const void *k, const void *v, void *o, const float *bias,
+                            const double *stats, int32_t stat_kind, double stat_count, float coeff_scalar,
+                            const float *gate, const pww_attn_desc_t *desc, void *stream);
 
 /*
  * Per-image global statistics of the raw score tensor S = Q K^T over all heads, rows and keys

@@ -47,7 +47,8 @@ bool arch_ok() {
 }
 
 int attn_fwd(const void *q, const void *k, const void *v, void *o, const float *bias, const float *bias_coeff,
-             const pww_attn_desc_t *d, hipStream_t stream);
+             const pww_attn_desc_t *d, hipStream_t stream, const double *stats = nullptr, int stat_kind = PWW_STAT_NONE,
+             double stat_count = 1.0, float coeff_scalar = 1.f);
 int qk_reduce(const void *q, const void *k, const pww_attn_desc_t *d, double *stats, void *workspace,
               size_t workspace_bytes, hipStream_t stream);
 size_t qk_reduce_workspace_bytes(const pww_attn_desc_t *d);
@@ -81,6 +82,13 @@ int pww_self_attn_fwd(const void *q, const void *k, const void *v, void *o, cons
 int pww_cross_attn_fwd(const void *q, const void *k, const void *v, void *o, const float *bias,
                        const float *bias_coeff, const pww_attn_desc_t *desc, void *stream) {
     return pww::attn_fwd(q, k, v, o, bias, bias_coeff, desc, static_cast<hipStream_t>(stream));
+}
+
+int pww_cross_attn_fwd_stat(const void *q, const void *k, const void *v, void *o, const float *bias,
+                            const double *stats, int32_t stat_kind, double stat_count, float coeff_scalar,
+                            const float *gate, const pww_attn_desc_t *desc, void *stream) {
+    return pww::attn_fwd(q, k, v, o, bias, gate, desc, static_cast<hipStream_t>(stream), stats, stat_kind, stat_count,
+                         coeff_scalar);
 }
 
 int pww_qk_reduce(const void *q, const void *k, const pww_attn_desc_t *desc, double *stats, void *workspace,

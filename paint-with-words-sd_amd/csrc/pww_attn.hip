@@ -36,7 +36,36 @@ struct AttnParams {
     long o_sb, o_sh, o_sn;
     long b_sb, b_sh, b_sn, b_sm;
     float scale_log2e;  // scale * log2(e): softmax runs in the exp2 domain
+    const double *stats;   // optional [B][4] from qk_reduce: the per-image coefficient is formed here
+    int stat_kind;
+    double stat_count;
+    float coeff_scalar;
 };
+
+// c[b] = coeff_scalar * stat(stats[b]) * gate[b]   (fp32 products in this order: what the host's elementwise ops gave)
+__device__ __forceinline__ float bias_coefficient(const AttnParams &p, int b) {
+    float c = p.coeff_scalar;
+    if (p.stat_kind != PWW_STAT_NONE) {
+        const double *st = p.stats + (long)b * 4;
+        double v;
+        switch (p.stat_kind) {
+            case PWW_STAT_MAX: v = st[0]; break;
+            case PWW_STAT_MIN: v = st[1]; break;
+            case PWW_STAT_MEAN: v = st[2] / p.stat_count; break;
+            case PWW_STAT_ABSMAX: v = fmax(fabs(st[0]), fabs(st[1])); break;
+            default: {   // PWW_STAT_STD: unbiased, from sum and sum of squares in fp64
+                const double n = p.stat_count;
+                const double var = (st[3] - st[2] * st[2] / n) / (n > 1.0 ? n - 1.0 : 1.0);
+                v = var > 0.0 ? var : 0.0;
+            }
+        }
+        float f = (float)v;
+        if (p.stat_kind == PWW_STAT_STD) f = sqrtf(f);
+        c = c * f;
+    }
+    if (p.bias_coeff) c = c * p.bias_coeff[b];
+    return c;
+}
 
 // V tile as staged in LDS: ROW-MAJOR like K, [64 keys][DT*32 d], and transposed by the READ: gfx950's
 // ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a 4-row x 16-column block whose rows are supplied,
@@ -334,7 +363,7 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
         bias.row_off = qvalid ? (unsigned)((long)qrow * p.b_sn * 4) : OOB_OFF;
         bias.key_stride = (unsigned)(p.b_sm * 4);
         bias.unit = p.b_sm == 1;
-        if (p.bias_coeff) coeff = p.bias_coeff[b];
+        coeff = bias_coefficient(p, b);
     }
     const float c1 = p.scale_log2e;
 
@@ -934,7 +963,8 @@ template <typename T> static int dispatch_nw(const AttnParams &p, hipStream_t s)
 static bool aligned16(const void *ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
 
 int attn_fwd(const void *q, const void *k, const void *v, void *o, const float *bias,
-             const float *bias_coeff, const pww_attn_desc_t *d, hipStream_t stream) {
+             const float *bias_coeff, const pww_attn_desc_t *d, hipStream_t stream,
+             const double *stats, int stat_kind, double stat_count, float coeff_scalar) {
     if (!d || !q || !k || !v || !o) { set_error("attn_fwd: null argument"); return PWW_EINVAL; }
     if (d->B <= 0 || d->H <= 0 || d->N <= 0 || d->M <= 0 || d->D <= 0) {
         set_error("attn_fwd: non-positive dimension (B=%d H=%d N=%d M=%d D=%d)", d->B, d->H, d->N, d->M, d->D);
@@ -977,6 +1007,12 @@ int attn_fwd(const void *q, const void *k, const void *v, void *o, const float *
     p.o_sb = d->o_stride[0]; p.o_sh = d->o_stride[1]; p.o_sn = d->o_stride[2];
     p.b_sb = d->bias_stride[0]; p.b_sh = d->bias_stride[1]; p.b_sn = d->bias_stride[2]; p.b_sm = d->bias_stride[3];
     p.scale_log2e = d->scale * 1.4426950408889634f;
+    if (stat_kind < PWW_STAT_NONE || stat_kind > PWW_STAT_ABSMAX || (stat_kind != PWW_STAT_NONE && (!stats || !bias))) {
+        set_error("attn_fwd: bad statistic selector %d (or missing stats / bias pointer)", stat_kind);
+        return PWW_EINVAL;
+    }
+    p.stats = bias ? stats : nullptr; p.stat_kind = bias ? stat_kind : PWW_STAT_NONE; p.stat_count = stat_count;
+    p.coeff_scalar = coeff_scalar;
     return d->dtype == PWW_DTYPE_F16 ? dispatch_nw<f16>(p, stream) : dispatch_nw<bf16>(p, stream);
 }
 

@@ -32,6 +32,89 @@ def _warn_once(key, msg):
         warnings.warn(msg, stacklevel=3)
 
 
+class LazyStat:
+    """``scale * reduce(qk)`` as handed back by QKProxy.max() / .min() / .mean() / .std() / .abs().max().
+
+    All the shipped weight functions only ever MULTIPLY this by Python numbers and by the weight map, so the value is
+    kept symbolic: (statistics tensor of pww_qk_reduce, which statistic, Python scale). If it reaches the kernel that
+    way (through ScaledW), the kernel forms the coefficient itself (pww_cross_attn_fwd_stat) and the three or four
+    [B]-sized elementwise launches per cross-attention layer and step disappear. Any other use -- arithmetic with
+    tensors, torch functions, .item(), comparison ... -- materialises the [B,1,1,1] / 0-dim fp32 tensor the old path
+    produced and carries on with it, unchanged."""
+    __slots__ = ("_proxy", "kind", "scale", "_t")
+
+    def __init__(self, proxy, kind, scale=1.0):
+        self._proxy, self.kind, self.scale, self._t = proxy, kind, scale, None
+
+    def stats(self):
+        return self._proxy._st()
+
+    def materialize(self):
+        if self._t is None:
+            st, n = self._proxy._st(), self._proxy._count()
+            if self.kind == ops.STAT_MAX:
+                t = st[:, 0]
+            elif self.kind == ops.STAT_MIN:
+                t = st[:, 1]
+            elif self.kind == ops.STAT_MEAN:
+                t = st[:, 2] / n
+            elif self.kind == ops.STAT_ABSMAX:
+                t = torch.maximum(st[:, 0].abs(), st[:, 1].abs())
+            else:   # STAT_STD: unbiased, like torch.std
+                t = ((st[:, 3] - st[:, 2] * st[:, 2] / n) / max(n - 1, 1)).clamp_min(0)
+            t = self._proxy._shape_out(t)
+            if self.kind == ops.STAT_STD:
+                t = t.sqrt()
+            self._t = t if self.scale == 1.0 else t * self.scale
+        return self._t
+
+    def _times(self, other, divide=False):
+        if isinstance(other, (int, float)) and not isinstance(other, bool):
+            return LazyStat(self._proxy, self.kind, self.scale / other if divide else self.scale * other)
+        return None
+
+    def __mul__(self, other):
+        r = self._times(other)
+        if r is not None:
+            return r
+        if isinstance(other, ScaledW):
+            return other * self
+        return self.materialize() * other
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, other):
+        r = self._times(other, divide=True)
+        return r if r is not None else self.materialize() / other
+
+    def __neg__(self):
+        return LazyStat(self._proxy, self.kind, -self.scale)
+
+    def __rtruediv__(self, other): return other / self.materialize()
+    def __add__(self, other): return self.materialize() + other
+    def __radd__(self, other): return other + self.materialize()
+    def __sub__(self, other): return self.materialize() - other
+    def __rsub__(self, other): return other - self.materialize()
+    def __pow__(self, other): return self.materialize() ** other
+    def __float__(self): return float(self.materialize())
+    def __bool__(self): return bool(self.materialize())
+    def __lt__(self, other): return self.materialize() < other
+    def __le__(self, other): return self.materialize() <= other
+    def __gt__(self, other): return self.materialize() > other
+    def __ge__(self, other): return self.materialize() >= other
+    def __getitem__(self, idx): return self.materialize()[idx]
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        conv = lambda a: a.materialize() if isinstance(a, LazyStat) else a  # noqa: E731
+        return func(*[conv(a) for a in args], **{k: conv(v) for k, v in (kwargs or {}).items()})
+
+
 class QKProxy:
     """Stands in for the raw score tensor ``qk = Q K^T`` ([B*heads, N, M]) that the reference hands
     to ``weight_function`` (:87, :106). Global reductions -- all the shipped weight functions use
@@ -68,12 +151,12 @@ class QKProxy:
     def max(self, *args, **kw):
         if args or kw:
             return self._materialize().max(*args, **kw)
-        return self._shape_out(self._st()[:, 0])
+        return LazyStat(self, ops.STAT_MAX)
 
     def min(self, *args, **kw):
         if args or kw:
             return self._materialize().min(*args, **kw)
-        return self._shape_out(self._st()[:, 1])
+        return LazyStat(self, ops.STAT_MIN)
 
     def sum(self, *args, **kw):
         if args or kw:
@@ -83,7 +166,7 @@ class QKProxy:
     def mean(self, *args, **kw):
         if args or kw:
             return self._materialize().mean(*args, **kw)
-        return self._shape_out(self._st()[:, 2] / self._count())
+        return LazyStat(self, ops.STAT_MEAN)
 
     def var(self, *args, **kw):
         if args or kw:
@@ -95,7 +178,7 @@ class QKProxy:
     def std(self, *args, **kw):
         if args or kw:
             return self._materialize().std(*args, **kw)
-        return self.var().sqrt()
+        return LazyStat(self, ops.STAT_STD)
 
     def abs(self):
         return _AbsQK(self)
@@ -172,8 +255,7 @@ class _AbsQK:
         self._p = proxy
 
     def max(self):
-        st = self._p._st()
-        return self._p._shape_out(torch.maximum(st[:, 0].abs(), st[:, 1].abs()))
+        return LazyStat(self._p, ops.STAT_ABSMAX)
 
     def __getattr__(self, name):
         return getattr(self._p._materialize().abs(), name)
@@ -189,10 +271,10 @@ class ScaledW:
     launches per cross-attention layer and step saved). Any other use -- addition, indexing, torch functions,
     attribute access -- materialises the real tensor and the computation continues on it, unchanged.
     """
-    __slots__ = ("w", "coeff")
+    __slots__ = ("w", "coeff", "stat")
 
-    def __init__(self, w, coeff=1.0):
-        self.w, self.coeff = w, coeff
+    def __init__(self, w, coeff=1.0, stat=None):
+        self.w, self.coeff, self.stat = w, coeff, stat      # value = w * coeff * (stat if stat is not None else 1)
 
     @staticmethod
     def _is_factor(x):
@@ -201,12 +283,18 @@ class ScaledW:
         return torch.is_tensor(x) and (x.dim() == 0 or (x.dim() == 4 and x.shape[1:] == (1, 1, 1)))
 
     def _scaled(self, factor, divide=False):
+        if isinstance(factor, LazyStat):
+            if not divide and self.stat is None and not torch.is_tensor(self.coeff):
+                return ScaledW(self.w, self.coeff, factor)       # stays symbolic: the kernel forms the product
+            factor = factor.materialize()
         if not self._is_factor(factor):
             return None
         if torch.is_tensor(factor):
             factor = factor.to(torch.float32)
+            if self.stat is not None:                            # a second tensor factor: fall back to tensors
+                return ScaledW(self.w, self.coeff * self.stat.materialize(), None)._scaled(factor, divide)
         c = self.coeff / factor if divide else self.coeff * factor
-        return ScaledW(self.w, c)
+        return ScaledW(self.w, c, self.stat)
 
     def __mul__(self, other):
         r = self._scaled(other)
@@ -219,10 +307,11 @@ class ScaledW:
         return r if r is not None else self.materialize() / other
 
     def __neg__(self):
-        return ScaledW(self.w, -self.coeff if not torch.is_tensor(self.coeff) else -self.coeff)
+        return ScaledW(self.w, -self.coeff, self.stat)
 
     def materialize(self):
-        return self.w * self.coeff
+        c = self.coeff if self.stat is None else self.coeff * self.stat.materialize()
+        return self.w * c
 
     # everything else behaves like the tensor it stands for
     def __add__(self, other): return self.materialize() + other
@@ -357,7 +446,16 @@ def pww_attention(attn, hidden_states, context=None):
         bias = f(lazy_w, context["SIGMA"], QKProxy(query, key, attn.heads))
 
     coeff = None
-    if isinstance(bias, ScaledW):      # coeff * w: keep the map, pass the coefficient to the kernel
+    stat = None
+    if isinstance(bias, LazyStat):     # a bare statistic: a per-image constant on every logit of a row cancels in softmax
+        bias = None
+    if isinstance(bias, ScaledW) and bias.stat is not None and not torch.is_tensor(bias.coeff) and torch.is_tensor(bias.w):
+        # c0 * w * g(sigma) * reduce(qk): map, statistics and Python scalar go to the kernel as they are
+        stat = (bias.stat.stats(), bias.stat.kind, float(bias.coeff) * float(bias.stat.scale))
+        bias = bias.w
+    elif isinstance(bias, ScaledW):    # coeff * w: keep the map, pass the coefficient to the kernel
+        if bias.stat is not None:
+            bias = ScaledW(bias.w, bias.coeff * bias.stat.materialize())
         c = bias.coeff
         B = query.shape[0]
         if torch.is_tensor(c):
@@ -375,7 +473,8 @@ def pww_attention(attn, hidden_states, context=None):
         # python scalar / 0-dim tensor: a constant added to every logit of a row cancels in softmax
         # (the unconditional pass returns 0.0, :493)
         bias = None
-    return ops.attention(query, key, value, attn.heads, attn.scale, bias=bias, bias_coeff=gate if bias is not None else None)
+    return ops.attention(query, key, value, attn.heads, attn.scale, bias=bias, bias_coeff=gate if bias is not None else None,
+                         stat=stat if bias is not None else None)
 
 
 def inj_forward(self, hidden_states, context=None, mask=None):

@@ -67,10 +67,15 @@ def _prep(t):
     return t if _rows_ok(t) else t.contiguous()
 
 
-def attention(q, k, v, heads, scale, bias=None, bias_coeff=None):
+STAT_NONE, STAT_MAX, STAT_MIN, STAT_MEAN, STAT_STD, STAT_ABSMAX = 0, 1, 2, 3, 4, 5   # PWW_STAT_* of include/pww_hip.h
+
+
+def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None):
     """softmax((Q K^T + c * bias) * scale) V on [B, tokens, heads*D] tensors (diffusers layout, no
     head-split copies). bias: fp32 tensor broadcastable to [B, heads, N, M] or None;
-    bias_coeff: optional fp32 [B] device tensor of per-image coefficients."""
+    bias_coeff: optional fp32 [B] device tensor of per-image coefficients (with `stat`: the row gate);
+    stat: optional (stats [B,4] float64 from qk_stats, STAT_* kind, python scalar) -- the kernel then forms
+    c[b] = scalar * stat(stats[b]) * bias_coeff[b] itself (pww_cross_attn_fwd_stat)."""
     _require_gpu(q, k, v, bias, bias_coeff)
     if not (q.dtype == k.dtype == v.dtype):
         raise PwwHipError("q/k/v dtypes differ: %s %s %s" % (q.dtype, k.dtype, v.dtype))
@@ -97,9 +102,17 @@ def attention(q, k, v, heads, scale, bias=None, bias_coeff=None):
                     bias_coeff = bias_coeff.expand(B).contiguous()
                 if bias_coeff.numel() != B:
                     raise PwwHipError("bias_coeff must have B=%d elements" % B)
-            rc = lib.pww_cross_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(bias), _ptr(bias_coeff),
-                                        ctypes.byref(d), _stream())
-            _lib.check(rc, "pww_cross_attn_fwd")
+            if stat is not None:
+                stats, kind, scalar = stat
+                if stats.dtype != torch.float64 or tuple(stats.shape) != (B, 4) or not stats.is_contiguous():
+                    raise PwwHipError("stat: stats must be a contiguous float64 [B, 4] tensor")
+                rc = lib.pww_cross_attn_fwd_stat(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(bias), _ptr(stats), int(kind),
+                                                 float(heads * N * M), float(scalar), _ptr(bias_coeff), ctypes.byref(d), _stream())
+                _lib.check(rc, "pww_cross_attn_fwd_stat")
+            else:
+                rc = lib.pww_cross_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(bias), _ptr(bias_coeff),
+                                            ctypes.byref(d), _stream())
+                _lib.check(rc, "pww_cross_attn_fwd")
     return out
 
 

@@ -87,6 +87,41 @@ static void run_case(const Case &c, bool timing) {
     HIPCHECK(hipMemcpy(out.data(), dout, out.size() * 2, hipMemcpyDeviceToHost));
     HIPCHECK(hipMemcpy(stats.data(), dstats, stats.size() * 8, hipMemcpyDeviceToHost));
 
+    // pww_cross_attn_fwd_stat: coefficient formed in the kernel from the statistics == explicit coefficient call, bit for bit
+    if (c.bias_mode == 1) {
+        const double cnt = (double)H * N * M;
+        for (int kind : {PWW_STAT_MAX, PWW_STAT_STD, PWW_STAT_ABSMAX, PWW_STAT_MEAN}) {
+            const float s0 = 0.37f;
+            std::vector<float> cexp(B);
+            for (int b = 0; b < B; ++b) {
+                const double *st = &stats[4 * b];
+                double v;
+                if (kind == PWW_STAT_MAX) v = st[0];
+                else if (kind == PWW_STAT_ABSMAX) v = std::max(fabs(st[0]), fabs(st[1]));
+                else if (kind == PWW_STAT_MEAN) v = st[2] / cnt;
+                else { v = (st[3] - st[2] * st[2] / cnt) / (cnt - 1.0); if (v < 0) v = 0; }
+                float f = (float)v;
+                if (kind == PWW_STAT_STD) f = sqrtf(f);
+                cexp[b] = (s0 * f) * coeff[b];
+            }
+            float *dce = dalloc<float>(B);
+            uint16_t *o1 = dalloc<uint16_t>(q.size()), *o2 = dalloc<uint16_t>(q.size());
+            HIPCHECK(hipMemcpy(dce, cexp.data(), B * 4, hipMemcpyHostToDevice));
+            int r1 = pww_cross_attn_fwd(dq, dk, dv, o1, dbias, dce, &d, nullptr);
+            int r2 = pww_cross_attn_fwd_stat(dq, dk, dv, o2, dbias, dstats, kind, cnt, s0, dcoeff, &d, nullptr);
+            HIPCHECK(hipDeviceSynchronize());
+            std::vector<uint16_t> h1(q.size()), h2(q.size());
+            HIPCHECK(hipMemcpy(h1.data(), o1, h1.size() * 2, hipMemcpyDeviceToHost));
+            HIPCHECK(hipMemcpy(h2.data(), o2, h2.size() * 2, hipMemcpyDeviceToHost));
+            long diff = 0;
+            for (size_t i = 0; i < h1.size(); ++i) diff += h1[i] != h2[i];
+            const bool ok = r1 == 0 && r2 == 0 && diff == 0;
+            printf("%s %-28s stat-coefficient kind=%d: %ld differing elements vs explicit coefficient (rc %d %d)\n", ok ? "PASS" : "FAIL", c.name, kind, diff, r1, r2);
+            if (!ok) g_fail++;
+            (void)hipFree(dce); (void)hipFree(o1); (void)hipFree(o2);
+        }
+    }
+
     // fp64 reference on sampled rows: O = softmax((QK^T + c*bias) * scale) V
     double max_err = 0, max_ref = 0; long nchk = 0; int nan_count = 0;
     std::vector<double> logit(M), ref(D);

@@ -145,6 +145,36 @@ def test_qk_proxy_reductions_with_injected_stats(monkeypatch):
     assert bias.shape == (N, M)
 
 
+def test_lazy_stat_algebra(monkeypatch):
+    """LazyStat (symbolic scale * reduce(qk)): Python factors stay symbolic and reach the kernel call as
+    (stats, kind, scalar); anything else materialises the tensor the old path produced."""
+    from pww_hip import attention as A
+    B, H, N, M, D = 2, 2, 6, 5, 8
+    q, k = torch.randn(B, N, H * D), torch.randn(B, M, H * D)
+    scores = torch.matmul(O.split_heads(q, H), O.split_heads(k, H).transpose(-1, -2)).reshape(B, -1).double()
+    monkeypatch.setattr(A.ops, "qk_stats", lambda q_, k_, h: torch.stack(
+        [scores.max(1).values, scores.min(1).values, scores.sum(1), (scores ** 2).sum(1)], 1))
+    p = A.QKProxy(q, k, H)
+    w = torch.rand(N, M)
+    for fn, kind, ref in ((cases.weight_fn_runner, A.ops.STAT_MAX, scores.max(1).values),
+                          (cases.weight_fn_std, A.ops.STAT_STD, scores.std(1))):
+        r = fn(A.ScaledW(w), torch.tensor(7.0), p)
+        assert isinstance(r, A.ScaledW) and r.w is w and isinstance(r.stat, A.LazyStat) and r.stat.kind == kind
+        want = fn(w.expand(B, 1, N, M), torch.tensor(7.0), type("Q", (), {"max": lambda s: ref.float().reshape(B, 1, 1, 1),
+                                                                          "std": lambda s: ref.float().reshape(B, 1, 1, 1)})())
+        assert torch.allclose(r.materialize(), want, rtol=1e-5)
+    s = 2.0 * p.max() / 4.0
+    assert isinstance(s, A.LazyStat) and s.scale == 0.5
+    assert torch.allclose(s.materialize().flatten(), 0.5 * scores.max(1).values.float())
+    assert isinstance(-p.min(), A.LazyStat) and torch.allclose((-p.min()).materialize().flatten(), -scores.min(1).values.float())
+    # tensor arithmetic, torch functions and comparisons fall back to real tensors
+    assert torch.is_tensor(p.max() + 1.0) and torch.is_tensor(torch.exp(p.mean())) and torch.is_tensor(p.max() * torch.ones(1))
+    assert bool((p.max() >= p.min()).all()) and p.max().shape == (B, 1, 1, 1)
+    r2 = (A.ScaledW(w) * p.max()) * p.std()          # two statistics: second one goes through tensors
+    assert isinstance(r2, A.ScaledW) and r2.stat is None
+    assert torch.allclose(r2.materialize(), w * scores.max(1).values.float().reshape(B, 1, 1, 1) * scores.std(1).float().reshape(B, 1, 1, 1), rtol=1e-5)
+
+
 def test_scaled_w_algebra():
     """ScaledW (lazy coeff * w): scalar / per-image factors fold into the coefficient, anything else falls back to
     the real tensor with identical values."""
