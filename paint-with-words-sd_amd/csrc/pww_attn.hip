@@ -222,7 +222,7 @@ __device__ __forceinline__ void attn_tile(f32x16 (&oacc)[DT], float &m_run, floa
     attn_tile_sm_pv<T, KS, DT, HAS_BIAS, MASKED, ROWSUM_MFMA>(s, oacc, m_run, l_run, Vs, key0, M, l31, hi, bias, coeff, c1);
 }
 
-// scores (already in `s`) -> (bias) -> online softmax -> PV against the V^T tile at Vs
+// scores (already in `s`) -> (bias) -> online softmax -> PV against the V tile at Vs
 template <typename T, int KS, int DT, bool HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
 __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[DT], float &m_run, float &l_run, const char *Vs,
                                                 int key0, int M, int l31, int hi, const BiasRef &bias,
@@ -299,7 +299,7 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
     }
     if (!ROWSUM_MFMA) l_run += psum;
 
-    // O^T[d][row] += Vt[d][key] * P^T[key][row]
+    // O^T[d][row] += V^T[d][key] * P^T[key][row]   (V^T fragments come out of the transpose read)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
         if (!MASKED || key0 + kb * 32 < M) {
@@ -510,8 +510,8 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
 }
 
 // ---- folded-reference variant (head dims with D % 16 == 8: SD1.x's d = 40) -----------------------------
-// For d = 40 the kernel is bound by the VALU side of the softmax, not by the matrix pipe
-// (profiles/r01_valu_ubench.md), so this variant removes VALU work and serialisation from the tile loop:
+// A stage of this kernel costs about the SUM of its LDS, MFMA and VALU times (profiles/r01_attn_phases.md), so the
+// way to make d = 40 faster is to remove work from one of the three. This variant removes VALU work per score:
 //   * Q is pre-multiplied by scale*log2(e) once, and the head-dim padding column d = D of the K tile holds 1.0
 //     while the same column of the lane's Q fragment holds -m_ref: the score MFMA then delivers
 //     x = (q.k) scale log2(e) - m_ref directly -- no per-score subtract/multiply (32 v_fma per 64-key tile).
@@ -519,8 +519,8 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
 //     exceeds it by more than 2^FOLD_TAU; until then P = exp2(x) <= 2^FOLD_TAU is harmless in f16/bf16 and the
 //     final division by the row sum (accumulated from the same P by the ones column of V) makes the result
 //     independent of the reference. m_ref is always exactly representable in T, so the folded column is exact.
-//   * both 64-key sub-tiles of a stage are scored before one joint max / (rare) re-reference, so the exp / convert
-//     work of one sub-tile has independent MFMAs (scores of the other, PV of the previous) to run beside.
+//   * both 64-key sub-tiles of a stage are scored before one joint max / (rare) re-reference, and all MFMA operand
+//     fragments of the stage are requested from LDS up front.
 constexpr float FOLD_TAU = 6.f;
 
 template <typename T, int KS>
@@ -827,7 +827,6 @@ template <typename T, int KS, int DT, int NW, bool HAS_BIAS, bool ROWSUM_MFMA>
 static int launch_attn_rs(const AttnParams &p, hipStream_t stream) {
     // two 64-key sub-tiles per stage (one barrier per 128 keys) while the double buffer stays small enough
     // for two workgroups per CU; the widest heads use single sub-tile stages
-    // (an 8-wave workgroup owns its CU alone, so it can spend the LDS on 256-key stages: PWW_ATTN_NSUB4)
     constexpr int SUBB = KTile<KS>::BYTES + VTile<DT>::BYTES;
     constexpr int NSUB = (2 * 2 * SUBB <= 80 * 1024) ? 2 : 1;   // (256-key stages for NW == 8 measured no faster)
     constexpr size_t lds = 2 * NSUB * (KTile<KS>::BYTES + VTile<DT>::BYTES);
@@ -925,7 +924,7 @@ static int launch_attn(const AttnParams &p, hipStream_t stream) {
             return launch_attn_ksplit<T, KS, DT, 2, 2, false>(p, stream);
         }
     }
-    // head dims with padding rows in the V^T tile get the row sum from the MFMA (self-attention path)
+    // head dims with padding columns in the V tile get the row sum from the MFMA (self-attention path)
     if constexpr (!HAS_BIAS) {
         if ((p.D & 31) != 0) return launch_attn_rs<T, KS, DT, NW, false, true>(p, stream);
     }
