@@ -317,6 +317,7 @@ int main(int argc, char **argv) {
         {"sd15_cross_n4096_d40", PWW_DTYPE_BF16, 2, 8, 4096, 77, 40, 1, false, 97, 1.0f},
         {"sd15_cross_fullbias_n4096", PWW_DTYPE_F16, 1, 8, 4096, 77, 40, 2, false, 97, 1.0f},
         {"sd21_self_n2304_d64", PWW_DTYPE_BF16, 1, 10, 2304, 2304, 64, 0, true, 61, 0.8f},
+        {"sd21_self_n9216_d64_b4", PWW_DTYPE_BF16, 4, 5, 9216, 9216, 64, 0, true, 1531, 0.8f},   // BASELINE config 5: 768x768, 2 images folded
         {"d96_n200_m130", PWW_DTYPE_F16, 1, 2, 200, 130, 96, 2, false, 1, 0.6f},
         {"d128_n130_m200", PWW_DTYPE_BF16, 1, 2, 130, 200, 128, 0, false, 1, 0.6f},
         {"d48_n33_m1", PWW_DTYPE_F16, 1, 1, 33, 1, 48, 0, false, 1, 1.0f},
