@@ -266,6 +266,7 @@ def main():
 
     if os.environ.get("NCCL_DEBUG", "").upper() in ("VERSION", ""):
         os.environ["NCCL_DEBUG"] = "WARN"     # the pool exports NCCL_DEBUG=VERSION: RCCL would print a banner on stdout
+    pww_hip.enable_miopen_find()      # what the drop-in API entry points do (PWW_MIOPEN_FIND=0: PyTorch's default immediate mode)
     rank, world, local = pdist.init_from_env("cuda")
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     torch.cuda.set_device(local)

@@ -88,6 +88,7 @@ def _sampler_for(unet, scheduler, mode):
     cache = unet.__dict__.setdefault("_pww_samplers", {})
     key = (id(scheduler), mode)
     if key not in cache:
+        pww_hip.enable_miopen_find()
         cache[key] = PwWSampler(unet, scheduler, mode)
     return cache[key]
 
