@@ -175,6 +175,26 @@ def test_lazy_stat_algebra(monkeypatch):
     assert torch.allclose(r2.materialize(), w * scores.max(1).values.float().reshape(B, 1, 1, 1) * scores.std(1).float().reshape(B, 1, 1, 1), rtol=1e-5)
 
 
+def test_miopen_find_switch(monkeypatch):
+    """enable_miopen_find(): on by default, off with PWW_MIOPEN_FIND=0 (what conftest.py sets for the parity tests)."""
+    import pww_hip
+    old = torch.backends.cudnn.benchmark
+    try:
+        torch.backends.cudnn.benchmark = False
+        monkeypatch.setenv("PWW_MIOPEN_FIND", "0")
+        pww_hip.enable_miopen_find()
+        assert torch.backends.cudnn.benchmark is False
+        monkeypatch.setenv("PWW_MIOPEN_FIND", "1")
+        pww_hip.enable_miopen_find()
+        assert torch.backends.cudnn.benchmark is True
+        torch.backends.cudnn.benchmark = False
+        monkeypatch.delenv("PWW_MIOPEN_FIND")
+        pww_hip.enable_miopen_find()
+        assert torch.backends.cudnn.benchmark is True
+    finally:
+        torch.backends.cudnn.benchmark = old
+
+
 def test_scaled_w_algebra():
     """ScaledW (lazy coeff * w): scalar / per-image factors fold into the coefficient, anything else falls back to
     the real tensor with identical values."""
