@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PWW_VERSION 100 /* 0.1.0 */
+#define PWW_VERSION 110 /* 0.1.10: + pww_cross_attn_fwd_fused, pww_gauss_blur, pww_resize_tokens, pww_inpaint_prep */
 
 #define PWW_OK 0
 #define PWW_EINVAL (-22)
@@ -128,6 +128,36 @@ int pww_cross_attn_fwd(const void *q, const void *k, const void *v, void *o,
 int pww_cross_attn_fwd_stat(const void *q, const void *k, const void *v, void *o, const float *bias,
                             const double *stats, int32_t stat_kind, double stat_count, float coeff_scalar,
                             const float *gate, const pww_attn_desc_t *desc, void *stream);
+
+/*
+ * pww_qk_reduce + pww_cross_attn_fwd_stat as ONE launch, for cross-attention over at most 128 keys (the 77 prompt
+ * tokens): the cond branch of inj_forward (paint_with_words.py:87-116) for weight functions of the form
+ * c0 * w * g(sigma) * reduce(qk). Every workgroup reduces its score tiles and publishes one partial per query block
+ * in `state`; the workgroups of an image re-read those slots until none is empty, fold them (agent-scope atomics on
+ * both sides, no fence, no counter on the critical path) and carry on with bias -> softmax -> PV. Output and
+ * statistics are bit-identical to the two-launch path.
+ *   bias        fp32 map, required (desc->bias_stride)
+ *   stat_kind   PWW_STAT_*; PWW_STAT_NONE gives c[b] = coeff_scalar * gate[b] with no hand-off at all
+ *   gate        fp32 [B] device array or NULL; images with gate[b] == 0 (the unconditional rows of a CFG-folded batch)
+ *               get no bias and take no part in the reduction
+ *   stats_out   optional double [B][4] (device): { max, min, sum, sum of squares } of the gated-in images
+ *   state       device buffer of pww_cross_fused_state_bytes(desc) bytes, 8-byte aligned, owned by the caller and
+ *               ZERO before the first call. The kernel leaves it zero again (the last workgroup of an image to leave
+ *               clears the image's words), so one buffer serves any number of calls -- of any shape it is large enough
+ *               for -- issued on ONE stream, hipGraph replays included; calls that may overlap on different streams
+ *               need a buffer each. Word B*H + B is an error flag: it becomes 1 if a hand-off ever timed out (50 ms;
+ *               the affected outputs are NaN) -- re-zero the buffer then.
+ *   workspace   caller-owned scratch, pww_cross_fused_workspace_bytes(desc) bytes, 8-byte aligned, uninitialised;
+ *               only touched by the two-launch path below
+ * The launch is sized to be fully resident (<= 2 workgroups per CU, several query blocks per workgroup for large
+ * batches); if B*H alone exceeds that, the call issues the two launches instead.
+ */
+int pww_cross_attn_fwd_fused(const void *q, const void *k, const void *v, void *o, const float *bias,
+                             int32_t stat_kind, float coeff_scalar, const float *gate, const pww_attn_desc_t *desc,
+                             double *stats_out, void *state, size_t state_bytes, void *workspace, size_t workspace_bytes,
+                             void *stream);
+size_t pww_cross_fused_state_bytes(const pww_attn_desc_t *desc);
+size_t pww_cross_fused_workspace_bytes(const pww_attn_desc_t *desc);
 
 /*
  * Per-image global statistics of the raw score tensor S = Q K^T over all heads, rows and keys

@@ -52,6 +52,11 @@ int attn_fwd(const void *q, const void *k, const void *v, void *o, const float *
 int qk_reduce(const void *q, const void *k, const pww_attn_desc_t *d, double *stats, void *workspace,
               size_t workspace_bytes, hipStream_t stream);
 size_t qk_reduce_workspace_bytes(const pww_attn_desc_t *d);
+int cross_attn_fused(const void *q, const void *k, const void *v, void *o, const float *bias, int stat_kind, float coeff_scalar,
+                     const float *gate, const pww_attn_desc_t *d, double *stats_out, void *state, size_t state_bytes,
+                     void *workspace, size_t workspace_bytes, hipStream_t stream);
+size_t cross_fused_workspace_bytes(const pww_attn_desc_t *d);
+size_t cross_fused_state_bytes(const pww_attn_desc_t *d);
 int mask_build(const uint8_t *rgb, int H, int W, const pww_region_t *regions, int R, const int32_t *col_ptr,
                const int32_t *col_reg, int T, float *out8, float *out16, float *out32, float *out64,
                hipStream_t stream);
@@ -90,6 +95,17 @@ int pww_cross_attn_fwd_stat(const void *q, const void *k, const void *v, void *o
     return pww::attn_fwd(q, k, v, o, bias, gate, desc, static_cast<hipStream_t>(stream), stats, stat_kind, stat_count,
                          coeff_scalar);
 }
+
+int pww_cross_attn_fwd_fused(const void *q, const void *k, const void *v, void *o, const float *bias, int32_t stat_kind,
+                             float coeff_scalar, const float *gate, const pww_attn_desc_t *desc, double *stats_out, void *state,
+                             size_t state_bytes, void *workspace, size_t workspace_bytes, void *stream) {
+    return pww::cross_attn_fused(q, k, v, o, bias, stat_kind, coeff_scalar, gate, desc, stats_out, state, state_bytes, workspace,
+                                 workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+size_t pww_cross_fused_workspace_bytes(const pww_attn_desc_t *desc) { return pww::cross_fused_workspace_bytes(desc); }
+
+size_t pww_cross_fused_state_bytes(const pww_attn_desc_t *desc) { return pww::cross_fused_state_bytes(desc); }
 
 int pww_qk_reduce(const void *q, const void *k, const pww_attn_desc_t *desc, double *stats, void *workspace,
                   size_t workspace_bytes, void *stream) {

@@ -1,0 +1,303 @@
+// Device-side building blocks shared by the fused attention kernels (pww_attn.hip: general flash-style kernel;
+// pww_cross.hip: single-stage cross-attention with the score statistic formed in the same launch): LDS tile
+// geometry, buffer-load staging, the bias reference, and one 64-key tile of scores -> (bias) -> online softmax -> PV.
+#pragma once
+#include <stdlib.h>
+#include "pww_tile.h"
+
+namespace pww {
+
+struct AttnParams {
+    const void *q, *k, *v;
+    void *o;
+    const float *bias;
+    const float *bias_coeff;
+    int B, H, N, M, D;
+    long q_sb, q_sh, q_sn;
+    long k_sb, k_sh, k_sm;
+    long v_sb, v_sh, v_sm;
+    long o_sb, o_sh, o_sn;
+    long b_sb, b_sh, b_sn, b_sm;
+    float scale_log2e;  // scale * log2(e): softmax runs in the exp2 domain
+    const double *stats;   // optional [B][4] from qk_reduce: the per-image coefficient is formed here
+    int stat_kind;
+    double stat_count;
+    float coeff_scalar;
+};
+
+// c * stat(st), the statistic selected from one image's { max, min, sum, sum of squares } (fp64) and rounded to fp32 first
+__device__ __forceinline__ float stat_coefficient(float c, int kind, const double *st, double count) {
+    double v;
+    switch (kind) {
+        case PWW_STAT_MAX: v = st[0]; break;
+        case PWW_STAT_MIN: v = st[1]; break;
+        case PWW_STAT_MEAN: v = st[2] / count; break;
+        case PWW_STAT_ABSMAX: v = fmax(fabs(st[0]), fabs(st[1])); break;
+        default: {   // PWW_STAT_STD: unbiased, from sum and sum of squares in fp64
+            const double n = count;
+            const double var = (st[3] - st[2] * st[2] / n) / (n > 1.0 ? n - 1.0 : 1.0);
+            v = var > 0.0 ? var : 0.0;
+        }
+    }
+    float f = (float)v;
+    if (kind == PWW_STAT_STD) f = sqrtf(f);
+    return c * f;
+}
+
+// c[b] = coeff_scalar * stat(stats[b]) * gate[b]   (fp32 products in this order: what the host's elementwise ops gave)
+__device__ __forceinline__ float bias_coefficient(const AttnParams &p, int b) {
+    float c = p.coeff_scalar;
+    if (p.stat_kind != PWW_STAT_NONE) c = stat_coefficient(c, p.stat_kind, p.stats + (long)b * 4, p.stat_count);
+    if (p.bias_coeff) c = c * p.bias_coeff[b];
+    return c;
+}
+
+// V tile as staged in LDS: ROW-MAJOR like K, [64 keys][DT*32 d], and transposed by the READ: gfx950's
+// ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a 4-row x 16-column block whose rows are supplied,
+// four 8-byte pieces each, by lanes 4r..4r+3 (probed on hardware: tools/tr_probe.cpp). So the PV MFMA's A operand
+// (V^T[d = lane & 31][8 consecutive keys]) is two such reads, and staging V costs what staging K costs: 16-byte
+// global loads and 16-byte LDS stores, no per-element transposition work (16 v_perm + 8 ds_write_b64 per 4x8 block
+// before, carried by 3 of 8 waves -- the stragglers every barrier waited for; profiles/r01_attn_phases.md 2b).
+// Row stride = 64 or 192 (mod 256) bytes, so the four rows a 32-lane half reads in one LDS cycle (64 bytes each)
+// fall into disjoint bank ranges.
+template <int DT> struct VTile {
+    static constexpr int COLS = DT * 32;               // head dim padded to the MFMA M granularity
+    static constexpr int CHK = COLS / 8;               // 16-byte chunks per key row (those with d < D are staged)
+    static constexpr int STRIDE = (DT & 1) ? DT * 64 : DT * 64 + 64;   // bytes per key row: 64 / 192 / 192 / 320 / 320
+    static constexpr int BYTES = KVBLK * STRIDE;
+    static constexpr int NCHUNK = KVBLK * CHK;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// byte offset, inside a V tile, of the 8-byte piece lane l supplies for keys 0..3 / d-tile 0 of its fragment
+template <int DT> __device__ __forceinline__ int vfrag_lane_off(int lane) {
+    return ((lane >> 5) * 8 + ((lane & 15) >> 2)) * VTile<DT>::STRIDE + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+}
+
+// A-operand fragment of the PV MFMA: V[key0 .. key0+7][d = dt*32 + (lane & 31)] with key0 = kb*32 + k2*16 + 8*(lane>>5).
+// `vl` = tile base + vfrag_lane_off(lane); the rest are compile-time immediates.
+template <typename T, int DT>
+__device__ __forceinline__ typename Vec<T>::v8 load_vfrag(const char *vl, int kb, int k2, int dt) {
+    typedef __attribute__((address_space(3))) s16x4 *lds_p;
+    const char *a = vl + (kb * 32 + k2 * 16) * VTile<DT>::STRIDE + dt * 64;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a + 4 * VTile<DT>::STRIDE));
+    const s16x8 v = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(typename Vec<T>::v8, v);
+}
+
+// Loop-invariant part of a thread's share of the K/V staging: which 16-byte chunks it moves and where
+// they land in an LDS stage buffer. A stage = NSUB sub-tiles of 64 keys, each sub-tile = [K tile | Vt tile].
+//
+// Global reads are BUFFER loads: a per-(b,h) resource descriptor (base = first key row of this head,
+// num_records = last valid byte + 1), a loop-invariant per-thread 32-bit byte offset, plus the stage's byte
+// offset. That keeps the hot loop free of 64-bit address arithmetic (v_mul_lo / v_mad_u64 are multi-cycle
+// VOP3 ops: ~70 of them per stage before), and rows past the last key are OUT OF RANGE for the descriptor,
+// so the hardware returns zeros for them -- no clamping, no selects, no special tail path. Idle threads and
+// head-dim padding chunks carry an offset >= 2^31 (never in range; the host checks the extent is < 2^31).
+constexpr unsigned OOB_OFF = 0x80000000u;
+
+template <int KPT, int VPT> struct StagePlan {
+    unsigned k_off[KPT];
+    int k_lds[KPT];
+    bool k_ok[KPT];
+    unsigned v_off[VPT];
+    int v_lds[VPT];
+    bool v_ok[VPT];
+};
+
+template <typename T, int KS, int DT, int NT, int NSUB, int KPT, int VPT>
+__device__ __forceinline__ void make_plan(StagePlan<KPT, VPT> &pl, int tid, int D, long k_sm, long v_sm) {
+    typedef KTile<KS> KT;
+    typedef VTile<DT> VT;
+    constexpr int SUB_BYTES = KT::BYTES + VT::BYTES;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const int c = tid + i * NT;
+        const int key = c / KT::CHK, ch = c - key * KT::CHK;       // key in [0, 64*NSUB)
+        pl.k_ok[i] = c < NSUB * KT::NCHUNK && ch * 8 < D;            // padding chunks stay at their initial zeros
+        pl.k_off[i] = pl.k_ok[i] ? (unsigned)((key * k_sm + ch * 8) * 2) : OOB_OFF;
+        pl.k_lds[i] = (key >> 6) * SUB_BYTES + (key & 63) * KT::STRIDE + ch * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int c = tid + i * NT;
+        const int key = c / VT::CHK, ch = c - key * VT::CHK;
+        pl.v_ok[i] = c < NSUB * VT::NCHUNK && ch * 8 < D;            // padding columns are initialised once, never staged
+        pl.v_off[i] = pl.v_ok[i] ? (unsigned)((key * v_sm + ch * 8) * 2) : OOB_OFF;
+        pl.v_lds[i] = (key >> 6) * SUB_BYTES + KT::BYTES + (key & 63) * VT::STRIDE + ch * 16;
+    }
+}
+
+// Issue the global loads of the stage whose first key row sits `k_stage_off` / `v_stage_off` bytes into the
+// head's K / V. Nothing here consumes the loaded registers: the loads stay in flight across the compute of
+// the current stage. (Unconditional on purpose: a load inside an `if` gets an s_waitcnt vmcnt(0) behind it.)
+template <typename SRD, int KPT, int VPT>
+__device__ __forceinline__ void stage_load(u32x4 (&kreg)[KPT], u32x4 (&vreg)[VPT], const StagePlan<KPT, VPT> &pl,
+                                           SRD srd_k, SRD srd_v, unsigned k_stage_off, unsigned v_stage_off) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_k, pl.k_off[i] + k_stage_off, 0, 0);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_v, pl.v_off[i] + v_stage_off, 0, 0);
+}
+
+// Registers -> LDS stage buffer (rows past the last key arrive as zeros from the buffer load).
+template <int DT, int KPT, int VPT>
+__device__ __forceinline__ void stage_store(const u32x4 (&kreg)[KPT], const u32x4 (&vreg)[VPT],
+                                            const StagePlan<KPT, VPT> &pl, char *buf) {
+#pragma unroll
+    for (int i = 0; i < KPT; ++i)
+        if (pl.k_ok[i]) *reinterpret_cast<u32x4 *>(buf + pl.k_lds[i]) = kreg[i];
+#pragma unroll
+    for (int i = 0; i < VPT; ++i)
+        if (pl.v_ok[i]) *reinterpret_cast<u32x4 *>(buf + pl.v_lds[i]) = vreg[i];
+}
+
+// Resource descriptor over one head's K or V rows: [base, base + (M-1)*row_stride + D) elements of T.
+template <typename T>
+__device__ __forceinline__ auto head_srd(const T *base, int M, long row_stride, int D) {
+    const unsigned bytes = (unsigned)(((long)(M - 1) * row_stride + D) * 2);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(base), 0, bytes, 0x00020000);
+}
+
+// max over both half-waves of a per-lane value (lanes l and l^32 hold the two halves of one query row)
+__device__ __forceinline__ float xhalf_max(float x) {
+#if __has_builtin(__builtin_amdgcn_permlane32_swap)
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+#else
+    return fmaxf(x, __shfl_xor(x, 32));
+#endif
+}
+
+// Waves per SIMD the register allocator must leave room for (2 => <= 256 VGPRs+AGPRs). The bias
+// variants (32 extra loads in flight per tile) and the widest heads keep the whole 512-entry file.
+template <int DT, int NW, bool HAS_BIAS> struct MinWaves {
+    static constexpr int value = (DT >= 4 || (NW == 2 && DT >= 3) || (HAS_BIAS && DT >= 3)) ? 1 : 2;   // (an 8-wave workgroup needs 2 waves per SIMD to fit at all)
+};
+
+// One KV tile: scores -> (bias) -> online softmax -> PV. MASKED tiles (only the last one can be)
+// additionally kill keys >= M; full tiles skip every key compare.
+// ROWSUM_MFMA: the head dim is not a multiple of 32, so the V tile has padding columns; column D holds
+// ones and the PV MFMA accumulates the softmax denominator there for free (no per-element adds).
+// Bias addressing for one lane: a buffer descriptor over this (b, h) slice of the bias, the byte offset of the
+// lane's query row (>= 2^31, i.e. out of range -> zeros, for rows past N) and the key stride in bytes. With a unit
+// key stride (the PwW [N, 77] maps) every bias load is `row offset + immediate`: one VGPR for all 32 loads of a tile.
+struct BiasRef {
+    __amdgpu_buffer_rsrc_t srd;
+    unsigned row_off;
+    unsigned key_stride;   // bytes
+    bool unit;             // key_stride == 4
+};
+
+template <typename T, int KS, int DT, bool HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
+__device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[DT], float &m_run, float &l_run, const char *Vs,
+                                                int key0, int M, int l31, int hi, const BiasRef &bias,
+                                                float coeff, float c1);
+
+template <typename T, int KS, int DT, bool HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
+__device__ __forceinline__ void attn_tile(f32x16 (&oacc)[DT], float &m_run, float &l_run,
+                                          const typename Vec<T>::v8 (&qf)[KS], const char *Ks, const char *Vs,
+                                          int key0, int M, int l31, int hi, const BiasRef &bias,
+                                          float coeff, float c1) {
+    f32x16 s[2];
+    score_tile<T, KS>(s, qf, Ks, key0, MASKED ? M : 0x7fffffff, l31, hi);
+    attn_tile_sm_pv<T, KS, DT, HAS_BIAS, MASKED, ROWSUM_MFMA>(s, oacc, m_run, l_run, Vs, key0, M, l31, hi, bias, coeff, c1);
+}
+
+// scores (already in `s`) -> (bias) -> online softmax -> PV against the V tile at Vs
+template <typename T, int KS, int DT, bool HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
+__device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[DT], float &m_run, float &l_run, const char *Vs,
+                                                int key0, int M, int l31, int hi, const BiasRef &bias,
+                                                float coeff, float c1) {
+    typedef typename Vec<T>::v8 V8;
+    const char *vl = Vs + vfrag_lane_off<DT>(hi * 32 + l31);
+
+    // raw-domain logits x = s + c*bias (scale > 0, so the row max commutes with the scaling)
+    // (a 4-way max tree and packed v_pk_fma_f32 for the exp arguments were measured: neutral to -3%)
+    float tmax = -INFINITY;
+    if (HAS_BIAS && bias.unit) {
+        // unit key stride (the PwW [N, 77] maps): a lane's 8 consecutive keys of each (block, half) are 32 contiguous
+        // bytes of its bias row -> two 16-byte loads instead of eight 4-byte ones (the row stride makes every lane hit
+        // its own cache line either way, so the texture-address work per tile drops 4x). Dword-aligned only, which
+        // buffer loads allow; the range check is per dword, so a row tail never zeroes its in-range neighbours.
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const unsigned off = bias.row_off + (unsigned)(key0 + kb * 32 + 16 * g + 8 * hi) * 4u;
+                const u32x4 b0 = __builtin_amdgcn_raw_buffer_load_b128(bias.srd, off, 0, 0);
+                const u32x4 b1 = __builtin_amdgcn_raw_buffer_load_b128(bias.srd, off + 16u, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = g * 8 + j;
+                    const float bv = __builtin_bit_cast(float, j < 4 ? b0[j] : b1[j - 4]);
+                    float x = fmaf(bv, coeff, s[kb][r]);
+                    if (MASKED) x = key0 + key_of(kb, r, hi) < M ? x : -INFINITY;
+                    s[kb][r] = x;
+                    tmax = fmaxf(tmax, x);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + key_of(kb, r, hi);
+            float x = s[kb][r];
+            if (HAS_BIAS) {   // keys >= M of a ragged tile read a neighbouring (in-range) value; they are masked below
+                const unsigned off = bias.row_off + (unsigned)key * bias.key_stride;
+                const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bias.srd, off, 0, 0));
+                x = fmaf(bv, coeff, x);
+            }
+            if (MASKED) x = key < M ? x : -INFINITY;
+            s[kb][r] = x;
+            tmax = fmaxf(tmax, x);
+        }
+    }
+    }
+    tmax = xhalf_max(tmax);
+    const float m_new = fmaxf(m_run, tmax);   // finite: key0 < M, so at least one key of the tile is live
+    if (!__all(m_new == m_run)) {             // exact skip: alpha == 1 for every row of the wave
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c1);
+        if (!ROWSUM_MFMA) l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        m_run = m_new;
+    }
+    const float mc = -m_new * c1;
+    float psum = 0.f;
+    V8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c1, mc));   // exp2((x - m) * scale * log2 e)
+            if (!ROWSUM_MFMA) psum += pv;
+            pf[kb][r >> 3][r & 7] = (T)pv;
+        }
+    }
+    if (!ROWSUM_MFMA) l_run += psum;
+
+    // O^T[d][row] += V^T[d][key] * P^T[key][row]   (V^T fragments come out of the transpose read)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        if (!MASKED || key0 + kb * 32 < M) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const V8 vf = load_vfrag<T, DT>(vl, kb, k2, dt);
+                    oacc[dt] = mfma32(vf, pf[kb][k2], oacc[dt]);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace pww

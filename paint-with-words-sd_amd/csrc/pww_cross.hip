@@ -1,0 +1,427 @@
+// Cross-attention over the prompt tokens (M <= 128 keys: one K/V stage) with the per-image score statistic formed
+// IN THE SAME LAUNCH:
+//     O = softmax((Q K^T + c[b] * w) * scale) V,     c[b] = c0 * stat_b(Q K^T) * gate[b]
+// This is the whole of the reference's cond branch of inj_forward (paint_with_words/paint_with_words.py:87-116) for the
+// shipped weight functions  c0 * w * g(sigma) * qk.max() / qk.std()  (:402-405, runner.py:104, README.md:152): the
+// global reduction over heads x rows x keys that weight_function applies to `qk`, the bias add before the 1/sqrt(d)
+// scaling (:112), softmax and PV. Before, the statistic needed its own launches (arrival-counter init + pww_qk_reduce)
+// and the attention kernel re-read Q and K 12 us later.
+//
+// Structure (workgroup = NW waves x 32 query rows, one (image, head) and a strided set of its query blocks):
+//   1. K and V of the head (M <= 128 rows) are staged into LDS once.
+//   2. every query block's score tile is computed on the MFMA and reduced to (max, min, sum, sum of squares); one
+//      fp64 partial per query block goes to the workspace -- same granularity, same arithmetic order as
+//      pww_qk_reduce, so the statistic is bit-identical to the two-launch path.
+//   3. hand-off between the workgroups of an image: the partial IS the flag (cdna_hip_programming.md Guideline 16,
+//      form R2 -- 8-byte granules, agent-scope atomics on both sides, no fence, no counter on the critical path).
+//      A slot holds the bitwise complement of the fp64 partial, so an all-zero slot means "not written yet"; every
+//      workgroup folds the image's partials itself (the fold order of pww_qk_reduce's last arriver) and simply repeats
+//      the fold's loads until none of them is empty (bounded by a wall-clock limit). A same-address arrival counter was
+//      measured first: 256-512 workgroups bumping and polling one word cost 12 us per launch -- as much as the
+//      attention itself. Leaving is counted (one returning atomic per workgroup, issued after the fold and consumed at
+//      the very end), and the last workgroup to leave zeroes the image's slots and the counter again: the state
+//      words need zeroing once, not per call (no memset node in front of every launch, also under hipGraph replay).
+//      Images whose gate is 0 (the unconditional rows of a CFG-folded batch) take no part in any of this.
+//   4. bias -> online softmax -> PV -> store, exactly the tile code of the general kernel (pww_attn_core.h).
+// The launch is sized so that every workgroup is resident at once (the host clamps the grid to the occupancy
+// answer, at most two workgroups per CU, and gives each workgroup several query blocks when the batch is large);
+// a launch that could not be made resident takes the two-launch path instead -- same result, bit for bit.
+#include "pww_attn_core.h"
+
+namespace pww {
+
+struct CrossParams {
+    AttnParams a;        // a.bias_coeff = the row gate [B] (or null), a.stats unused
+    unsigned long long *slots;   // persistent, zero between launches: [B][nqb * H][4] complemented fp64 partials
+    unsigned *sync;              // persistent, zero between launches: left[B][H] (workgroups of a head that have left),
+                                 // heads_left[B], then the error word
+    double *stats_out;   // optional [B][4]: the folded statistics of the gated-in images
+    int nqb;             // query blocks per (image, head)
+    int nchunk;          // workgroups per (image, head)
+};
+
+constexpr unsigned long long SPIN_LIMIT_TICKS = 5000000ull;   // wall_clock64 runs at 100 MHz: 50 ms
+
+// a slot holds ~bits(value): zero = empty (no finite or infinite double has an all-ones bit pattern)
+__device__ __forceinline__ void slot_publish(unsigned long long *p, double v) {
+    __hip_atomic_store(p, ~(unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long slot_read(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double slot_value(unsigned long long x) { return __longlong_as_double((long long)~x); }
+
+template <typename T, int KS, int DT, int NW, bool SINGLE>
+__global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel(const CrossParams cp) {
+    typedef typename Vec<T>::v8 V8;
+    typedef typename Vec<T>::v4 V4;
+    typedef KTile<KS> KT;
+    typedef VTile<DT> VT;
+    constexpr int NSUB = 2;
+    constexpr int NT = NW * 64;
+    constexpr int SUB_BYTES = KT::BYTES + VT::BYTES;
+    constexpr int STAGE_BYTES = NSUB * SUB_BYTES;
+    constexpr int KPT = (NSUB * KT::NCHUNK + NT - 1) / NT;
+    constexpr int VPT = (NSUB * VT::NCHUNK + NT - 1) / NT;
+    const AttnParams &p = cp.a;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [K|V stage][fin: NW x 4 f64][final: 4 f64][red: NW x 4 f32][flag]
+    double *fin = reinterpret_cast<double *>(smem + STAGE_BYTES);
+    double *final_st = fin + NW * 4;
+    float *red = reinterpret_cast<float *>(final_st + 4);
+    volatile int *ok_flag = reinterpret_cast<volatile int *>(red + NW * 4);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int BH = p.B * p.H;
+    const int bh = blockIdx.x % BH, chunk = blockIdx.x / BH;
+    const int b = bh / p.H, h = bh - b * p.H;
+
+    const float gate = p.bias_coeff ? p.bias_coeff[b] : 1.f;
+    const bool biased = p.bias != nullptr && gate != 0.f;                 // workgroup-uniform
+    const bool need_stat = biased && p.stat_kind != PWW_STAT_NONE;
+
+    const T *Qp = reinterpret_cast<const T *>(p.q) + b * p.q_sb + h * p.q_sh;
+    const T *Kp = reinterpret_cast<const T *>(p.k) + b * p.k_sb + h * p.k_sh;
+    const T *Vp = reinterpret_cast<const T *>(p.v) + b * p.v_sb + h * p.v_sh;
+    T *Op = reinterpret_cast<T *>(p.o) + b * p.o_sb + h * p.o_sh;
+
+    V8 qf[KS];
+    if constexpr (SINGLE) {   // one query block per workgroup: its Q fragments stay in registers for both passes
+        const int qrow = (chunk * NW + wave) * 32 + l31;
+        load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qrow < p.N, hi, p.D);
+    }
+
+    // K and V of this head -> LDS (rows past M and the head-dim padding are zeros)
+    for (int i = tid * 16; i < STAGE_BYTES; i += NT * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0u, 0u, 0u, 0u};
+    {
+        StagePlan<KPT, VPT> plan;
+        make_plan<T, KS, DT, NT, NSUB, KPT, VPT>(plan, tid, p.D, p.k_sm, p.v_sm);
+        const auto srd_k = head_srd(Kp, p.M, p.k_sm, p.D);
+        const auto srd_v = head_srd(Vp, p.M, p.v_sm, p.D);
+        u32x4 kreg[KPT];
+        u32x4 vreg[VPT];
+        stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);
+        __syncthreads();                      // the zero fill is complete
+        stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
+    }
+    __syncthreads();
+
+    float coeff = 0.f;
+    unsigned depart_prev = 0u;     // lane 0 of the workgroup: how many workgroups of the image had left before this one
+    if (need_stat) {
+        // ---- pass 1: per query block (max, min, sum, sum of squares) of the raw scores, as pww_qk_reduce computes them
+        for (int qb = chunk; qb < cp.nqb; qb += cp.nchunk) {
+            const int qrow = (qb * NW + wave) * 32 + l31;
+            const bool qvalid = qrow < p.N;
+            if constexpr (!SINGLE) load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qvalid, hi, p.D);
+            float vmax = -INFINITY, vmin = INFINITY, vsum = 0.f, vsq = 0.f;
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub) {
+                const int key0 = sub * KVBLK;
+                if (key0 < p.M) {
+                    f32x16 s[2];
+                    score_tile<T, KS>(s, qf, smem + sub * SUB_BYTES, key0, p.M, l31, hi);
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const bool live = qvalid && (key0 + key_of(kb, r, hi) < p.M);
+                            const float x = s[kb][r];
+                            vmax = fmaxf(vmax, live ? x : -INFINITY);
+                            vmin = fminf(vmin, live ? x : INFINITY);
+                            vsum += live ? x : 0.f;
+                            vsq += live ? x * x : 0.f;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+                vmin = fminf(vmin, __shfl_xor(vmin, off));
+                vsum += __shfl_xor(vsum, off);
+                vsq += __shfl_xor(vsq, off);
+            }
+            __syncthreads();
+            if (lane == 0) {
+                red[wave * 4 + 0] = vmax; red[wave * 4 + 1] = vmin;
+                red[wave * 4 + 2] = vsum; red[wave * 4 + 3] = vsq;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                double dmax = -INFINITY, dmin = INFINITY, dsum = 0.0, dsq = 0.0;
+                for (int w = 0; w < NW; ++w) {
+                    dmax = fmax(dmax, (double)red[w * 4 + 0]);
+                    dmin = fmin(dmin, (double)red[w * 4 + 1]);
+                    dsum += (double)red[w * 4 + 2];
+                    dsq += (double)red[w * 4 + 3];
+                }
+                unsigned long long *slot = cp.slots + ((long)b * cp.nqb * p.H + (long)qb * p.H + h) * 4;
+                slot_publish(slot + 0, dmax); slot_publish(slot + 1, dmin);
+                slot_publish(slot + 2, dsum); slot_publish(slot + 3, dsq);
+            }
+        }
+        // ---- hand-off + fold: every workgroup folds the image's partials itself (the order of pww_qk_reduce's
+        // last-arriver fold), re-reading them until none is empty
+        {
+            const int bpi = cp.nqb * p.H;
+            const unsigned long long *base = cp.slots + (long)b * bpi * 4;
+            double dmax, dmin, dsum, dsq;
+            const unsigned long long t0 = wall_clock64();
+            bool complete;
+            for (;;) {
+                dmax = -INFINITY; dmin = INFINITY; dsum = 0.0; dsq = 0.0;
+                complete = true;
+                for (int i = tid; i < bpi; i += NT) {
+                    const unsigned long long x0 = slot_read(base + i * 4 + 0), x1 = slot_read(base + i * 4 + 1);
+                    const unsigned long long x2 = slot_read(base + i * 4 + 2), x3 = slot_read(base + i * 4 + 3);
+                    complete = complete && x0 != 0ull && x1 != 0ull && x2 != 0ull && x3 != 0ull;
+                    dmax = fmax(dmax, slot_value(x0));
+                    dmin = fmin(dmin, slot_value(x1));
+                    dsum += slot_value(x2);
+                    dsq += slot_value(x3);
+                }
+                const bool expired = wall_clock64() - t0 > SPIN_LIMIT_TICKS;
+                if (__syncthreads_and(complete || expired)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const int ok = __syncthreads_and(complete);
+            if (tid == 0) {
+                // leaving is counted per head (a few dozen workgroups per word, not hundreds); the returned count is only
+                // looked at when the workgroup is done
+                if (ok) depart_prev = __hip_atomic_fetch_add(cp.sync + b * p.H + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else __hip_atomic_store(cp.sync + p.B * p.H + p.B, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // error word
+                *ok_flag = ok;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                dmax = fmax(dmax, __shfl_xor(dmax, off));
+                dmin = fmin(dmin, __shfl_xor(dmin, off));
+                dsum += __shfl_xor(dsum, off);
+                dsq += __shfl_xor(dsq, off);
+            }
+            if (lane == 0) { fin[wave * 4 + 0] = dmax; fin[wave * 4 + 1] = dmin; fin[wave * 4 + 2] = dsum; fin[wave * 4 + 3] = dsq; }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < NW; ++w) {
+                    dmax = fmax(dmax, fin[w * 4 + 0]); dmin = fmin(dmin, fin[w * 4 + 1]);
+                    dsum += fin[w * 4 + 2]; dsq += fin[w * 4 + 3];
+                }
+                final_st[0] = dmax; final_st[1] = dmin; final_st[2] = dsum; final_st[3] = dsq;
+                if (cp.stats_out && h == 0 && chunk == 0) {
+                    double *st = cp.stats_out + (long)b * 4;
+                    st[0] = dmax; st[1] = dmin; st[2] = dsum; st[3] = dsq;
+                }
+            }
+            __syncthreads();
+            const double st[4] = {final_st[0], final_st[1], final_st[2], final_st[3]};
+            coeff = stat_coefficient(p.coeff_scalar, p.stat_kind, st, p.stat_count);
+            if (p.bias_coeff) coeff = coeff * gate;
+            if (!*ok_flag) coeff = __builtin_nanf("");     // a hand-off that timed out must not look like a result
+        }
+    } else if (biased) {
+        coeff = p.coeff_scalar;
+        if (p.bias_coeff) coeff = coeff * gate;
+    }
+
+    // ---- pass 2: bias -> softmax -> PV per query block
+    BiasRef bias;
+    if (biased) {
+        const float *bbase = p.bias + b * p.b_sb + h * p.b_sh;
+        const unsigned bytes = (unsigned)((((long)(p.N - 1) * p.b_sn + (long)(p.M - 1) * p.b_sm) + 1) * 4);
+        bias.srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bbase), 0, bytes, 0x00020000);
+        bias.key_stride = (unsigned)(p.b_sm * 4);
+        bias.unit = p.b_sm == 1;
+    }
+    const float c1 = p.scale_log2e;
+    for (int qb = chunk; qb < cp.nqb; qb += cp.nchunk) {
+        const int qrow = (qb * NW + wave) * 32 + l31;
+        const bool qvalid = qrow < p.N;
+        if constexpr (!SINGLE) load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qvalid, hi, p.D);
+        if (biased) bias.row_off = qvalid ? (unsigned)((long)qrow * p.b_sn * 4) : OOB_OFF;
+        f32x16 oacc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int key0 = sub * KVBLK;
+            if (key0 < p.M) {
+                const char *Ks = smem + sub * SUB_BYTES;
+                if (biased)
+                    attn_tile<T, KS, DT, true, true, false>(oacc, m_run, l_run, qf, Ks, Ks + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
+                else
+                    attn_tile<T, KS, DT, false, true, false>(oacc, m_run, l_run, qf, Ks, Ks + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
+            }
+        }
+        const float l_tot = l_run + __shfl_xor(l_run, 32);
+        const float inv = 1.f / l_tot;
+        if (qvalid) {
+            T *orow = Op + (long)qrow * p.o_sn;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = dt * 32 + g * 8 + hi * 4;
+                    if (d < p.D) {
+                        V4 out;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) out[j] = (T)(oacc[dt][g * 4 + j] * inv);
+                        *reinterpret_cast<V4 *>(orow + d) = out;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- the last workgroup of an image to leave puts the image's state words back to zero. (Every other workgroup of
+    // the image has finished reading the slots: a workgroup leaves only after its fold. Last of its head -> bumps the
+    // image's heads_left word; last of those -> everybody is out.)
+    if (need_stat) {
+        if (tid == 0) {
+            int last = 0;
+            if (*ok_flag && depart_prev == (unsigned)cp.nchunk - 1u) {
+                const unsigned prev = __hip_atomic_fetch_add(cp.sync + p.B * p.H + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = prev == (unsigned)p.H - 1u;
+            }
+            *ok_flag = last;
+        }
+        __syncthreads();
+        if (*ok_flag) {
+            const int nslot = cp.nqb * p.H * 4;
+            unsigned long long *base = cp.slots + (long)b * nslot;
+            for (int i = tid; i < nslot; i += NT) __hip_atomic_store(base + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = tid; i < p.H; i += NT) __hip_atomic_store(cp.sync + b * p.H + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(cp.sync + p.B * p.H + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------
+
+int attn_fwd(const void *q, const void *k, const void *v, void *o, const float *bias, const float *bias_coeff,
+             const pww_attn_desc_t *d, hipStream_t stream, const double *stats, int stat_kind, double stat_count,
+             float coeff_scalar);
+int attn_validate(const void *q, const void *k, const void *v, void *o, const float *bias, const pww_attn_desc_t *d);
+void attn_fill_params(AttnParams &p, const void *q, const void *k, const void *v, void *o, const float *bias,
+                      const float *bias_coeff, const pww_attn_desc_t *d);
+int qk_reduce(const void *q, const void *k, const pww_attn_desc_t *d, double *stats, void *workspace, size_t workspace_bytes,
+              hipStream_t stream);
+size_t qk_reduce_workspace_bytes(const pww_attn_desc_t *d);
+bool attn_wide_groups(const pww_attn_desc_t *d);
+
+static int device_cus() {
+    static thread_local int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        cus = prop.multiProcessorCount;
+    }
+    return cus;
+}
+
+template <typename T, int KS, int DT, int NW>
+static int launch_cross(CrossParams cp, hipStream_t stream, bool *launched) {
+    constexpr size_t lds = 2 * (KTile<KS>::BYTES + VTile<DT>::BYTES) + NW * 4 * 8 + 4 * 8 + NW * 4 * 4 + 16;
+    auto k_single = cross_fused_kernel<T, KS, DT, NW, true>;
+    auto k_multi = cross_fused_kernel<T, KS, DT, NW, false>;
+    static thread_local int per_cu = -1;
+    if (per_cu < 0) {
+        for (auto kern : {k_single, k_multi})
+            if (lds > 64 * 1024 && check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"))
+                return PWW_EHIP;
+        int n1 = 0, n2 = 0;
+        if (check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_single, NW * 64, lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor") ||
+            check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, k_multi, NW * 64, lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor"))
+            return PWW_EHIP;
+        // never count on more than two resident workgroups per CU (the API can be one high near an SGPR edge -- MI355X_MICROARCH.md)
+        per_cu = n1 < n2 ? n1 : n2;
+        per_cu = per_cu > 2 ? 2 : per_cu;
+    }
+    const AttnParams &p = cp.a;
+    const long cap = (long)per_cu * device_cus();
+    const long BH = (long)p.B * p.H;
+    cp.nqb = (p.N + NW * 32 - 1) / (NW * 32);
+    if (cap < BH) { *launched = false; return PWW_OK; }      // cannot be made resident: the caller takes the two-launch path
+    long nchunk = cap / BH;
+    if (nchunk > cp.nqb) nchunk = cp.nqb;
+    cp.nchunk = (int)nchunk;
+    const dim3 grid((unsigned)(BH * nchunk));
+    if (cp.nchunk == cp.nqb) hipLaunchKernelGGL(k_single, grid, dim3(NW * 64), lds, stream, cp);
+    else hipLaunchKernelGGL(k_multi, grid, dim3(NW * 64), lds, stream, cp);
+    *launched = true;
+    return check_hip(hipGetLastError(), "cross_fused_kernel launch");
+}
+
+template <typename T, int NW> static int dispatch_cross_d(const CrossParams &cp, hipStream_t s, bool *launched) {
+    const int D = cp.a.D;
+    if (D <= 48) return launch_cross<T, 3, 2, NW>(cp, s, launched);
+    if (D <= 64) return launch_cross<T, 4, 2, NW>(cp, s, launched);
+    if (D <= 80) return launch_cross<T, 5, 3, NW>(cp, s, launched);
+    if (D <= 96) return launch_cross<T, 6, 3, NW>(cp, s, launched);
+    if constexpr (NW == 2) { set_error("cross_attn_fused: internal dispatch error"); return PWW_EINVAL; } else {
+        if (D <= 128) return launch_cross<T, 8, 4, NW>(cp, s, launched);
+        return launch_cross<T, 10, 5, NW>(cp, s, launched);
+    }
+}
+
+// scratch of the two-launch path (pww_qk_reduce's workspace followed by its [B][4] statistics): only touched when the
+// launch cannot be made resident
+size_t cross_fused_workspace_bytes(const pww_attn_desc_t *d) {
+    if (!d || d->B <= 0 || d->H <= 0 || d->N <= 0) return 0;
+    return ((qk_reduce_workspace_bytes(d) + 63) & ~(size_t)63) + (size_t)d->B * 4 * sizeof(double) + 64;
+}
+
+// persistent state words: left[B][H], heads_left[B], error word (padded to 8 bytes), then the partial slots
+static size_t state_sync_bytes(const pww_attn_desc_t *d) { return (((size_t)d->B * d->H + d->B + 1) * sizeof(unsigned) + 7) & ~(size_t)7; }
+
+size_t cross_fused_state_bytes(const pww_attn_desc_t *d) {
+    if (!d || d->B <= 0 || d->H <= 0 || d->N <= 0) return 0;
+    return state_sync_bytes(d) + (size_t)d->B * ((d->N + 63) / 64) * d->H * 4 * sizeof(unsigned long long);
+}
+
+int cross_attn_fused(const void *q, const void *k, const void *v, void *o, const float *bias, int stat_kind, float coeff_scalar,
+                     const float *gate, const pww_attn_desc_t *d, double *stats_out, void *state, size_t state_bytes,
+                     void *workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (int rc = attn_validate(q, k, v, o, bias, d)) return rc;
+    if (!bias) { set_error("cross_attn_fused: bias map required"); return PWW_EINVAL; }
+    if (d->M > 2 * KVBLK) { set_error("cross_attn_fused: at most %d keys (got %d)", 2 * KVBLK, d->M); return PWW_ENOTSUP; }
+    if (stat_kind < PWW_STAT_NONE || stat_kind > PWW_STAT_ABSMAX) { set_error("cross_attn_fused: bad statistic selector %d", stat_kind); return PWW_EINVAL; }
+    if (!state || state_bytes < cross_fused_state_bytes(d) || (reinterpret_cast<uintptr_t>(state) & 7)) {
+        set_error("cross_attn_fused: state buffer missing, misaligned or too small (need %zu bytes, 8-byte aligned)", cross_fused_state_bytes(d));
+        return PWW_EINVAL;
+    }
+    if (!workspace || workspace_bytes < cross_fused_workspace_bytes(d) || (reinterpret_cast<uintptr_t>(workspace) & 7)) {
+        set_error("cross_attn_fused: workspace missing, misaligned or too small (need %zu bytes, 8-byte aligned)", cross_fused_workspace_bytes(d));
+        return PWW_EINVAL;
+    }
+    CrossParams cp;
+    attn_fill_params(cp.a, q, k, v, o, bias, gate, d);
+    cp.a.stats = nullptr; cp.a.stat_kind = stat_kind; cp.a.stat_count = (double)d->H * d->N * d->M; cp.a.coeff_scalar = coeff_scalar;
+    cp.sync = reinterpret_cast<unsigned *>(state);
+    cp.slots = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(state) + state_sync_bytes(d));
+    cp.stats_out = stats_out;
+    cp.nqb = cp.nchunk = 0;
+    bool launched = false;
+    const bool wide = attn_wide_groups(d);
+    int rc;
+    if (d->dtype == PWW_DTYPE_F16) rc = wide ? dispatch_cross_d<f16, 4>(cp, stream, &launched) : dispatch_cross_d<f16, 2>(cp, stream, &launched);
+    else rc = wide ? dispatch_cross_d<bf16, 4>(cp, stream, &launched) : dispatch_cross_d<bf16, 2>(cp, stream, &launched);
+    if (rc || launched) return rc;
+    // more (image, head) pairs than resident workgroups: statistic and attention as two launches, same arithmetic
+    char *ws = reinterpret_cast<char *>(workspace);
+    const size_t red_bytes = (qk_reduce_workspace_bytes(d) + 63) & ~(size_t)63;
+    double *stats = stats_out ? stats_out : reinterpret_cast<double *>(ws + red_bytes);
+    if (stat_kind != PWW_STAT_NONE)
+        if (int rc2 = qk_reduce(q, k, d, stats, ws, red_bytes, stream)) return rc2;
+    return attn_fwd(q, k, v, o, bias, gate, d, stream, stat_kind != PWW_STAT_NONE ? stats : nullptr, stat_kind,
+                    (double)d->H * d->N * d->M, coeff_scalar);
+}
+
+}  // namespace pww

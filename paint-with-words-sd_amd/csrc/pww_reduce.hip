@@ -161,10 +161,11 @@ static int launch_reduce(ReduceParams p, hipStream_t stream) {
     return check_hip(hipGetLastError(), "qk_reduce_kernel launch");
 }
 
+bool attn_wide_groups_dims(int B, int H, int N, int D);
+
 template <typename T> static int dispatch_reduce(const ReduceParams &p, hipStream_t s) {
     const int D = p.D;
-    const long rows32 = (long)((p.N + 31) / 32) * p.B * p.H;
-    const bool wide = rows32 >= 4 * 256 && p.N >= 128;
+    const bool wide = attn_wide_groups_dims(p.B, p.H, p.N, p.D);   // the attention kernels' rule (pww_attn.hip)
 #define PWW_RED(KS_) (wide ? launch_reduce<T, KS_, 4>(p, s) : launch_reduce<T, KS_, 2>(p, s))
     if (D <= 48) return PWW_RED(3);
     if (D <= 64) return PWW_RED(4);

@@ -15,7 +15,7 @@ MAX_HEAD_DIM = 160
 
 # every symbol include/pww_hip.h declares (tests check the library exports all of them)
 EXPORTS = ("pww_version", "pww_last_error", "pww_device_arch", "pww_self_attn_fwd", "pww_cross_attn_fwd",
-           "pww_cross_attn_fwd_stat",
+           "pww_cross_attn_fwd_stat", "pww_cross_attn_fwd_fused", "pww_cross_fused_workspace_bytes", "pww_cross_fused_state_bytes",
            "pww_qk_reduce", "pww_mask_build", "pww_mask_build_rgb", "pww_mask_build_f32", "pww_cfg_combine",
            "pww_workspace_bytes")
 
@@ -59,6 +59,12 @@ def load():
     lib.pww_self_attn_fwd.argtypes = [vp, vp, vp, vp, ctypes.POINTER(AttnDesc), vp]
     lib.pww_cross_attn_fwd.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.POINTER(AttnDesc), vp]
     lib.pww_cross_attn_fwd_stat.argtypes = [vp, vp, vp, vp, vp, vp, i32, ctypes.c_double, f32, vp, ctypes.POINTER(AttnDesc), vp]
+    lib.pww_cross_attn_fwd_fused.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp, ctypes.POINTER(AttnDesc), vp, vp, ctypes.c_size_t, vp,
+                                             ctypes.c_size_t, vp]
+    lib.pww_cross_fused_workspace_bytes.argtypes = [ctypes.POINTER(AttnDesc)]
+    lib.pww_cross_fused_workspace_bytes.restype = ctypes.c_size_t
+    lib.pww_cross_fused_state_bytes.argtypes = [ctypes.POINTER(AttnDesc)]
+    lib.pww_cross_fused_state_bytes.restype = ctypes.c_size_t
     lib.pww_qk_reduce.argtypes = [vp, vp, ctypes.POINTER(AttnDesc), vp, vp, ctypes.c_size_t, vp]
     lib.pww_mask_build.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.pww_mask_build_rgb.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, i32, vp, vp]
@@ -66,11 +72,11 @@ def load():
     lib.pww_cfg_combine.argtypes = [vp, vp, f32, vp, i64, i32, vp]
     lib.pww_workspace_bytes.argtypes = [ctypes.POINTER(AttnDesc)]
     lib.pww_workspace_bytes.restype = ctypes.c_size_t
-    for name in ("pww_device_arch", "pww_self_attn_fwd", "pww_cross_attn_fwd", "pww_cross_attn_fwd_stat", "pww_qk_reduce", "pww_mask_build",
+    for name in ("pww_device_arch", "pww_self_attn_fwd", "pww_cross_attn_fwd", "pww_cross_attn_fwd_stat", "pww_cross_attn_fwd_fused", "pww_qk_reduce", "pww_mask_build",
                  "pww_mask_build_rgb", "pww_mask_build_f32", "pww_cfg_combine"):
         getattr(lib, name).restype = ctypes.c_int
-    if lib.pww_version() // 100 != 1:
-        raise PwwHipError("libpww_hip ABI version %d is not 1.x" % lib.pww_version())
+    if lib.pww_version() // 100 != 1 or lib.pww_version() < 110:
+        raise PwwHipError("libpww_hip ABI version %d is not 1.x >= 1.10 (rebuild: python paint-with-words-sd_amd/build.py)" % lib.pww_version())
     _lib = lib
     return lib
 

@@ -11,6 +11,7 @@ HIP kernel. The user's ``weight_function(w, sigma, qk)`` still receives ``qk`` -
 whose reductions are computed by the score-reduction kernel instead of from a materialised tensor.
 """
 import math
+import os
 import warnings
 
 import torch
@@ -23,6 +24,7 @@ _HALF = (torch.float16, torch.bfloat16)
 ROW_GATE = "_PWW_ROW_GATE"   # private context key: fp32 [B] per-row bias coefficient (see pww_hip/sampler.py)
 _LAZY_W = True               # hand weight_function a ScaledW instead of the raw map (see ScaledW)
 KV_CACHE = "_PWW_KV_CACHE"   # private context key: {id(attn): (attn, [B, 77, 2C] fused K|V projection)} for one request
+FUSED_CROSS = os.environ.get("PWW_FUSED_CROSS", "1") != "0"   # statistic + attention in one launch (pww_cross_attn_fwd_fused); 0 = two launches (A/B)
 _warned = set()
 
 
@@ -447,11 +449,21 @@ def pww_attention(attn, hidden_states, context=None):
 
     coeff = None
     stat = None
+    scratch = None
     if isinstance(bias, LazyStat):     # a bare statistic: a per-image constant on every logit of a row cancels in softmax
         bias = None
     if isinstance(bias, ScaledW) and bias.stat is not None and not torch.is_tensor(bias.coeff) and torch.is_tensor(bias.w):
-        # c0 * w * g(sigma) * reduce(qk): map, statistics and Python scalar go to the kernel as they are
-        stat = (bias.stat.stats(), bias.stat.kind, float(bias.coeff) * float(bias.stat.scale))
+        # c0 * w * g(sigma) * reduce(qk): map, statistic selector and Python scalar go to the kernel as they are. Over
+        # the prompt tokens (M <= 128) the statistic is formed in the attention launch itself, unless the weight
+        # function already forced it to exist as a tensor.
+        scalar = float(bias.coeff) * float(bias.stat.scale)
+        if FUSED_CROSS and bias.stat._proxy._stats is None and key.shape[1] <= ops.FUSED_MAX_KEYS:
+            stat = (None, bias.stat.kind, scalar)
+            scratch = attn.__dict__.get("_pww_fused_scratch")
+            if scratch is None:
+                scratch = attn.__dict__["_pww_fused_scratch"] = ops.FusedScratch()
+        else:
+            stat = (bias.stat.stats(), bias.stat.kind, scalar)
         bias = bias.w
     elif isinstance(bias, ScaledW):    # coeff * w: keep the map, pass the coefficient to the kernel
         if bias.stat is not None:
@@ -474,7 +486,7 @@ def pww_attention(attn, hidden_states, context=None):
         # (the unconditional pass returns 0.0, :493)
         bias = None
     return ops.attention(query, key, value, attn.heads, attn.scale, bias=bias, bias_coeff=gate if bias is not None else None,
-                         stat=stat if bias is not None else None)
+                         stat=stat if bias is not None else None, scratch=scratch)
 
 
 def inj_forward(self, hidden_states, context=None, mask=None):

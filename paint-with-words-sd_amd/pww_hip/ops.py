@@ -70,12 +70,51 @@ def _prep(t):
 STAT_NONE, STAT_MAX, STAT_MIN, STAT_MEAN, STAT_STD, STAT_ABSMAX = 0, 1, 2, 3, 4, 5   # PWW_STAT_* of include/pww_hip.h
 
 
-def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None):
+FUSED_MAX_KEYS = 128   # pww_cross_attn_fwd_fused: one K/V stage
+
+
+class FusedScratch:
+    """Device buffers of pww_cross_attn_fwd_fused for one call site (one attention layer): the persistent state words
+    (zeroed ONCE here -- the kernel leaves them zero after every launch, so captured hipGraphs replay without a memset
+    node) and the scratch of the two-launch path. Allocated outside stream capture (the first, eager call of a layer
+    creates them) and kept alive by their owner, because captured graphs hold their addresses."""
+
+    def __init__(self):
+        self.state = None
+        self.ws = None
+        self._err_index = 0
+
+    def _alloc(self, current, nbytes, device, zero):
+        if current is not None and current.device == device and current.numel() * 8 >= nbytes:
+            return current
+        if torch.cuda.is_current_stream_capturing():
+            raise PwwHipError("fused cross-attention buffers must exist before hipGraph capture (run one eager call first)")
+        n = (nbytes + 7) // 8
+        return (torch.zeros if zero else torch.empty)((n,), dtype=torch.int64, device=device)
+
+    def ensure(self, lib, d, device):
+        self.state = self._alloc(self.state, int(lib.pww_cross_fused_state_bytes(ctypes.byref(d))), device, True)
+        self.ws = self._alloc(self.ws, int(lib.pww_cross_fused_workspace_bytes(ctypes.byref(d))), device, False)
+        self._err_index = d.B * d.H + d.B
+        return self.state, self.ws
+
+    def error(self):
+        """True if a hand-off inside the fused kernel timed out in the last call's geometry (synchronises; diagnostics /
+        tests only). The state words must then be re-zeroed: `reset()`."""
+        return self.state is not None and bool(self.state.view(torch.int32)[self._err_index].item() != 0)
+
+    def reset(self):
+        if self.state is not None:
+            self.state.zero_()
+
+
+def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None, scratch=None, stats_out=None):
     """softmax((Q K^T + c * bias) * scale) V on [B, tokens, heads*D] tensors (diffusers layout, no
     head-split copies). bias: fp32 tensor broadcastable to [B, heads, N, M] or None;
     bias_coeff: optional fp32 [B] device tensor of per-image coefficients (with `stat`: the row gate);
-    stat: optional (stats [B,4] float64 from qk_stats, STAT_* kind, python scalar) -- the kernel then forms
-    c[b] = scalar * stat(stats[b]) * bias_coeff[b] itself (pww_cross_attn_fwd_stat)."""
+    stat: optional (stats, STAT_* kind, python scalar): the kernel forms c[b] = scalar * stat(stats[b]) * bias_coeff[b]
+    itself. `stats` is either the float64 [B,4] tensor of qk_stats (pww_cross_attn_fwd_stat) or None together with a
+    FusedScratch in `scratch`: the statistic is then computed in the same launch (pww_cross_attn_fwd_fused, M <= 128)."""
     _require_gpu(q, k, v, bias, bias_coeff)
     if not (q.dtype == k.dtype == v.dtype):
         raise PwwHipError("q/k/v dtypes differ: %s %s %s" % (q.dtype, k.dtype, v.dtype))
@@ -102,7 +141,18 @@ def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None):
                     bias_coeff = bias_coeff.expand(B).contiguous()
                 if bias_coeff.numel() != B:
                     raise PwwHipError("bias_coeff must have B=%d elements" % B)
-            if stat is not None:
+            if stat is not None and stat[0] is None:
+                _, kind, scalar = stat
+                if scratch is None or M > FUSED_MAX_KEYS:
+                    raise PwwHipError("fused statistic needs a FusedScratch and at most %d keys" % FUSED_MAX_KEYS)
+                state, ws = scratch.ensure(lib, d, q.device)
+                if stats_out is not None and (stats_out.dtype != torch.float64 or tuple(stats_out.shape) != (B, 4) or not stats_out.is_contiguous()):
+                    raise PwwHipError("stats_out must be a contiguous float64 [B, 4] tensor")
+                rc = lib.pww_cross_attn_fwd_fused(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(bias), int(kind), float(scalar),
+                                                  _ptr(bias_coeff), ctypes.byref(d), _ptr(stats_out), _ptr(state), state.numel() * 8,
+                                                  _ptr(ws), ws.numel() * 8, _stream())
+                _lib.check(rc, "pww_cross_attn_fwd_fused")
+            elif stat is not None:
                 stats, kind, scalar = stat
                 if stats.dtype != torch.float64 or tuple(stats.shape) != (B, 4) or not stats.is_contiguous():
                     raise PwwHipError("stat: stats must be a contiguous float64 [B, 4] tensor")

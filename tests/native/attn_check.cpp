@@ -122,6 +122,66 @@ static void run_case(const Case &c, bool timing) {
         }
     }
 
+    // pww_cross_attn_fwd_fused: statistic + attention in ONE launch == pww_qk_reduce + pww_cross_attn_fwd_stat, bit for bit
+    // (output AND statistics), with every gate open and with the last image gated out (the unconditional rows of a
+    // CFG-folded batch); repeated launches re-use the same sync words (the kernel leaves them zero).
+    if (c.bias_mode == 1 && M <= 128) {
+        const size_t fws_bytes = pww_cross_fused_workspace_bytes(&d), sync_bytes = pww_cross_fused_state_bytes(&d);
+        void *fws = dalloc<char>(fws_bytes + 8); unsigned *dsync = dalloc<unsigned>(sync_bytes / 4 + 1);
+        HIPCHECK(hipMemset(dsync, 0, sync_bytes));
+        double *fstats = dalloc<double>(4 * B);
+        uint16_t *o1 = dalloc<uint16_t>(q.size()), *o2 = dalloc<uint16_t>(q.size());
+        float *dgate = dalloc<float>(B);
+        for (int variant = 0; variant < (B > 1 ? 2 : 1); ++variant) {
+            std::vector<float> gate(coeff);
+            if (variant == 1) gate[B - 1] = 0.f;
+            HIPCHECK(hipMemcpy(dgate, gate.data(), B * 4, hipMemcpyHostToDevice));
+            for (int kind : {PWW_STAT_MAX, PWW_STAT_STD, PWW_STAT_ABSMAX, PWW_STAT_MEAN, PWW_STAT_MIN, PWW_STAT_NONE}) {
+                const float s0 = 0.37f;
+                HIPCHECK(hipMemset(fstats, 0, 4 * B * 8));
+                HIPCHECK(hipMemset(o1, 0xff, q.size() * 2)); HIPCHECK(hipMemset(o2, 0xee, q.size() * 2));
+                int r1 = pww_cross_attn_fwd_stat(dq, dk, dv, o1, dbias, kind == PWW_STAT_NONE ? nullptr : dstats, kind, (double)H * N * M, s0, dgate, &d, nullptr);
+                int r2 = 0;
+                for (int rep = 0; rep < 3 && !r2; ++rep)
+                    r2 = pww_cross_attn_fwd_fused(dq, dk, dv, o2, dbias, kind, s0, dgate, &d, fstats, dsync, sync_bytes, fws, fws_bytes, nullptr);
+                HIPCHECK(hipDeviceSynchronize());
+                std::vector<uint16_t> h1(q.size()), h2(q.size()); std::vector<double> fs(4 * B); std::vector<unsigned> hs(sync_bytes / 4);
+                HIPCHECK(hipMemcpy(h1.data(), o1, h1.size() * 2, hipMemcpyDeviceToHost));
+                HIPCHECK(hipMemcpy(h2.data(), o2, h2.size() * 2, hipMemcpyDeviceToHost));
+                HIPCHECK(hipMemcpy(fs.data(), fstats, fs.size() * 8, hipMemcpyDeviceToHost));
+                HIPCHECK(hipMemcpy(hs.data(), dsync, sync_bytes, hipMemcpyDeviceToHost));
+                long diff = 0, sdiff = 0, dirty = 0;
+                for (size_t i = 0; i < h1.size(); ++i) diff += h1[i] != h2[i];
+                if (kind != PWW_STAT_NONE)
+                    for (int b = 0; b < B; ++b) if (gate[b] != 0.f) for (int j = 0; j < 4; ++j) sdiff += memcmp(&fs[4 * b + j], &stats[4 * b + j], 8) != 0;
+                for (unsigned w : hs) dirty += w != 0;
+                const bool ok = r1 == 0 && r2 == 0 && diff == 0 && sdiff == 0 && dirty == 0;
+                printf("%s %-28s fused kind=%d gate-variant=%d: %ld differing outputs, %ld differing statistics, %ld dirty state words (rc %d %d%s%s)\n",
+                       ok ? "PASS" : "FAIL", c.name, kind, variant, diff, sdiff, dirty, r1, r2, r2 ? " " : "", r2 ? pww_last_error() : "");
+                if (!ok) g_fail++;
+            }
+        }
+        if (timing) {
+            hipEvent_t e0, e1; HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+            const int iters = 50;
+            std::vector<float> gate(coeff); if (B > 1) for (int b = B / 2; b < B; ++b) gate[b] = 0.f;     // folded CFG batch: second half unconditional
+            HIPCHECK(hipMemcpy(dgate, gate.data(), B * 4, hipMemcpyHostToDevice));
+            float ms_f = 0, ms_s = 0;
+            for (int pass = 0; pass < 2; ++pass) {
+                for (int i = 0; i < 5 + iters; ++i) {
+                    if (i == 5) HIPCHECK(hipEventRecord(e0, nullptr));
+                    if (pass == 0) pww_cross_attn_fwd_fused(dq, dk, dv, o2, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, nullptr, dsync, sync_bytes, fws, fws_bytes, nullptr);
+                    else { pww_qk_reduce(dq, dk, &d, dstats, dws, ws_bytes, nullptr); pww_cross_attn_fwd_stat(dq, dk, dv, o1, dbias, dstats, PWW_STAT_MAX, (double)H * N * M, 0.37f, dgate, &d, nullptr); }
+                }
+                HIPCHECK(hipEventRecord(e1, nullptr)); HIPCHECK(hipEventSynchronize(e1));
+                HIPCHECK(hipEventElapsedTime(pass == 0 ? &ms_f : &ms_s, e0, e1));
+            }
+            printf("TIME %-28s fused statistic+attention %.2f us/call | pww_qk_reduce + pww_cross_attn_fwd_stat %.2f us/call (gates: first half 1, second half 0)\n",
+                   c.name, ms_f * 1e3 / iters, ms_s * 1e3 / iters);
+        }
+        for (void *ptr : {(void *)fws, (void *)dsync, (void *)fstats, (void *)o1, (void *)o2, (void *)dgate}) (void)hipFree(ptr);
+    }
+
     // fp64 reference on sampled rows: O = softmax((QK^T + c*bias) * scale) V
     double max_err = 0, max_ref = 0; long nchk = 0; int nan_count = 0;
     std::vector<double> logit(M), ref(D);
@@ -298,6 +358,7 @@ static void check_errors() {
 int main(int argc, char **argv) {
     const bool quick = argc > 1 && !strcmp(argv[1], "--quick");
     const char *only = (argc > 2 && !strcmp(argv[1], "--only")) ? argv[2] : nullptr;
+    const char *match = (argc > 2 && !strcmp(argv[1], "--match")) ? argv[2] : nullptr;     // substring of the case name
     char arch[64] = ""; int rc = pww_device_arch(arch, sizeof(arch));
     printf("libpww_hip version %d, device arch '%s' (rc=%d)\n", pww_version(), arch, rc);
     std::vector<Case> cases = {
@@ -315,6 +376,10 @@ int main(int argc, char **argv) {
         {"sd15_self_n4096_d40", PWW_DTYPE_BF16, 1, 8, 4096, 4096, 40, 0, true, 97, 1.0f},
         {"sd15_self_n4096_d40_f16_b2", PWW_DTYPE_F16, 2, 8, 4096, 4096, 40, 0, true, 193, 1.0f},
         {"sd15_cross_n4096_d40", PWW_DTYPE_BF16, 2, 8, 4096, 77, 40, 1, false, 97, 1.0f},
+        {"sd15_cross_n4096_d40_b16", PWW_DTYPE_BF16, 16, 8, 4096, 77, 40, 1, false, 397, 1.0f},     // 8 images folded: several query blocks per workgroup
+        {"cross_n64_d160_b72_split", PWW_DTYPE_F16, 72, 8, 64, 77, 160, 1, false, 7, 0.5f},        // more (image, head) pairs than resident workgroups: two-launch path
+        {"cross_n200_m128_d64", PWW_DTYPE_BF16, 3, 5, 200, 128, 64, 1, false, 1, 0.8f},
+        {"cross_n100_m40_d80", PWW_DTYPE_F16, 2, 4, 100, 40, 80, 1, false, 1, 0.8f},
         {"sd15_cross_fullbias_n4096", PWW_DTYPE_F16, 1, 8, 4096, 77, 40, 2, false, 97, 1.0f},
         {"sd21_self_n2304_d64", PWW_DTYPE_BF16, 1, 10, 2304, 2304, 64, 0, true, 61, 0.8f},
         {"sd21_self_n9216_d64_b4", PWW_DTYPE_BF16, 4, 5, 9216, 9216, 64, 0, true, 1531, 0.8f},   // BASELINE config 5: 768x768, 2 images folded
@@ -343,9 +408,10 @@ int main(int argc, char **argv) {
         const bool big = (long)c.N * c.M >= 1024L * 1024L || c.N >= 4096;
         if (quick && big) continue;
         if (only && strcmp(only, c.name)) continue;
-        run_case(c, big);
+        if (match && !strstr(c.name, match)) continue;
+        run_case(c, big || c.bias_mode == 1);
     }
-    if (!only) {
+    if (!only && !match) {
         check_mask();
         check_cfg();
         check_errors();

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol(built_lib):
     raw = ctypes.CDLL(built_lib)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.pww_version() == 100
+    assert lib.pww_version() == 110
     assert lib.pww_last_error() == b"" or isinstance(lib.pww_last_error(), bytes)
     assert lib.pww_workspace_bytes(None) == 0
 
@@ -191,6 +191,14 @@ def test_miopen_find_switch(monkeypatch):
         monkeypatch.delenv("PWW_MIOPEN_FIND")
         pww_hip.enable_miopen_find()
         assert torch.backends.cudnn.benchmark is True
+        # the scoped form the drop-in API uses: on inside, the caller's value restored afterwards (no global side effect)
+        torch.backends.cudnn.benchmark = False
+        with pww_hip.miopen_find():
+            assert torch.backends.cudnn.benchmark is True
+        assert torch.backends.cudnn.benchmark is False
+        monkeypatch.setenv("PWW_MIOPEN_FIND", "0")
+        with pww_hip.miopen_find():
+            assert torch.backends.cudnn.benchmark is False
     finally:
         torch.backends.cudnn.benchmark = old
 
