@@ -210,6 +210,32 @@ int pww_mask_build_f32(const float *masks, int32_t H, int32_t W, int32_t R,
                        int32_t ratio, float *out, void *stream);
 
 /*
+ * CROSS_ATTENTION_WEIGHT_ORIG [H][W][T] -> [n_tokens][T]: the reference's fallback when a layer's token count has no
+ * pre-computed map (paint_with_words.py:96-101; image sizes that are not multiples of 64): bilinear
+ * (align_corners=True) to (oh, ow) = floor(H / r), floor(W / r) with r = sqrt(H*W / n_tokens) -- computed by the
+ * caller in double precision, as torch does -- then 1-D nearest over the flattened oh*ow pixels.
+ */
+int pww_resize_tokens(const float *orig, int32_t H, int32_t W, int32_t T, int32_t oh, int32_t ow,
+                      int32_t n_tokens, float *out, void *stream);
+
+/*
+ * out = GaussianBlur(in) for one float mask [H][W] (paint_with_words.py:307-312: torchvision GaussianBlur(39x39,
+ * sigma), reflect padding). `weights` = the normalised 1-D kernel, `ksize` floats on the device (odd, ksize/2 < H, W);
+ * `tmp` = H*W doubles of scratch. Two 1-D passes with fp64 accumulation. in == out is allowed.
+ */
+int pww_gauss_blur(const float *in, float *out, int32_t H, int32_t W, const float *weights, int32_t ksize,
+                   double *tmp, void *stream);
+
+/*
+ * Inpainting inputs from the PIL-side arrays (paint_with_words_inpaint.py:92-106, :115):
+ *   mask_out      [H][W]     1.0 where mask/255 >= 0.5 else 0.0        (NULL = skip)
+ *   masked_image  [3][H][W]  (rgb / 127.5 - 1) * (mask < 0.5)
+ *   mask_lat      [h][w]     mask_out at latent resolution, nearest     (NULL = skip)
+ */
+int pww_inpaint_prep(const uint8_t *rgb, const uint8_t *mask, int32_t H, int32_t W, int32_t h, int32_t w,
+                     float *mask_out, float *masked_image, float *mask_lat, void *stream);
+
+/*
  * out = uncond + g * (cond - uncond)  (paint_with_words.py:501-503), fp32 math, n elements of
  * `dtype` in, fp32 out.
  */

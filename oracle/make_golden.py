@@ -21,6 +21,7 @@ import time
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 from PIL import Image
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -205,6 +206,166 @@ def gen_inpaint():
     print("loop_tiny_inpaint8: latents std %.4f" % lat.std())
 
 
+# ---- round-2 fixtures ---------------------------------------------------------------------------
+
+SEED_SIGMA_CONTEXT = {(0, 0, 0): "cat,1.0,42,4.0", (255, 255, 255): "dog,1.0,7", (13, 255, 0): "tree,1.5,-1,9.5",
+                      (90, 206, 255): "sky,0.2", (74, 18, 1): "ground,0.2"}
+
+
+def gen_seed_sigma(ref):
+    """Regions that carry BOTH a seed and a sigma ("text,strength,seed,sigma"): the reference blurs the masks in place
+    (:338-340) BEFORE thresholding them for region seeding (:300-304, :451), so the seeded area is the dilated one."""
+    from sd_standin import HashTokenizer
+    tok = HashTokenizer()
+    ex = np.array(Image.open(os.path.join(GOLDEN, "example_input.png")).convert("RGB"))
+    ctx2, seeds, sigmas = ref["_extract_seed_and_sigma_from_context"](dict(SEED_SIGMA_CONTEXT))
+    sep, w, h = ref["_image_context_seperator"](Image.fromarray(ex), ctx2, tok)
+    sep = ref["_blur_image_mask"](sep, sigmas)
+    bm = ref["_get_binary_mask"](sep, seeds, torch.float32, (64, 64))
+    np.savez_compressed(os.path.join(GOLDEN, "binary_mask_seed_sigma.npz"), mask=torch.stack(bm).numpy()[:, 0, 0],
+                        seeds=np.array(list(seeds.items())), sigmas=np.array(list(sigmas.items())))
+    lat, dt = _run_loop(ref, "tiny", 5, ex, SEED_SIGMA_CONTEXT, cases.RUNNER_PROMPT, cases.weight_fn_runner, seed=2)
+    np.savez_compressed(os.path.join(GOLDEN, "loop_tiny_seed_sigma5.npz"), latents=lat, steps=5)
+    print("seed+sigma: binary masks", [float(b.sum()) for b in bm], "loop latents std %.4f (%.1fs)" % (lat.std(), dt))
+
+
+def gen_prep():
+    """prepare_mask_and_masked_image (paint_with_words_inpaint.py:20-106, PIL branch) + the latent-size mask (:115)."""
+    ref = ref_loader.load_reference_inpaint()
+    init = cases.synthetic_init_image()
+    mask = Image.open(os.path.join(GOLDEN, "moon_mask_L.png"))
+    m, mi = ref["prepare_mask_and_masked_image"](Image.fromarray(init), mask)
+    ml = F.interpolate(m, size=(64, 64))
+    np.savez_compressed(os.path.join(GOLDEN, "inpaint_prep.npz"), mask=np.packbits(m.numpy()[0, 0] > 0.5), masked_rows=mi.numpy()[0, :, ::8],
+                        masked_sum=mi.double().sum(dim=(2, 3)).numpy()[0], masked_abs_sum=mi.abs().double().sum().item(),
+                        mask_lat=ml.numpy()[0, 0])
+    print("inpaint_prep: mask ones %d, latent mask ones %d, masked sum %s" % (int(m.sum()), int(ml.sum()), mi.double().sum().item()))
+
+
+def _install_ref(ref, unet):
+    for m in unet.modules():
+        if m.__class__.__name__ == "CrossAttention":
+            m.__class__.__call__ = ref["inj_forward"]
+
+
+def _uninstall_ref():
+    from sd_standin import CrossAttention
+    if "__call__" in CrossAttention.__dict__:
+        del CrossAttention.__call__
+
+
+def gen_forwards(ref):
+    """Single UNet forwards of the FULL-SIZE stand-ins with the reference's inj_forward plugged in (fp32, CPU):
+    the shapes BASELINE configs 4 and 5 run at -- SD1.5-inpainting (9 input channels, 4 regions, moon mask) and
+    SD2.1 at 768x768 (N = 9216 tokens, head dim 64, 12 regions, 0.4 w log(1+sigma^2) qk.std())."""
+    import warnings
+    warnings.filterwarnings("ignore")
+    only = os.environ.get("PWW_GOLDEN_ONLY", "")
+    if "sd21" not in only:
+        au = np.array(Image.open(os.path.join(GOLDEN, "aurora_1.png")).convert("RGB"))
+        tools = cases.build_tools("sd15_inpaint")
+        vae, unet, text, tok, sch = tools
+        _install_ref(ref, unet)
+        try:
+            _, _, cond, uncond = ref["_encode_text_color_inputs"](text, tok, "cpu", Image.fromarray(au), dict(cases.INPAINT_CONTEXT),
+                                                                  cases.AURORA_PROMPT, "")
+            sch.set_timesteps(30)
+            i = 4
+            t, sigma = sch.timesteps[i], sch.sigmas[i]
+            out = {"step_index": i, "sigma": float(sigma)}
+            g = torch.Generator().manual_seed(81)
+            x8 = torch.randn(8, 9, 64, 64, generator=g)
+            x8[:, 4] = (x8[:, 4] > 0).float()          # channel 4 is the binary mask
+            out["x"] = x8.numpy()
+            for j in (0, 5):
+                x = sch.scale_model_input(x8[j:j + 1, :4], t)
+                x = torch.cat([x, x8[j:j + 1, 4:]], dim=1)
+                cond.update({"SIGMA": sigma, "WEIGHT_FUNCTION": cases.weight_fn_inpaint})
+                t0 = time.time()
+                out[f"eps_cond_{j}"] = unet(x, t, encoder_hidden_states=cond).sample.numpy()
+                uncond.update({"SIGMA": sigma, "WEIGHT_FUNCTION": lambda w, sigma, qk: 0.0})
+                out[f"eps_uncond_{j}"] = unet(x, t, encoder_hidden_states=uncond).sample.numpy()
+                print("fwd sd15_inpaint image %d: %.1fs |eps| %.4f" % (j, time.time() - t0, np.abs(out[f"eps_cond_{j}"]).mean()))
+        finally:
+            _uninstall_ref()
+        np.savez_compressed(os.path.join(GOLDEN, "fwd_sd15_inpaint.npz"), **out)
+    if "inpaint" not in only:
+        grid, gctx, gprompt = cases.grid_case(seeds=True)
+        tools = cases.build_tools("sd21")
+        vae, unet, text, tok, sch = tools
+        _install_ref(ref, unet)
+        try:
+            _, _, cond, uncond = ref["_encode_text_color_inputs"](text, tok, "cpu", Image.fromarray(grid), dict(gctx), gprompt, "")
+            sch.set_timesteps(30)
+            i = 4
+            t, sigma = sch.timesteps[i], sch.sigmas[i]
+            g = torch.Generator().manual_seed(11)
+            x0 = torch.randn(1, 4, 96, 96, generator=g) * sch.init_noise_sigma
+            x = sch.scale_model_input(x0, t)
+            out = {"step_index": i, "sigma": float(sigma), "x": x0.numpy()}
+            cond.update({"SIGMA": sigma, "WEIGHT_FUNCTION": cases.weight_fn_std})
+            t0 = time.time()
+            out["eps_cond"] = unet(x, t, encoder_hidden_states=cond).sample.numpy()
+            uncond.update({"SIGMA": sigma, "WEIGHT_FUNCTION": lambda w, sigma, qk: 0.0})
+            out["eps_uncond"] = unet(x, t, encoder_hidden_states=uncond).sample.numpy()
+            print("fwd sd21 768x768: %.1fs |eps| %.4f" % (time.time() - t0, np.abs(out["eps_cond"]).mean()))
+        finally:
+            _uninstall_ref()
+        np.savez_compressed(os.path.join(GOLDEN, "fwd_sd21_grid768.npz"), **out)
+
+
+def gen_plms():
+    """ORACLE-generated (not reference-generated: the reference cannot run PNDM/PLMS -- no `.sigmas`, a repeated timestep,
+    SURVEY.md section 8 a-note): final latent of BASELINE configs[1] -- full-size SD1.5 stand-in, 30 PLMS steps
+    (31 UNet evaluations x {cond, uncond}), CFG 7.5, 5-region example -- through oracle/pww_oracle.py in fp32 on the CPU.
+    The oracle itself is pinned to the reference by every other fixture; this file pins the HIP path on the benchmarked
+    configuration to the oracle without 9 minutes of CPU time inside the GPU test."""
+    from oracle import pww_oracle as O
+    ex = np.array(Image.open(os.path.join(GOLDEN, "example_input.png")).convert("RGB"))
+    vae, unet, text, tok, sch = cases.build_tools("sd15", scheduler="plms")
+    O.install_oracle_attention(unet)
+    try:
+        t0 = time.time()
+        lat = O.paint_with_words_latents(dict(cases.RUNNER_CONTEXT), ex, cases.RUNNER_PROMPT, unet, text, tok, sch,
+                                         num_inference_steps=30, guidance_scale=7.5, seed=0, weight_function=cases.weight_fn_runner)
+        dt = time.time() - t0
+    finally:
+        _uninstall_ref()
+    np.savez_compressed(os.path.join(GOLDEN, "loop_sd15_example_plms30_oracle.npz"), latents=lat.numpy(), seconds=np.float64(dt),
+                        threads=torch.get_num_threads())
+    print("loop_sd15_example_plms30_oracle: %.1fs latents std %.4f" % (dt, lat.std()))
+
+
+def gen_ref_timing(ref):
+    """CPU baseline as SURVEY.md section 8(d) specifies it: the AST-loaded, unmodified reference `paint_with_words`
+    (config 1: full-size SD1.5 stand-in fp32, 512x512, 10 LMS steps, CFG 7.5, 5-region example) on this build box's
+    cores, with the time spent inside its `inj_forward` accumulated separately. bench.py reports this file's figures
+    next to the oracle port it times on the GPU box's own host cores."""
+    ex = np.array(Image.open(os.path.join(GOLDEN, "example_input.png")).convert("RGB"))
+    inner = ref["inj_forward"]
+    acc = {"s": 0.0, "calls": 0}
+
+    def timed(self, hidden_states, context=None, mask=None):
+        t0 = time.perf_counter()
+        try:
+            return inner(self, hidden_states, context, mask)
+        finally:
+            acc["s"] += time.perf_counter() - t0
+            acc["calls"] += 1
+    ref["inj_forward"] = timed
+    try:
+        lat, dt = _run_loop(ref, "sd15", 10, ex, cases.RUNNER_CONTEXT, cases.RUNNER_PROMPT, cases.weight_fn_runner, 0)
+    finally:
+        ref["inj_forward"] = inner
+    golden = np.load(os.path.join(GOLDEN, "loop_sd15_example_lms10.npz"))["latents"]
+    rec = {"what": "AST-loaded reference paint_with_words, fp32, device=cpu, 10 LMS steps (20 UNet forwards), 512x512, 5-region example, stand-in SD1.5 UNet (seed 1234)",
+           "wall_s": round(dt, 2), "s_per_unet_forward": round(dt / 20, 3), "s_inside_inj_forward": round(acc["s"], 2),
+           "inj_forward_calls": acc["calls"], "threads": torch.get_num_threads(), "cpu_count": os.cpu_count(),
+           "images_per_s_30_steps": round(1.0 / (dt / 10 * 30), 6), "max_abs_diff_vs_golden": float(np.abs(lat - golden).max())}
+    json.dump(rec, open(os.path.join(GOLDEN, "ref_cpu_timing.json"), "w"), indent=1)
+    print("ref_cpu_timing", rec)
+
+
 if __name__ == "__main__":
     assert ref_loader.available(), "reference not found at %s" % ref_loader.REFERENCE_ROOT
     os.makedirs(GOLDEN, exist_ok=True)
@@ -221,3 +382,13 @@ if __name__ == "__main__":
         gen_loops(ref, "--full" in sys.argv)
     if "inpaint" in which:
         gen_inpaint()
+    if "seedsigma" in which:
+        gen_seed_sigma(ref)
+    if "prep" in which:
+        gen_prep()
+    if "fwd" in which:
+        gen_forwards(ref)
+    if "plms" in which:
+        gen_plms()
+    if "reftime" in which:
+        gen_ref_timing(ref)

@@ -64,6 +64,10 @@ int mask_build_rgb(const uint8_t *rgb, int H, int W, const pww_region_t *regions
                    const int32_t *col_reg, int T, int ratio, float *out, hipStream_t stream);
 int mask_build_f32(const float *masks, int H, int W, int R, const int32_t *col_ptr, const int32_t *col_reg, int T,
                    int ratio, float *out, hipStream_t stream);
+int resize_tokens(const float *orig, int H, int W, int T, int oh, int ow, int n_tokens, float *out, hipStream_t stream);
+int gauss_blur(const float *in, float *out, int H, int W, const float *weights, int ksize, double *tmp, hipStream_t stream);
+int inpaint_prep(const uint8_t *rgb, const uint8_t *mask, int H, int W, int h, int w, float *mask_out, float *masked,
+                 float *mask_lat, hipStream_t stream);
 int cfg_combine(const void *cond, const void *uncond, float g, float *out, long n, int dtype, hipStream_t stream);
 
 }  // namespace pww
@@ -128,6 +132,21 @@ int pww_mask_build_rgb(const uint8_t *rgb, int32_t H, int32_t W, const pww_regio
 int pww_mask_build_f32(const float *masks, int32_t H, int32_t W, int32_t R, const int32_t *col_ptr,
                        const int32_t *col_reg, int32_t T, int32_t ratio, float *out, void *stream) {
     return pww::mask_build_f32(masks, H, W, R, col_ptr, col_reg, T, ratio, out, static_cast<hipStream_t>(stream));
+}
+
+int pww_resize_tokens(const float *orig, int32_t H, int32_t W, int32_t T, int32_t oh, int32_t ow, int32_t n_tokens, float *out,
+                      void *stream) {
+    return pww::resize_tokens(orig, H, W, T, oh, ow, n_tokens, out, static_cast<hipStream_t>(stream));
+}
+
+int pww_gauss_blur(const float *in, float *out, int32_t H, int32_t W, const float *weights, int32_t ksize, double *tmp,
+                   void *stream) {
+    return pww::gauss_blur(in, out, H, W, weights, ksize, tmp, static_cast<hipStream_t>(stream));
+}
+
+int pww_inpaint_prep(const uint8_t *rgb, const uint8_t *mask, int32_t H, int32_t W, int32_t h, int32_t w, float *mask_out,
+                     float *masked_image, float *mask_lat, void *stream) {
+    return pww::inpaint_prep(rgb, mask, H, W, h, w, mask_out, masked_image, mask_lat, static_cast<hipStream_t>(stream));
 }
 
 int pww_cfg_combine(const void *cond, const void *uncond, float guidance, float *out, int64_t n, int32_t dtype,

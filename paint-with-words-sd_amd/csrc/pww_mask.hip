@@ -126,6 +126,120 @@ int mask_build_f32(const float *masks, int H, int W, int R, const int32_t *col_p
     return launch_mask(tap, H, W, ratio, R, col_ptr, col_reg, T, out, stream);
 }
 
+// ---- CROSS_ATTENTION_WEIGHT_ORIG -> [n_tokens, T]: the reference's fallback for token counts without a per-resolution
+// key (paint_with_words.py:96-101): bilinear(align_corners=True) to (oh, ow) = floor(size / sqrt(H*W/n)), flattened
+// row-major, then 1-D nearest to n_tokens (src = floor(dst * n_in / n_out) in fp32, ATen's nearest). One thread per
+// output element; consecutive threads read consecutive prompt positions of the same four taps (coalesced).
+__global__ void __launch_bounds__(256) resize_tokens_kernel(const float *orig, int H, int W, int T, int oh, int ow, int n_tokens, float *out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n_tokens * T) return;
+    const int n = (int)(i / T), t = (int)(i - (long)n * T);
+    const int n_in = oh * ow;
+    const float nscale = __fdiv_rn((float)n_in, (float)n_tokens);
+    int src = (int)floorf(__fmul_rn((float)n, nscale));
+    src = src < n_in - 1 ? src : n_in - 1;
+    const int oy = src / ow, ox = src - oy * ow;
+    const float sy = oh > 1 ? __fdiv_rn((float)(H - 1), (float)(oh - 1)) : 0.f;
+    const float sx = ow > 1 ? __fdiv_rn((float)(W - 1), (float)(ow - 1)) : 0.f;
+    const float fy = __fmul_rn(sy, (float)oy), fx = __fmul_rn(sx, (float)ox);
+    int y0 = (int)fy, x0 = (int)fx;
+    y0 = y0 < H - 1 ? y0 : H - 1; x0 = x0 < W - 1 ? x0 : W - 1;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = fminf(fmaxf(__fsub_rn(fy, (float)y0), 0.f), 1.f);
+    const float lx = fminf(fmaxf(__fsub_rn(fx, (float)x0), 0.f), 1.f);
+    const float hy = __fsub_rn(1.f, ly), hx = __fsub_rn(1.f, lx);
+    auto tap = [&](int y, int x) { return orig[((long)y * W + x) * T + t]; };
+    const float top = __fadd_rn(__fmul_rn(tap(y0, x0), hx), __fmul_rn(tap(y0, x1), lx));
+    const float bot = __fadd_rn(__fmul_rn(tap(y1, x0), hx), __fmul_rn(tap(y1, x1), lx));
+    out[i] = __fadd_rn(__fmul_rn(top, hy), __fmul_rn(bot, ly));
+}
+
+int resize_tokens(const float *orig, int H, int W, int T, int oh, int ow, int n_tokens, float *out, hipStream_t stream) {
+    if (!orig || !out) { set_error("resize_tokens: null argument"); return PWW_EINVAL; }
+    if (H <= 0 || W <= 0 || T <= 0 || oh <= 0 || ow <= 0 || n_tokens <= 0 || oh > H || ow > W) {
+        set_error("resize_tokens: bad size H=%d W=%d T=%d oh=%d ow=%d n=%d", H, W, T, oh, ow, n_tokens);
+        return PWW_EINVAL;
+    }
+    if (!arch_ok()) return PWW_ENOTSUP;
+    const long total = (long)n_tokens * T;
+    hipLaunchKernelGGL(resize_tokens_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, orig, H, W, T, oh, ow, n_tokens, out);
+    return check_hip(hipGetLastError(), "resize_tokens_kernel launch");
+}
+
+// ---- per-region Gaussian blur of a float mask (paint_with_words.py:307-312: torchvision GaussianBlur(39x39, sigma),
+// reflect padding). The 2-D kernel is the outer product of one normalised 1-D kernel, so two 1-D passes give the same
+// map; accumulation in fp64 (the taps are summed in ascending order, deterministic) keeps the result within fp32
+// rounding of the exact convolution whatever order the reference's conv2d sums its 1521 taps in.
+__device__ __forceinline__ int reflect_index(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+
+__global__ void __launch_bounds__(256) blur_rows_kernel(const float *in, int H, int W, const float *k, int ks, double *tmp) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)H * W) return;
+    const int y = (int)(i / W), x = (int)(i - (long)y * W), half = ks / 2;
+    const float *row = in + (long)y * W;
+    double acc = 0.0;
+    for (int j = 0; j < ks; ++j) acc += (double)k[j] * (double)row[reflect_index(x + j - half, W)];
+    tmp[i] = acc;
+}
+
+__global__ void __launch_bounds__(256) blur_cols_kernel(const double *tmp, int H, int W, const float *k, int ks, float *out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)H * W) return;
+    const int y = (int)(i / W), x = (int)(i - (long)y * W), half = ks / 2;
+    double acc = 0.0;
+    for (int j = 0; j < ks; ++j) acc += (double)k[j] * tmp[(long)reflect_index(y + j - half, H) * W + x];
+    out[i] = (float)acc;
+}
+
+int gauss_blur(const float *in, float *out, int H, int W, const float *weights, int ksize, double *tmp, hipStream_t stream) {
+    if (!in || !out || !weights || !tmp) { set_error("gauss_blur: null argument"); return PWW_EINVAL; }
+    if (H <= 0 || W <= 0 || ksize <= 0 || (ksize & 1) == 0 || ksize / 2 >= H || ksize / 2 >= W) {
+        set_error("gauss_blur: bad size H=%d W=%d ksize=%d (odd, reflect padding needs ksize/2 < H, W)", H, W, ksize);
+        return PWW_EINVAL;
+    }
+    if (!arch_ok()) return PWW_ENOTSUP;
+    const unsigned blocks = (unsigned)(((long)H * W + 255) / 256);
+    hipLaunchKernelGGL(blur_rows_kernel, dim3(blocks), dim3(256), 0, stream, in, H, W, weights, ksize, tmp);
+    hipLaunchKernelGGL(blur_cols_kernel, dim3(blocks), dim3(256), 0, stream, tmp, H, W, weights, ksize, out);
+    return check_hip(hipGetLastError(), "blur kernels launch");
+}
+
+// ---- inpainting inputs (paint_with_words_inpaint.py:92-106 PIL branch, :115): init image uint8 [H,W,3] -> [-1,1]
+// planar, mask uint8 [H,W] -> {0,1} at threshold 0.5, masked_image = image * (mask < 0.5), and the mask at latent
+// resolution (nearest: src = floor(dst * in/out) in fp32) -- one pass over the pixels instead of a dozen torch ops.
+__global__ void __launch_bounds__(256) inpaint_prep_kernel(const uint8_t *rgb, const uint8_t *mask, int H, int W, int h, int w,
+                                                            float *mask_out, float *masked, float *mask_lat) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long npx = (long)H * W;
+    if (i < npx) {
+        const float m = __fdiv_rn((float)mask[i], 255.0f) >= 0.5f ? 1.f : 0.f;
+        const float keep = m < 0.5f ? 1.f : 0.f;
+        if (mask_out) mask_out[i] = m;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = __fsub_rn(__fdiv_rn((float)rgb[i * 3 + c], 127.5f), 1.0f);
+            masked[c * npx + i] = __fmul_rn(v, keep);
+        }
+    }
+    if (mask_lat && i < (long)h * w) {
+        const int y = (int)(i / w), x = (int)(i - (long)y * w);
+        int sy = (int)floorf(__fmul_rn((float)y, __fdiv_rn((float)H, (float)h)));
+        int sx = (int)floorf(__fmul_rn((float)x, __fdiv_rn((float)W, (float)w)));
+        sy = sy < H - 1 ? sy : H - 1; sx = sx < W - 1 ? sx : W - 1;
+        mask_lat[i] = __fdiv_rn((float)mask[(long)sy * W + sx], 255.0f) >= 0.5f ? 1.f : 0.f;
+    }
+}
+
+int inpaint_prep(const uint8_t *rgb, const uint8_t *mask, int H, int W, int h, int w, float *mask_out, float *masked,
+                 float *mask_lat, hipStream_t stream) {
+    if (!rgb || !mask || !masked) { set_error("inpaint_prep: null argument"); return PWW_EINVAL; }
+    if (H <= 0 || W <= 0 || (mask_lat && (h <= 0 || w <= 0 || h > H || w > W))) { set_error("inpaint_prep: bad size"); return PWW_EINVAL; }
+    if (!arch_ok()) return PWW_ENOTSUP;
+    hipLaunchKernelGGL(inpaint_prep_kernel, dim3((unsigned)(((long)H * W + 255) / 256)), dim3(256), 0, stream, rgb, mask, H, W, h, w,
+                       mask_out, masked, mask_lat);
+    return check_hip(hipGetLastError(), "inpaint_prep_kernel launch");
+}
+
 // ---- classifier-free guidance combine ---------------------------------------------------------
 template <typename T>
 __global__ void cfg_combine_kernel(const T *cond, const T *uncond, float g, float *out, long n) {

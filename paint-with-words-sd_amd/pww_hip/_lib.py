@@ -16,7 +16,7 @@ MAX_HEAD_DIM = 160
 # every symbol include/pww_hip.h declares (tests check the library exports all of them)
 EXPORTS = ("pww_version", "pww_last_error", "pww_device_arch", "pww_self_attn_fwd", "pww_cross_attn_fwd",
            "pww_cross_attn_fwd_stat", "pww_cross_attn_fwd_fused", "pww_cross_fused_workspace_bytes", "pww_cross_fused_state_bytes",
-           "pww_qk_reduce", "pww_mask_build", "pww_mask_build_rgb", "pww_mask_build_f32", "pww_cfg_combine",
+           "pww_qk_reduce", "pww_mask_build", "pww_mask_build_rgb", "pww_mask_build_f32", "pww_resize_tokens", "pww_gauss_blur", "pww_inpaint_prep", "pww_cfg_combine",
            "pww_workspace_bytes")
 
 
@@ -69,11 +69,14 @@ def load():
     lib.pww_mask_build.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.pww_mask_build_rgb.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, i32, vp, vp]
     lib.pww_mask_build_f32.argtypes = [vp, i32, i32, i32, vp, vp, i32, i32, vp, vp]
+    lib.pww_resize_tokens.argtypes = [vp, i32, i32, i32, i32, i32, i32, vp, vp]
+    lib.pww_gauss_blur.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp]
+    lib.pww_inpaint_prep.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.pww_cfg_combine.argtypes = [vp, vp, f32, vp, i64, i32, vp]
     lib.pww_workspace_bytes.argtypes = [ctypes.POINTER(AttnDesc)]
     lib.pww_workspace_bytes.restype = ctypes.c_size_t
     for name in ("pww_device_arch", "pww_self_attn_fwd", "pww_cross_attn_fwd", "pww_cross_attn_fwd_stat", "pww_cross_attn_fwd_fused", "pww_qk_reduce", "pww_mask_build",
-                 "pww_mask_build_rgb", "pww_mask_build_f32", "pww_cfg_combine"):
+                 "pww_mask_build_rgb", "pww_mask_build_f32", "pww_resize_tokens", "pww_gauss_blur", "pww_inpaint_prep", "pww_cfg_combine"):
         getattr(lib, name).restype = ctypes.c_int
     if lib.pww_version() // 100 != 1 or lib.pww_version() < 110:
         raise PwwHipError("libpww_hip ABI version %d is not 1.x >= 1.10 (rebuild: python paint-with-words-sd_amd/build.py)" % lib.pww_version())

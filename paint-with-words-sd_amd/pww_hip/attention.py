@@ -337,13 +337,22 @@ class ScaledW:
 
 def _orig_weight_to_tokens(w_orig, n_tokens):
     """The reference's fallback when no CROSS_ATTENTION_WEIGHT_<N> key exists (:96-101): bilinear
-    (align_corners=True) by 1/sqrt(H*W/N), then 1-D nearest to N. Rare (sizes not divisible by 64),
-    host-side torch ops on the device tensor."""
-    img_h, img_w, nc = w_orig.shape
-    ratio = math.sqrt(img_h * img_w / n_tokens)
-    w = F.interpolate(w_orig.permute(2, 0, 1).unsqueeze(0), scale_factor=1 / ratio, mode="bilinear", align_corners=True)
-    w = F.interpolate(w.reshape(1, nc, -1), size=(n_tokens,), mode="nearest").permute(2, 1, 0).squeeze()
-    return w
+    (align_corners=True) by 1/sqrt(H*W/N), then 1-D nearest to N -- pww_resize_tokens on the device map. A batched
+    [n, H, W, T] map (paint_with_words_batch) gives [n, 1, N, T]."""
+    if w_orig.dim() == 4:
+        return torch.stack([ops.resize_tokens(w, n_tokens) for w in w_orig], dim=0).unsqueeze(1)
+    return ops.resize_tokens(w_orig, n_tokens)
+
+
+def refresh_orig_cache(context):
+    """Recompute the cached fallback maps of a request context IN PLACE (hipGraph mode: a new color map was copied into
+    the static CROSS_ATTENTION_WEIGHT_ORIG tensor; the captured graphs read the resized maps by address)."""
+    cache = context.get("_PWW_ORIG_CACHE")
+    w = context.get("CROSS_ATTENTION_WEIGHT_ORIG")
+    if not cache or not torch.is_tensor(w):
+        return
+    for n_img, t in cache.items():
+        t.copy_(_orig_weight_to_tokens(w, n_img))
 
 
 def _half(t, like_dtype):

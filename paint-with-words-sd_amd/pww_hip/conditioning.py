@@ -8,7 +8,7 @@ names follow the reference's so the call sites read the same.
 """
 import numpy as np
 import torch
-import torch.nn.functional as F
+import torch.nn.functional as F  # noqa: F401  (region-seed masks: _get_binary_mask)
 
 from . import ops
 
@@ -74,16 +74,9 @@ def _column_lists(table, token_lis, ratio_tag="8"):
 
 
 def gaussian_blur_mask(mask, sigma, ksize=39):
-    """_blur_image_mask (:307-312): torchvision GaussianBlur(39x39, sigma) semantics -- separable
-    Gaussian exp(-0.5 (x/sigma)^2) normalised, reflect padding -- as torch ops on the device mask."""
-    half = (ksize - 1) * 0.5
-    x = torch.linspace(-half, half, steps=ksize, device=mask.device, dtype=torch.float32)
-    k = torch.exp(-0.5 * (x / sigma) ** 2)
-    k = k / k.sum()
-    k2 = torch.mm(k[:, None], k[None, :])
-    p = ksize // 2
-    m = F.pad(mask[None, None].float(), [p, p, p, p], mode="reflect")
-    return F.conv2d(m, k2[None, None])[0, 0]
+    """_blur_image_mask (:307-312): torchvision GaussianBlur(39x39, sigma) semantics on the device mask
+    (pww_gauss_blur: two 1-D passes, reflect padding, fp64 accumulation)."""
+    return ops.gauss_blur(mask, sigma, ksize)
 
 
 def build_weight_maps(color_map_rgb, table, token_lis, device, extra_sigmas=None, with_orig=True):
@@ -94,14 +87,15 @@ def build_weight_maps(color_map_rgb, table, token_lis, device, extra_sigmas=None
     cols = _column_lists(table, token_lis)
     regions = [(c[0], c[1], c[2], s) for (_, c, s) in table]
     ratios = (8, 16, 32, 64)
+    blurred = {}
     if extra_sigmas:
-        # blurred regions need float masks (:338-340): build them on device, blur, then accumulate
+        # blurred regions need float masks (:338-340): build them on device, blur (pww_gauss_blur), then accumulate
         print("Use extra sigma to smooth mask", extra_sigmas)
         masks = []
         for r, (_, c, s) in enumerate(table):
             m = (rgb == torch.tensor(c, dtype=torch.uint8, device=device)).all(dim=-1).float() * s
             if r in extra_sigmas:
-                m = gaussian_blur_mask(m, extra_sigmas[r])
+                m = blurred[r] = gaussian_blur_mask(m, extra_sigmas[r])
             masks.append(m)
         masks = torch.stack(masks)
         outs = ops.mask_build_f32(masks, cols, ratios + ((1,) if with_orig else ()))
@@ -114,6 +108,7 @@ def build_weight_maps(color_map_rgb, table, token_lis, device, extra_sigmas=None
         maps[always_round(H / r) * always_round(W / r)] = outs[r]
     if with_orig:
         maps["ORIG"] = outs[1].reshape(H, W, len(token_lis))
+    maps["_BLURRED"] = blurred      # region ordinal -> blurred float mask (region seeding thresholds these, :300-304)
     return maps
 
 
@@ -126,15 +121,17 @@ def _warn_missing_colors(color_map_rgb, table):
 
 
 def _encode_text_color_inputs(text_encoder, tokenizer, device, color_map_image, color_context, input_prompt,
-                              unconditional_input_prompt, dtype=None):
+                              unconditional_input_prompt, dtype=None, use_sigma=True):
     """:315-388 with the weight maps built by the HIP mask kernel. Returns
     (extra_seeds, seperated_word_contexts, encoder_hidden_states, uncond_encoder_hidden_states);
-    `seperated_word_contexts` is the region table [(token_ids, (r,g,b), strength)] (the reference
-    returns full-resolution float masks here; the only consumer, region seeding :451, gets what it
-    needs from the table + color map)."""
+    `seperated_word_contexts` is (region table [(token_ids, (r,g,b), strength)], rgb, {ordinal: blurred mask}) (the
+    reference returns full-resolution float masks here; the only consumer, region seeding :451, gets what it
+    needs from the table + color map, plus the blurred masks of the regions that carry a sigma)."""
     text_input = tokenizer([input_prompt], padding="max_length", max_length=tokenizer.model_max_length,
                            truncation=True, return_tensors="pt")
     color_context, extra_seeds, extra_sigmas = _extract_seed_and_sigma_from_context(color_context)
+    if not use_sigma:      # the pipeline classes parse the sigma tail and drop it (reference :574): no blur there
+        extra_sigmas = {}
     rgb = np.array(color_map_image.convert("RGB")) if hasattr(color_map_image, "convert") else np.asarray(color_map_image)
     height, width = rgb.shape[:2]
     table = _parse_regions(color_context, tokenizer)
@@ -143,9 +140,11 @@ def _encode_text_color_inputs(text_encoder, tokenizer, device, color_map_image, 
     if table:
         _warn_missing_colors(rgb, table)
         maps = build_weight_maps(rgb, table, token_lis, device, extra_sigmas)
+        blurred = maps.pop("_BLURRED")
     else:   # empty color_context (:242-243): all-zero maps
         maps = {k: torch.zeros((k, len(token_lis)), dtype=torch.float32, device=device) for k in keys}
         maps["ORIG"] = torch.zeros((height, width, len(token_lis)), dtype=torch.float32, device=device)
+        blurred = {}
 
     cond_embeddings = text_encoder(text_input.input_ids.to(device))[0]
     uncond_input = tokenizer([unconditional_input_prompt], padding="max_length",
@@ -159,16 +158,22 @@ def _encode_text_color_inputs(text_encoder, tokenizer, device, color_map_image, 
     for k in keys:
         encoder_hidden_states[f"CROSS_ATTENTION_WEIGHT_{k}"] = maps[k]
         uncond_encoder_hidden_states[f"CROSS_ATTENTION_WEIGHT_{k}"] = 0
-    return extra_seeds, (table, rgb), encoder_hidden_states, uncond_encoder_hidden_states
+    return extra_seeds, (table, rgb, blurred), encoder_hidden_states, uncond_encoder_hidden_states
 
 
-def _get_binary_mask(table_rgb, extra_seeds, dtype, size):
-    """:300-304: per seeded region, (mask > 0) bilinearly resized (align_corners=False) to `size`."""
-    table, rgb = table_rgb
+def _get_binary_mask(region_info, extra_seeds, dtype, size):
+    """:300-304: per seeded region, (mask > 0) bilinearly resized (align_corners=False) to `size`. The reference
+    thresholds the masks AFTER _blur_image_mask has replaced the blurred ones in place (:338-340), so a region given
+    as "text,strength,seed,sigma" seeds the dilated area its blur reaches."""
+    table, rgb = region_info[0], region_info[1]
+    blurred = region_info[2] if len(region_info) > 2 else {}
     img = torch.as_tensor(rgb)
     out = []
     for k in extra_seeds.keys():
         _, color, strength = table[k]
-        m = ((img == torch.tensor(color, dtype=img.dtype)).all(dim=-1).float() * strength > 0).to(dtype)
+        if k in blurred:
+            m = (blurred[k].cpu() > 0).to(dtype)
+        else:
+            m = ((img == torch.tensor(color, dtype=img.dtype)).all(dim=-1).float() * strength > 0).to(dtype)
         out.append(F.interpolate(m[None, None], size=size, mode="bilinear"))
     return out

@@ -11,6 +11,7 @@ per-link bound: few big transfers), (b) per request a broadcast of the raw color
 import os
 import pickle
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -87,14 +88,16 @@ def build_and_broadcast(build_fn, skeleton_fn, device, dtype, src=0, group=None)
 
 
 def broadcast_request(payload, device, src=0, group=None):
-    """Broadcast a request (color map uint8 array + python metadata) from `src`.
-    payload on src: dict with 'rgb' (uint8 numpy [H,W,3]) and picklable metadata; None elsewhere."""
+    """Broadcast a request from `src`: every numpy array in the payload dict (the uint8 color map 'rgb', and for
+    inpainting the mask and the init image) travels as a tensor broadcast, everything else (color_context, prompt ...)
+    pickled in one byte tensor. payload on src: dict; None elsewhere. Returns the dict on every rank."""
     if not (dist.is_available() and dist.is_initialized()):
         return payload
     rank = dist.get_rank(group)
     if rank == src:
-        meta = {k: v for k, v in payload.items() if k != "rgb"}
-        meta["_rgb_shape"] = tuple(payload["rgb"].shape)
+        arrays = {k: np.ascontiguousarray(v) for k, v in payload.items() if isinstance(v, np.ndarray)}
+        meta = {k: v for k, v in payload.items() if k not in arrays}
+        meta["_arrays"] = [(k, tuple(a.shape), str(a.dtype)) for k, a in arrays.items()]
         blob = pickle.dumps(meta)
         head = torch.tensor([len(blob)], dtype=torch.int64, device=device)
     else:
@@ -106,13 +109,13 @@ def broadcast_request(payload, device, src=0, group=None):
         meta_t = torch.empty(int(head.item()), dtype=torch.uint8, device=device)
     dist.broadcast(meta_t, src=src, group=group)
     meta = pickle.loads(meta_t.cpu().numpy().tobytes())
-    shape = meta.pop("_rgb_shape")
-    if rank == src:
-        rgb = torch.as_tensor(payload["rgb"], dtype=torch.uint8).to(device).contiguous()
-    else:
-        rgb = torch.empty(shape, dtype=torch.uint8, device=device)
-    dist.broadcast(rgb, src=src, group=group)
-    meta["rgb"] = rgb.cpu().numpy()
+    for key, shape, dtype in meta.pop("_arrays"):
+        if rank == src:
+            t = torch.from_numpy(arrays[key]).to(device).contiguous()
+        else:
+            t = torch.empty(shape, dtype=getattr(torch, dtype), device=device)
+        dist.broadcast(t, src=src, group=group)
+        meta[key] = t.cpu().numpy()
     return meta
 
 

@@ -252,6 +252,64 @@ def mask_build_f32(masks, cols, ratios=(8, 16, 32, 64)):
     return outs
 
 
+def resize_tokens(w_orig, n_tokens):
+    """CROSS_ATTENTION_WEIGHT_ORIG [H, W, T] (fp32, device) -> [n_tokens, T]: the reference's fallback resize
+    (paint_with_words.py:96-101). The intermediate size is computed like torch does for `scale_factor`."""
+    import math
+    _require_gpu(w_orig)
+    if w_orig.dim() != 3 or w_orig.dtype != torch.float32:
+        raise PwwHipError("resize_tokens needs an fp32 [H, W, T] map")
+    w_orig = w_orig.contiguous()
+    H, W, T = w_orig.shape
+    ratio = math.sqrt(H * W / n_tokens)
+    oh, ow = int(math.floor(H * (1 / ratio))), int(math.floor(W * (1 / ratio)))
+    out = torch.empty((n_tokens, T), dtype=torch.float32, device=w_orig.device)
+    with torch.cuda.device(w_orig.device):
+        _lib.check(_lib.load().pww_resize_tokens(_ptr(w_orig), H, W, T, oh, ow, int(n_tokens), _ptr(out), _stream()), "pww_resize_tokens")
+    return out
+
+
+def gaussian_kernel1d(sigma, ksize=39):
+    """torchvision's _get_gaussian_kernel1d in fp32: exp(-0.5 (x / sigma)^2) on linspace(-h, h, ksize), normalised."""
+    half = (ksize - 1) * 0.5
+    x = torch.linspace(-half, half, steps=ksize, dtype=torch.float32)
+    pdf = torch.exp(-0.5 * (x / sigma).pow(2))
+    return pdf / pdf.sum()
+
+
+def gauss_blur(mask, sigma, ksize=39):
+    """GaussianBlur(ksize x ksize, sigma) with reflect padding of one fp32 [H, W] device mask (paint_with_words.py:307-312)."""
+    _require_gpu(mask)
+    if mask.dim() != 2:
+        raise PwwHipError("gauss_blur needs an [H, W] mask")
+    mask = mask.to(torch.float32).contiguous()
+    H, W = mask.shape
+    k = gaussian_kernel1d(float(sigma), ksize).to(mask.device)
+    tmp = torch.empty((H, W), dtype=torch.float64, device=mask.device)
+    out = torch.empty_like(mask)
+    with torch.cuda.device(mask.device):
+        _lib.check(_lib.load().pww_gauss_blur(_ptr(mask), _ptr(out), H, W, _ptr(k), int(ksize), _ptr(tmp), _stream()), "pww_gauss_blur")
+    return out
+
+
+def inpaint_prep(rgb, mask, lat_h, lat_w):
+    """uint8 init image [H, W, 3] + uint8 mask [H, W] (device) -> (mask [1,1,H,W], masked_image [1,3,H,W], latent-size
+    mask [1,1,h,w]) fp32, as paint_with_words_inpaint.py:92-106 / :115 compute them."""
+    _require_gpu(rgb, mask)
+    if rgb.dtype != torch.uint8 or mask.dtype != torch.uint8 or rgb.dim() != 3 or rgb.shape[2] != 3 or tuple(mask.shape) != tuple(rgb.shape[:2]):
+        raise PwwHipError("inpaint_prep needs uint8 rgb [H, W, 3] and uint8 mask [H, W]")
+    rgb, mask = rgb.contiguous(), mask.contiguous()
+    H, W = mask.shape
+    dev = rgb.device
+    m = torch.empty((1, 1, H, W), dtype=torch.float32, device=dev)
+    masked = torch.empty((1, 3, H, W), dtype=torch.float32, device=dev)
+    ml = torch.empty((1, 1, lat_h, lat_w), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().pww_inpaint_prep(_ptr(rgb), _ptr(mask), H, W, int(lat_h), int(lat_w), _ptr(m), _ptr(masked), _ptr(ml), _stream()),
+                   "pww_inpaint_prep")
+    return m, masked, ml
+
+
 def cfg_combine(cond, uncond, guidance_scale):
     """uncond + g * (cond - uncond) in fp32 (returns fp32)."""
     _require_gpu(cond, uncond)

@@ -15,7 +15,7 @@ Three execution modes over the SAME arithmetic:
 import torch
 
 from . import ops
-from .attention import install, refresh_kv_cache, ROW_GATE, KV_CACHE
+from .attention import install, refresh_kv_cache, refresh_orig_cache, ROW_GATE, KV_CACHE
 
 
 def initial_latents(seed, in_channels, height, width, region_masks=None, extra_seeds=None, batch_seeds=None):
@@ -38,16 +38,66 @@ def initial_latents(seed, in_channels, height, width, region_masks=None, extra_s
     return torch.cat(out, dim=0)
 
 
+def _as_list(x, n):
+    """One context dict per image: a single dict serves every image of the batch."""
+    if isinstance(x, (list, tuple)):
+        if len(x) not in (1, n):
+            raise ValueError("got %d context dicts for %d images" % (len(x), n))
+        return list(x) if len(x) == n else [x[0]] * n
+    return [x] * n
+
+
 def _fold_context(cond, uncond, n_images, device):
-    """Build the single dict of a folded call: rows [cond x n, uncond x n]."""
-    c, u = cond["CONTEXT_TENSOR"], uncond["CONTEXT_TENSOR"]
-    c = c.expand(n_images, -1, -1) if c.shape[0] == 1 else c
-    u = u.expand(n_images, -1, -1) if u.shape[0] == 1 else u
-    folded = dict(cond)
+    """Build the single dict of a folded call: rows [cond x n, uncond x n]. `cond` / `uncond`: one dict, or one dict per
+    image (paint_with_words_batch: per-image prompts and color maps). Per-image weight maps are stacked to
+    [2n, 1, N, 77] -- the kernels take the image axis through bias_stride[0] -- with zeros for the unconditional rows
+    (their gate is 0, the values are never used); a shared map stays [N, 77]."""
+    conds, unconds = _as_list(cond, n_images), _as_list(uncond, n_images)
+    shared = all(c is conds[0] for c in conds)
+
+    def rows(dicts):
+        if all(d is dicts[0] for d in dicts):
+            t = dicts[0]["CONTEXT_TENSOR"]
+            return t.expand(n_images, -1, -1) if t.shape[0] == 1 else t
+        return torch.cat([d["CONTEXT_TENSOR"] for d in dicts], dim=0)
+
+    folded = dict(conds[0])
     folded[KV_CACHE] = {}
-    folded["CONTEXT_TENSOR"] = torch.cat([c, u], dim=0).contiguous()
+    folded.pop("_PWW_ORIG_CACHE", None)
+    folded["CONTEXT_TENSOR"] = torch.cat([rows(conds), rows(unconds)], dim=0).contiguous()
     folded[ROW_GATE] = torch.cat([torch.ones(n_images), torch.zeros(n_images)]).to(device=device, dtype=torch.float32)
+    if not shared:
+        for key in [k for k in conds[0] if k.startswith("CROSS_ATTENTION_WEIGHT_")]:
+            maps = [c[key] for c in conds]
+            if not all(torch.is_tensor(m) for m in maps):
+                raise ValueError("per-image contexts must all carry a tensor for %s" % key)
+            w = torch.stack(maps, dim=0)                       # [n, N, 77]  (ORIG: [n, H, W, 77])
+            w = torch.cat([w, torch.zeros_like(w)], dim=0)
+            folded[key] = w if key.endswith("_ORIG") else w.unsqueeze(1)
     return folded
+
+
+def weight_function_signature(f):
+    """What a captured hipGraph depends on in a weight function: its code and the constants it can see (closure cells,
+    defaults, numeric globals it names). The reference's callers pass a FRESH lambda per request (runner.py:104,
+    gradio_pww.py:43), so identity is useless as a cache key; two lambdas with the same code and constants replay the
+    same graphs, and a changed constant (the graphs bake `c0 * g(sigma)` into kernel arguments) re-captures. Values that
+    are not plain numbers / strings are keyed by identity."""
+    def atom(v):
+        if isinstance(v, (int, float, str, bool, bytes, type(None))):
+            return ("v", type(v).__name__, v)
+        if isinstance(v, tuple) and all(isinstance(x, (int, float, str, bool, type(None))) for x in v):
+            return ("t", v)
+        return ("id", id(v))
+    code = getattr(f, "__code__", None)
+    if code is None:       # callable object / builtin: identity
+        return ("callable", id(f))
+    consts = tuple(atom(c) if not hasattr(c, "co_code") else ("code", c.co_code, c.co_names) for c in code.co_consts)
+    cells = tuple(atom(c.cell_contents) for c in (f.__closure__ or ()))
+    defaults = tuple(atom(v) for v in (f.__defaults__ or ())) + tuple(sorted((k, atom(v)) for k, v in (f.__kwdefaults__ or {}).items()))
+    g = getattr(f, "__globals__", {})
+    globs = tuple((n, atom(g[n])) for n in code.co_names if n in g and isinstance(g[n], (int, float, str, bool)))
+    return ("code", code.co_code, consts, code.co_names, code.co_varnames[:code.co_argcount], cells, defaults, globs)
 
 
 class _GraphedUNet:
@@ -102,10 +152,10 @@ class PwWSampler:
     def _static_context(self, folded, weight_function, latents, timesteps):
         """Captured graphs read the context tensors by ADDRESS: keep one set of static tensors alive
         and copy each new request's values into them; rebuild the graphs when the geometry, the
-        weight function (its constants are baked into kernel arguments) or the schedule changes."""
+        weight function (code or constants: they are baked into kernel arguments) or the schedule changes."""
         def tensor_sig(d):
             return tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in d.items() if torch.is_tensor(v)))
-        sig = (id(weight_function), tuple(latents.shape), tuple(float(t) for t in timesteps), tensor_sig(folded))
+        sig = (weight_function_signature(weight_function), tuple(latents.shape), tuple(float(t) for t in timesteps), tensor_sig(folded))
         if sig != self._graph_sig:
             self._graphed.graphs.clear()
             self._graph_sig = sig
@@ -115,6 +165,7 @@ class PwWSampler:
                 if torch.is_tensor(v):
                     self._static_folded[k].copy_(v)
             refresh_kv_cache(self._static_folded)     # new prompt embedding -> new K|V, same addresses
+            refresh_orig_cache(self._static_folded)   # new color map -> new fallback maps, same addresses
         return self._static_folded
 
     def _sigma_and_index(self, i, t):
@@ -129,14 +180,16 @@ class PwWSampler:
     @torch.no_grad()
     def sample(self, cond, uncond, latents, timesteps, guidance_scale, weight_function, extra_channels=None,
                on_step=None):
-        """latents: [n_images, C, h, w] already scaled by init_noise_sigma (or noised for img2img).
+        """cond / uncond: the two context dicts of the PwW protocol, or one dict per image (per-image prompts / maps).
+        latents: [n_images, C, h, w] already scaled by init_noise_sigma (or noised for img2img).
         extra_channels: inpaint's cat([mask, masked_image_latents]) ([n or 1, 5, h, w]) or None."""
         sch, unet, dev = self.scheduler, self.unet, latents.device
         n = latents.shape[0]
         udt = unet.dtype if hasattr(unet, "dtype") else next(unet.parameters()).dtype
+        conds, unconds = _as_list(cond, n), _as_list(uncond, n)
         if self.mode == "eager":   # per-request caches of the fused K|V projections (prompt constant over the steps)
-            cond.setdefault(KV_CACHE, {}).clear()
-            uncond.setdefault(KV_CACHE, {}).clear()
+            for d in conds + unconds:
+                d.setdefault(KV_CACHE, {}).clear()
         folded = None
         if self.mode != "eager":
             folded = _fold_context(cond, uncond, n, dev)
@@ -152,10 +205,10 @@ class PwWSampler:
             if self.mode == "eager":
                 eps_c, eps_u = [], []
                 for j in range(n):   # the reference is batch-1 (:445); images are independent
-                    cond.update({"SIGMA": sigma, "WEIGHT_FUNCTION": weight_function})
-                    eps_c.append(unet(x[j:j + 1], t, encoder_hidden_states=cond).sample)
-                    uncond.update({"SIGMA": sigma, "WEIGHT_FUNCTION": lambda w, sigma, qk: 0.0})
-                    eps_u.append(unet(x[j:j + 1], t, encoder_hidden_states=uncond).sample)
+                    conds[j].update({"SIGMA": sigma, "WEIGHT_FUNCTION": weight_function})
+                    eps_c.append(unet(x[j:j + 1], t, encoder_hidden_states=conds[j]).sample)
+                    unconds[j].update({"SIGMA": sigma, "WEIGHT_FUNCTION": lambda w, sigma, qk: 0.0})
+                    eps_u.append(unet(x[j:j + 1], t, encoder_hidden_states=unconds[j]).sample)
                 eps_c, eps_u = torch.cat(eps_c), torch.cat(eps_u)
             else:
                 folded.update({"SIGMA": sigma, "WEIGHT_FUNCTION": weight_function})
@@ -171,5 +224,5 @@ class PwWSampler:
                 noise_pred = eps_u + guidance_scale * (eps_c - eps_u)
             latents = sch.step(noise_pred, t, latents).prev_sample
             if on_step is not None:
-                on_step(i, latents)
+                on_step(i, t, latents)
         return latents

@@ -257,3 +257,127 @@ def test_public_api_matches_reference_signatures():
     assert list(inspect.signature(pw.inj_forward).parameters) == ["self", "hidden_states", "context", "mask"]
     with pytest.raises(AssertionError):
         pww_load_tools(device="cpu")          # reference :142-144: a model path is required
+
+
+def test_pipeline_call_signatures_match_reference():
+    """The pipeline classes take the reference's parameters in the reference's ORDER with its defaults
+    (paint_with_words.py:631-655, paint_with_words_inpaint.py:341-361): positional callers and `image=` / `eta=` users
+    of the reference land on the same arguments here."""
+    import inspect
+    from paint_with_words import PaintWithWord_StableDiffusionPipeline as P, PaintWithWord_StableDiffusionInpaintPipeline as PI
+    ref = [("self", None), ("prompt", None), ("color_map_image", None), ("color_context", {}), ("weight_function", "f"), ("height", None), ("width", None),
+           ("num_inference_steps", 30), ("guidance_scale", 7.5), ("negative_prompt", ""), ("num_images_per_prompt", 1), ("eta", 0.5), ("seed", 0),
+           ("generator", None), ("image", None), ("latents", None), ("output_type", "pil"), ("return_dict", True), ("callback", None), ("callback_steps", 1)]
+    params = inspect.signature(P.__call__).parameters
+    assert list(params) == [n for n, _ in ref]
+    for n, d in ref[2:]:
+        if d != "f":
+            assert params[n].default == d, n
+    ref_i = [("self", None), ("prompt", None), ("image", None), ("mask_image", None), ("color_map_image", None), ("color_context", {}), ("weight_function", "f"),
+             ("height", None), ("width", None), ("num_inference_steps", 30), ("guidance_scale", 7.5), ("negative_prompt", ""), ("num_images_per_prompt", 1),
+             ("eta", 1.0), ("seed", 0), ("generator", None), ("latents", None), ("output_type", "pil"), ("return_dict", True), ("callback", None), ("callback_steps", 1)]
+    params = inspect.signature(PI.__call__).parameters
+    assert list(params) == [n for n, _ in ref_i]
+    for n, d in ref_i[2:]:
+        if d != "f":
+            assert params[n].default == d, n
+    assert list(inspect.signature(P.__init__).parameters) == ["self", "vae", "text_encoder", "tokenizer", "unet", "scheduler", "safety_checker",
+                                                              "feature_extractor", "requires_safety_checker"]
+    assert list(inspect.signature(P.from_pretrained).parameters) == ["save_dir", "kwargs"]
+    # the reference defines the classes inside the function modules: those import paths resolve too
+    from paint_with_words.paint_with_words import PaintWithWord_StableDiffusionPipeline as P2
+    from paint_with_words.paint_with_words_inpaint import PaintWithWord_StableDiffusionInpaintPipeline as PI2
+    assert P2 is P and PI2 is PI
+
+
+def test_weight_function_signature_survives_fresh_lambdas():
+    """The hipGraph cache key (pww_hip/sampler.py): the reference's callers build a fresh lambda per request
+    (runner.py:104, gradio_pww.py:43) -- same code and constants must give the same key, a changed constant (in the
+    code, a closure cell, a default or a numeric global) a different one."""
+    from pww_hip.sampler import weight_function_signature as sig
+
+    def make(c):
+        return lambda w, sigma, qk: c * w * math.log(1 + sigma) * qk.max()
+
+    def make_lit():
+        return lambda w, sigma, qk: 0.4 * w * math.log(1 + sigma) * qk.max()
+
+    assert make(0.4) is not make(0.4) and sig(make(0.4)) == sig(make(0.4))
+    assert sig(make(0.4)) != sig(make(0.5))
+    assert sig(make_lit()) == sig(make_lit())
+    assert sig(make_lit()) != sig(lambda w, sigma, qk: 0.5 * w * math.log(1 + sigma) * qk.max())
+    assert sig(make_lit()) != sig(lambda w, sigma, qk: 0.4 * w * math.log(1 + sigma) * qk.std())
+    f1 = lambda w, sigma, qk, k=2.0: k * w * qk.max()   # noqa: E731
+    f2 = lambda w, sigma, qk, k=3.0: k * w * qk.max()   # noqa: E731
+    assert sig(f1) != sig(f2)
+    assert sig(cases.weight_fn_runner) == sig(cases.weight_fn_runner) != sig(cases.weight_fn_std)
+    t = torch.ones(2)
+    assert sig(lambda w, s, qk: t * w) == sig(lambda w, s, qk: t * w)       # same captured object: same key
+
+
+def test_fold_context_per_image_maps():
+    """Folding a batch whose images have their OWN contexts (paint_with_words_batch): rows [cond..., uncond...], weight
+    maps stacked to [2n, 1, N, 77] with zero maps for the gated-out unconditional rows; a shared context stays [N, 77]."""
+    from pww_hip.sampler import _fold_context
+    from pww_hip.attention import ROW_GATE
+    def ctx(seed):
+        g = torch.Generator().manual_seed(seed)
+        return {"CONTEXT_TENSOR": torch.randn(1, 77, 8, generator=g), "CROSS_ATTENTION_WEIGHT_16": torch.rand(16, 77, generator=g),
+                "CROSS_ATTENTION_WEIGHT_ORIG": torch.rand(8, 8, 77, generator=g)}
+    conds = [ctx(1), ctx(2), ctx(3)]
+    unc = {"CONTEXT_TENSOR": torch.zeros(1, 77, 8), "CROSS_ATTENTION_WEIGHT_16": 0, "CROSS_ATTENTION_WEIGHT_ORIG": 0}
+    f = _fold_context(conds, unc, 3, "cpu")
+    assert f["CONTEXT_TENSOR"].shape == (6, 77, 8) and torch.equal(f["CONTEXT_TENSOR"][1], conds[1]["CONTEXT_TENSOR"][0])
+    assert f["CROSS_ATTENTION_WEIGHT_16"].shape == (6, 1, 16, 77)
+    assert torch.equal(f["CROSS_ATTENTION_WEIGHT_16"][2, 0], conds[2]["CROSS_ATTENTION_WEIGHT_16"]) and float(f["CROSS_ATTENTION_WEIGHT_16"][3:].abs().sum()) == 0.0
+    assert f["CROSS_ATTENTION_WEIGHT_ORIG"].shape == (6, 8, 8, 77)
+    assert f[ROW_GATE].tolist() == [1, 1, 1, 0, 0, 0]
+    shared = _fold_context(conds[0], unc, 3, "cpu")
+    assert shared["CROSS_ATTENTION_WEIGHT_16"] is conds[0]["CROSS_ATTENTION_WEIGHT_16"] and shared["CONTEXT_TENSOR"].shape == (6, 77, 8)
+    with pytest.raises(ValueError):
+        _fold_context(conds[:2], unc, 3, "cpu")
+
+
+def test_bench_spawns_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2 --config 3` outside a launcher re-executes itself as 2 ranks (torch.distributed.run,
+    127.0.0.1 rendezvous); on a box without GPUs `--dry-run` carries the run through rendezvous (gloo), the weight
+    broadcast of a 1/8-width model and the request broadcast, and prints the contract line with value null."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PWW_BENCH_VERBOSE="0")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(cases.REPO, "bench.py"), "--gpus", "2", "--config", "3", "--dry-run"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] is None and rec["dry_run"] is True and rec["scaling"] == "weak"
+    assert rec["config"]["weight_broadcast"]["broadcast_bytes"] > 0 and rec["config"]["images_per_step"] == 16
+    assert "8 vertical stripes" in rec["config"]["workload"] and rec["config"]["baseline_config"] == 3
+    # without --dry-run and without a GPU the run stops at the device check with a clear message
+    out = subprocess.run([sys.executable, os.path.join(cases.REPO, "bench.py"), "--config", "4"], capture_output=True, text=True, timeout=600, env=env)
+    if not torch.cuda.is_available():
+        assert out.returncode != 0 and "needs a HIP device" in (out.stderr + out.stdout)
+
+
+def test_bench_workloads_build():
+    """Every BASELINE workload of bench.py builds its request (arrays + color_context + prompt) and names its phrases."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pww_bench", os.path.join(cases.REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from sd_standin import HashTokenizer
+    from pww_hip.conditioning import _parse_regions, _column_lists, _extract_seed_and_sigma_from_context
+    tok = HashTokenizer()
+    for cfg_id, n_regions, size in ((2, 5, 512), (3, 8, 512), (4, 4, 512), (5, 12, 768)):
+        req = bench.make_request(cfg_id)
+        assert req["rgb"].shape == (size, size, 3) and len(req["context"]) == n_regions
+        ctx, seeds, _ = _extract_seed_and_sigma_from_context(dict(req["context"]))
+        assert len(seeds) == (12 if cfg_id == 5 else 0)
+        table = _parse_regions(ctx, tok)
+        ids = tok([req["prompt"]], padding="max_length", max_length=77, truncation=True, return_tensors="pt")["input_ids"][0].tolist()
+        cols = _column_lists(table, ids)
+        assert sum(1 for c in cols if c) >= n_regions          # every region's phrase occurs in the prompt
+        assert bench.CONFIGS[cfg_id]["wf"] in bench.weight_functions()
+    assert bench.make_request(4)["mask"].shape == (512, 512) and bench.make_request(4)["init"].shape == (512, 512, 3)
