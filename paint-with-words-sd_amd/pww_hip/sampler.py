@@ -110,9 +110,15 @@ class _GraphedUNet:
         self.static_in = None
         self.static_t = None
 
+    def reset(self):
+        """Drop every captured graph AND the memory pool they shared: once the last graph of a pool is gone the
+        allocator retires the pool, and capturing into the stale handle trips an internal assert."""
+        self.graphs.clear()
+        self.pool = None
+
     def __call__(self, key, x, t_value, context):
         if self.static_in is None or self.static_in.shape != x.shape or self.static_in.dtype != x.dtype:
-            self.graphs.clear()
+            self.reset()
             self.static_in = torch.empty_like(x)
             self.static_t = torch.zeros((), dtype=torch.float32, device=x.device)
         self.static_in.copy_(x)
@@ -157,7 +163,7 @@ class PwWSampler:
             return tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in d.items() if torch.is_tensor(v)))
         sig = (weight_function_signature(weight_function), tuple(latents.shape), tuple(float(t) for t in timesteps), tensor_sig(folded))
         if sig != self._graph_sig:
-            self._graphed.graphs.clear()
+            self._graphed.reset()
             self._graph_sig = sig
             self._static_folded = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in folded.items()}
         else:
@@ -184,6 +190,7 @@ class PwWSampler:
         latents: [n_images, C, h, w] already scaled by init_noise_sigma (or noised for img2img).
         extra_channels: inpaint's cat([mask, masked_image_latents]) ([n or 1, 5, h, w]) or None."""
         sch, unet, dev = self.scheduler, self.unet, latents.device
+        install(unet)      # the plug is a class-level patch (:193-195): put it back if somebody removed it since __init__
         n = latents.shape[0]
         udt = unet.dtype if hasattr(unet, "dtype") else next(unet.parameters()).dtype
         conds, unconds = _as_list(cond, n), _as_list(uncond, n)

@@ -381,3 +381,29 @@ def test_bench_workloads_build():
         assert sum(1 for c in cols if c) >= n_regions          # every region's phrase occurs in the prompt
         assert bench.CONFIGS[cfg_id]["wf"] in bench.weight_functions()
     assert bench.make_request(4)["mask"].shape == (512, 512) and bench.make_request(4)["init"].shape == (512, 512, 3)
+
+
+def test_reference_runner_script_resolves_against_this_package(tmp_path):
+    """The reference's OWN runner.py, unmodified (read from /root/reference, build box only), executed against this
+    package: `from paint_with_words import paint_with_words, PaintWithWord_StableDiffusionPipeline` and its keyword call
+    must resolve, pww_load_tools must run (stand-in diffusers / transformers / dotenv modules: tests/scripts/
+    reference_env.py), and without a GPU the run must stop exactly where the modules move to "cuda:0" -- not at an
+    ImportError / TypeError of the drop-in surface. The GPU box runs tests/scripts/runner_like.py to the saved image
+    (tests/test_round2_gpu.py::test_runner_script_end_to_end)."""
+    import subprocess
+    import sys
+    runner = "/root/reference/runner.py"
+    if not os.path.isfile(runner):
+        pytest.skip("reference checkout not present (GPU box)")
+    os.symlink("/root/reference/contents", tmp_path / "contents")
+    out = subprocess.run([sys.executable, os.path.join(cases.REPO, "tests", "scripts", "reference_env.py"), runner], cwd=tmp_path,
+                         capture_output=True, text=True, timeout=600)
+    if torch.cuda.is_available():
+        assert out.returncode == 0, out.stderr[-3000:]
+        return
+    err = out.stderr
+    assert out.returncode != 0
+    assert "ImportError" not in err and "TypeError" not in err and "AttributeError" not in err, err[-3000:]
+    assert "pww_load_tools" in err and "CompVis/stable-diffusion-v1-4" in out.stdout          # got as far as loading and placing the modules
+    assert ("Torch not compiled with CUDA enabled" in err or "No HIP GPUs are available" in err or "HIP" in err.splitlines()[-1]
+            or "CUDA" in err.splitlines()[-1]), err[-1500:]
