@@ -380,7 +380,8 @@ def main():
 
     from pww_hip import dist as pdist, ops
     import pww_hip
-    import paint_with_words.paint_with_words as pw_api
+    import importlib
+    pw_api = importlib.import_module("paint_with_words.paint_with_words")   # (the package re-exports a FUNCTION of the same name)
     from paint_with_words import paint_with_words_batch, paint_with_words_inpaint_batch
     from PIL import Image
 

@@ -375,6 +375,7 @@ int main(int argc, char **argv) {
         {"sd15_cross_n1024_d80", PWW_DTYPE_BF16, 2, 8, 1024, 77, 80, 1, false, 17, 0.7f},
         {"sd15_self_n4096_d40", PWW_DTYPE_BF16, 1, 8, 4096, 4096, 40, 0, true, 97, 1.0f},
         {"sd15_self_n4096_d40_f16_b2", PWW_DTYPE_F16, 2, 8, 4096, 4096, 40, 0, true, 193, 1.0f},
+        {"sd15_self_n4096_d40_bf16_b2", PWW_DTYPE_BF16, 2, 8, 4096, 4096, 40, 0, true, 193, 1.0f},   // the bench's dominant launch (bf16, 2 folded rows)
         {"sd15_cross_n4096_d40", PWW_DTYPE_BF16, 2, 8, 4096, 77, 40, 1, false, 97, 1.0f},
         {"sd15_cross_n4096_d40_b16", PWW_DTYPE_BF16, 16, 8, 4096, 77, 40, 1, false, 397, 1.0f},     // 8 images folded: several query blocks per workgroup
         {"cross_n64_d160_b72_split", PWW_DTYPE_F16, 72, 8, 64, 77, 160, 1, false, 7, 0.5f},        // more (image, head) pairs than resident workgroups: two-launch path
