@@ -229,7 +229,18 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
 //     independent of the reference. m_ref is always exactly representable in T, so the folded column is exact.
 //   * both 64-key sub-tiles of a stage are scored before one joint max / (rare) re-reference, and all MFMA operand
 //     fragments of the stage are requested from LDS up front.
+//   * bf16 ("range-free" mode, RF): a bf16 P keeps its 8 significant bits at ANY magnitude, and O^T / the row sum
+//     accumulate in fp32, so the reference never has to follow the running maximum at all: it is set ONCE, from the
+//     first stage (its row maximum plus 2^FOLD_HEADROOM), and the 41 max / compare instructions per stage -- a quarter
+//     of the loop's VALU work, sitting in a phase where the matrix pipe idles -- disappear (69.6 -> 64.0 us at
+//     N = 4096, B = 2). The only thing that can go wrong is range: a later score more than ~120 binary orders above the
+//     first stage's maximum would overflow exp2. That cannot be excluded for arbitrary inputs, so the row sums are
+//     checked at the end and a workgroup that sees a non-finite (or zero) sum recomputes its rows with the exact online
+//     softmax (exact_rows below): always correct, fast for every input whose logits span less than e^83.
 constexpr float FOLD_TAU = 6.f;
+constexpr float FOLD_HEADROOM = 8.f;
+template <typename T> struct RangeFree { static constexpr bool value = false; };
+template <> struct RangeFree<bf16> { static constexpr bool value = true; };
 
 template <typename T, int KS>
 __device__ __forceinline__ void fold_set_ref(typename Vec<T>::v8 (&qf)[KS], float mref, int hi, int D) {
@@ -316,8 +327,12 @@ __device__ __forceinline__ void fold_tile(f32x16 (&oacc)[DT], float &mref, bool 
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[0][kb][r] = key0 + key_of(kb, r, hi) < M ? s[0][kb][r] : -INFINITY;
     }
-    const float tmax = xhalf_max(max32(s[0], -INFINITY));   // finite: key0 < M
-    if (first || !__all(tmax <= FOLD_TAU)) fold_rereference<T, KS, DT, 1>(s, oacc, mref, qf, tmax, first, hi, D);
+    if constexpr (RangeFree<T>::value) {
+        if (first) fold_rereference<T, KS, DT, 1>(s, oacc, mref, qf, xhalf_max(max32(s[0], -INFINITY)) + FOLD_HEADROOM, true, hi, D);
+    } else {
+        const float tmax = xhalf_max(max32(s[0], -INFINITY));   // finite: key0 < M
+        if (first || !__all(tmax <= FOLD_TAU)) fold_rereference<T, KS, DT, 1>(s, oacc, mref, qf, tmax, first, hi, D);
+    }
     fold_exp_pv<T, DT, MASKED>(s[0], oacc, Vs, key0, M, l31, hi);
 }
 
@@ -396,13 +411,70 @@ __device__ __forceinline__ void fold_stage2(f32x16 (&oacc)[DT], float &mref, boo
     score_frags<T, KS>(s[1], k1, qf);
     load_vfrags<T, DT>(v1, cur + SUB_BYTES + KT::BYTES, l31, hi);   // lands during the max / check below
     __builtin_amdgcn_sched_barrier(0);
-    const float tmax = xhalf_max(max32(s[1], max32(s[0], -INFINITY)));
-    if (first || !__all(tmax <= FOLD_TAU)) fold_rereference<T, KS, DT, 2>(s, oacc, mref, qf, tmax, first, hi, D);
+    if constexpr (RangeFree<T>::value) {    // reference set once, from the first stage (see the header comment)
+        if (first) fold_rereference<T, KS, DT, 2>(s, oacc, mref, qf, xhalf_max(max32(s[1], max32(s[0], -INFINITY))) + FOLD_HEADROOM, true, hi, D);
+    } else {
+        const float tmax = xhalf_max(max32(s[1], max32(s[0], -INFINITY)));
+        if (first || !__all(tmax <= FOLD_TAU)) fold_rereference<T, KS, DT, 2>(s, oacc, mref, qf, tmax, first, hi, D);
+    }
     V8 pf[2][2];
     exp_tile<T>(pf, s[0]);
     pv_frags<T, DT>(pf, oacc, v0);
     exp_tile<T>(pf, s[1]);
     pv_frags<T, DT>(pf, oacc, v1);
+}
+
+// The exact path behind the range-free mode: the workgroup's rows again, from key 0, with the plain online softmax of
+// attn_fwd_kernel (running maximum in the raw-score domain, row sum from the ones column of V). Q is re-read unscaled and
+// its fragment column D is zero, so the ones the folded kernel keeps in column D of the K tile contribute nothing.
+template <typename T, int KS, int DT, int NSUB, int KPT, int VPT, typename SRD>
+__device__ __forceinline__ void exact_rows(f32x16 (&oacc)[DT], const AttnParams &p, const T *qrow_ptr, bool qvalid, char *smem,
+                                        const StagePlan<KPT, VPT> &plan, SRD srd_k, SRD srd_v, unsigned k_step, unsigned v_step,
+                                        int l31, int hi) {
+    typedef typename Vec<T>::v8 V8;
+    typedef KTile<KS> KT;
+    typedef VTile<DT> VT;
+    constexpr int SUB_BYTES = KT::BYTES + VT::BYTES;
+    constexpr int STAGE_BYTES = NSUB * SUB_BYTES;
+    constexpr int STAGE_KEYS = NSUB * KVBLK;
+    V8 qf[KS];
+    load_q_frags<T, KS>(qf, qrow_ptr, qvalid, hi, p.D);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    BiasRef bias;
+    const float c1 = p.scale_log2e;
+    const int nstage = (p.M + STAGE_KEYS - 1) / STAGE_KEYS, nfull = p.M / STAGE_KEYS;
+    u32x4 kreg[KPT];
+    u32x4 vreg[VPT];
+    __syncthreads();                                   // every wave is done with the stage buffers
+    stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);
+    stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
+    stage_load(kreg, vreg, plan, srd_k, srd_v, k_step, v_step);
+    __syncthreads();
+    int st = 0;
+    for (; st < nfull; ++st) {
+        char *cur = smem + (st & 1) * STAGE_BYTES;
+        stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem + ((st & 1) ^ 1) * STAGE_BYTES);
+        stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub)
+            attn_tile<T, KS, DT, false, false, true>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES, cur + sub * SUB_BYTES + KT::BYTES,
+                                                     st * STAGE_KEYS + sub * KVBLK, p.M, l31, hi, bias, 1.f, c1);
+        __syncthreads();
+    }
+    if (st < nstage) {
+        char *cur = smem + (st & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int key0 = st * STAGE_KEYS + sub * KVBLK;
+            if (key0 < p.M)
+                attn_tile<T, KS, DT, false, true, true>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES, cur + sub * SUB_BYTES + KT::BYTES,
+                                                        key0, p.M, l31, hi, bias, 1.f, c1);
+        }
+    }
 }
 
 template <typename T, int KS, int DT, int NW>
@@ -506,14 +578,39 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
 
     // softmax denominator: row D of O^T (tile D / 32, register (D % 32) / 2, held by the hi == 0 half)
     const int rl = p.D & 31, tl = p.D >> 5;
-    float lv = 0.f;
+    float lsum;
+    {
+        float lv = 0.f;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        const float c = rl == 8 ? oacc[dt][4] : oacc[dt][12];
-        lv = dt == tl ? c : lv;
+        for (int dt = 0; dt < DT; ++dt) {
+            const float c = rl == 8 ? oacc[dt][4] : oacc[dt][12];
+            lv = dt == tl ? c : lv;
+        }
+        const float other = __shfl_xor(lv, 32);
+        lsum = hi ? other : lv;
     }
-    const float other = __shfl_xor(lv, 32);
-    const float inv = 1.f / (hi ? other : lv);
+    if constexpr (RangeFree<T>::value) {
+        // range check of the range-free mode: a finite, positive row sum means no exp2 overflowed and no row vanished
+        // (and the accumulated O^T itself: a P just below the float range times |V| > 1 overflows the product, not the sum)
+        float asum = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asum += fabsf(oacc[dt][r]);     // inf or NaN anywhere makes the comparison below false
+        const bool bad = qvalid && !(lsum > 0.f && lsum < 3.0e38f && asum < 3.0e38f);
+        if (__syncthreads_or(bad)) {
+            exact_rows<T, KS, DT, NSUB, KPT, VPT>(oacc, p, Qp + (long)qrow * p.q_sn, qvalid, smem, plan, srd_k, srd_v, k_step, v_step, l31, hi);
+            float lv = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const float c = rl == 8 ? oacc[dt][4] : oacc[dt][12];
+                lv = dt == tl ? c : lv;
+            }
+            const float other = __shfl_xor(lv, 32);
+            lsum = hi ? other : lv;
+        }
+    }
+    const float inv = 1.f / lsum;
     if (qvalid) {
         T *orow = Op + (long)qrow * p.o_sn;
 #pragma unroll
@@ -525,277 +622,6 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
                     V4 out;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) out[j] = (T)(oacc[dt][g * 4 + j] * inv);
-                    *reinterpret_cast<V4 *>(orow + d) = out;
-                }
-            }
-        }
-    }
-}
-
-// ---- folded-reference kernel with the PV product on 16x16x32 MFMAs (d = 40) -------------------------------------
-// The 32x32x16 PV product pads the 41 useful rows of O^T (40 head dims + the row-sum column) to 64: 8 MFMAs per 64 keys
-// of which 36 % multiply zeros. On v_mfma_f32_16x16x32 the same product is 3 d-tiles x 2 row tiles = 12 MFMAs of half
-// the cost each (48 rows: 85 % useful), every V fragment feeds two MFMAs (one per 16-row tile), and O^T needs 24
-// accumulator registers instead of 32.
-//   * P comes out of the score MFMA with lane (hi, row) holding keys {8 hi + j} (registers 0-7) and {16 + 8 hi + j}
-//     (8-15) of a 32-key block. The 16x16x32 B operand wants lane (g, n) to hold 8 keys of row n of ONE 16-row tile:
-//     one v_permlane16_swap per register pair moves rows 16-31 of the first set against rows 0-15 of the second, after
-//     which lane group g holds keys kperm(g) + j with kperm = {0, 16, 8, 24} -- for rows 0-15 in one result, rows
-//     16-31 in the other. The contraction index may be permuted freely as long as the A operand uses the same order.
-//   * A operand: V^T[d = 16 dt + (lane & 15)][keys kperm(g) + j], two ds_read_b64_tr_b16 per fragment from the
-//     row-major V tile; rows 16 apart would share banks at ANY 16-byte-aligned row stride (16 * stride = 0 mod 256 B),
-//     so rows with bit 4 of the key set are skewed by 32 bytes.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-
-constexpr int V16_STRIDE = 192;                       // bytes per key row (48 columns used + skew)
-constexpr int V16_BYTES = KVBLK * V16_STRIDE;
-constexpr int V16_DT = 3;                             // 16-wide d tiles: 40 head dims + the ones column
-__device__ __forceinline__ int v16_skew(int key) { return (key & 16) ? 32 : 0; }
-
-template <typename T, int KS, int NT, int NSUB, int KPT, int VPT>
-__device__ __forceinline__ void make_plan16(StagePlan<KPT, VPT> &pl, int tid, int D, long k_sm, long v_sm) {
-    typedef KTile<KS> KT;
-    constexpr int SUB_BYTES = KT::BYTES + V16_BYTES;
-    constexpr int VCHK = V16_DT * 2;                  // 16-byte chunks per key row
-#pragma unroll
-    for (int i = 0; i < KPT; ++i) {
-        const int c = tid + i * NT;
-        const int key = c / KT::CHK, ch = c - key * KT::CHK;
-        pl.k_ok[i] = c < NSUB * KT::NCHUNK && ch * 8 < D;
-        pl.k_off[i] = pl.k_ok[i] ? (unsigned)((key * k_sm + ch * 8) * 2) : OOB_OFF;
-        pl.k_lds[i] = (key >> 6) * SUB_BYTES + (key & 63) * KT::STRIDE + ch * 16;
-    }
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-        const int c = tid + i * NT;
-        const int key = c / VCHK, ch = c - key * VCHK;
-        pl.v_ok[i] = c < NSUB * KVBLK * VCHK && ch * 8 < D;
-        pl.v_off[i] = pl.v_ok[i] ? (unsigned)((key * v_sm + ch * 8) * 2) : OOB_OFF;
-        pl.v_lds[i] = (key >> 6) * SUB_BYTES + KT::BYTES + (key & 63) * V16_STRIDE + v16_skew(key) + ch * 16;
-    }
-}
-
-// A fragments of one 64-key sub-tile: v[kb][dt] = V[keys kb*32 + kperm(g) + 0..7][d = 16 dt + (lane & 15)]
-template <typename T>
-__device__ __forceinline__ void load_vfrags16(typename Vec<T>::v8 (&vf)[2][V16_DT], const char *Vs, int lane) {
-    typedef __attribute__((address_space(3))) s16x4 *lds_p;
-    const int g = lane >> 4, i = lane & 15;
-    const int row = ((g & 1) << 4) | ((g >> 1) << 3);          // kperm(g) = {0, 16, 8, 24}
-    const char *vl = Vs + (row + (i >> 2)) * V16_STRIDE + ((g & 1) ? 32 : 0) + (i & 3) * 8;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int dt = 0; dt < V16_DT; ++dt) {
-            const char *a = vl + kb * 32 * V16_STRIDE + dt * 32;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a));
-            const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a + 4 * V16_STRIDE));
-            const s16x8 v = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
-            vf[kb][dt] = __builtin_bit_cast(typename Vec<T>::v8, v);
-        }
-}
-
-// O^T (two 16-row tiles x three 16-d tiles) += V^T P^T for one 64-key sub-tile
-template <typename T>
-__device__ __forceinline__ void pv16(const typename Vec<T>::v8 (&pf)[2][2], f32x4 (&oacc)[2][V16_DT],
-                                     const typename Vec<T>::v8 (&vf)[2][V16_DT]) {
-    typedef typename Vec<T>::v8 V8;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const u32x4 a = __builtin_bit_cast(u32x4, pf[kb][0]), b = __builtin_bit_cast(u32x4, pf[kb][1]);
-        u32x4 x, y;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const auto r = __builtin_amdgcn_permlane16_swap(a[i], b[i], false, false);
-            x[i] = r[0]; y[i] = r[1];
-        }
-        const V8 p0 = __builtin_bit_cast(V8, x), p1 = __builtin_bit_cast(V8, y);     // rows 0-15 / rows 16-31 of the wave
-#pragma unroll
-        for (int dt = 0; dt < V16_DT; ++dt) {
-            oacc[0][dt] = mfma16(vf[kb][dt], p0, oacc[0][dt]);
-            oacc[1][dt] = mfma16(vf[kb][dt], p1, oacc[1][dt]);
-        }
-    }
-}
-
-template <typename T, int KS, int NS>
-__device__ __forceinline__ void fold16_rereference(f32x16 (&s)[NS][2], f32x4 (&oacc)[2][V16_DT], float &mref,
-                                                   typename Vec<T>::v8 (&qf)[KS], float tmax, bool first, int hi, int D) {
-    asm volatile("; fold16_rereference: rare path" ::: "memory");     // keeps this a branch (see fold_rereference)
-    const float mnew = (first || tmax > FOLD_TAU) ? (float)(T)(mref + tmax) : mref;
-    const float delta = mnew - mref;
-    const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-    for (int n = 0; n < NS; ++n)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[n][kb][r] -= delta;
-    // the score layout keeps row (lane & 31) in a lane, the 16x16 result tiles keep row (lane & 15) of tile 0 / tile 1
-    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(alpha), __float_as_uint(alpha), false, false);
-    const float a0 = __uint_as_float(sw[0]), a1 = __uint_as_float(sw[1]);
-#pragma unroll
-    for (int dt = 0; dt < V16_DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { oacc[0][dt][r] *= a0; oacc[1][dt][r] *= a1; }
-    mref = mnew;
-    fold_set_ref<T, KS>(qf, mref, hi, D);
-}
-
-template <typename T, int KS, int SUB_BYTES>
-__device__ __forceinline__ void fold16_stage2(f32x4 (&oacc)[2][V16_DT], float &mref, bool first, typename Vec<T>::v8 (&qf)[KS],
-                                              const char *cur, int l31, int hi, int lane, int D) {
-    typedef typename Vec<T>::v8 V8;
-    typedef KTile<KS> KT;
-    V8 k0[2][KS], k1[2][KS], v0[2][V16_DT], v1[2][V16_DT];
-    load_kfrags<T, KS>(k0, cur, l31, hi);
-    load_kfrags<T, KS>(k1, cur + SUB_BYTES, l31, hi);
-    load_vfrags16<T>(v0, cur + KT::BYTES, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 s[2][2];
-    score_frags<T, KS>(s[0], k0, qf);
-    score_frags<T, KS>(s[1], k1, qf);
-    load_vfrags16<T>(v1, cur + SUB_BYTES + KT::BYTES, lane);
-    __builtin_amdgcn_sched_barrier(0);
-    const float tmax = xhalf_max(max32(s[1], max32(s[0], -INFINITY)));
-    if (first || !__all(tmax <= FOLD_TAU)) fold16_rereference<T, KS, 2>(s, oacc, mref, qf, tmax, first, hi, D);
-    V8 pf[2][2];
-    exp_tile<T>(pf, s[0]);
-    pv16<T>(pf, oacc, v0);
-    exp_tile<T>(pf, s[1]);
-    pv16<T>(pf, oacc, v1);
-}
-
-// one (possibly ragged) 64-key sub-tile of the tail stage
-template <typename T, int KS>
-__device__ __forceinline__ void fold16_tile(f32x4 (&oacc)[2][V16_DT], float &mref, bool first, typename Vec<T>::v8 (&qf)[KS],
-                                            const char *Ks, const char *Vs, int key0, int M, int l31, int hi, int lane, int D) {
-    typedef typename Vec<T>::v8 V8;
-    f32x16 s[1][2];
-    score_tile<T, KS>(s[0], qf, Ks, key0, M, l31, hi);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[0][kb][r] = key0 + key_of(kb, r, hi) < M ? s[0][kb][r] : -INFINITY;
-    const float tmax = xhalf_max(max32(s[0], -INFINITY));
-    if (first || !__all(tmax <= FOLD_TAU)) fold16_rereference<T, KS, 1>(s, oacc, mref, qf, tmax, first, hi, D);
-    V8 pf[2][2], vf[2][V16_DT];
-    exp_tile<T>(pf, s[0]);                 // masked keys: exp2(-inf) = 0, and their V rows are zeros (out-of-range loads)
-    load_vfrags16<T>(vf, Vs, lane);
-    pv16<T>(pf, oacc, vf);
-}
-
-template <typename T, int KS, int NW>
-__global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) attn_fwd_fold16_kernel(const AttnParams p) {
-    typedef typename Vec<T>::v8 V8;
-    typedef typename Vec<T>::v4 V4;
-    typedef KTile<KS> KT;
-    constexpr int NSUB = 2;
-    constexpr int NT = NW * 64;
-    constexpr int SUB_BYTES = KT::BYTES + V16_BYTES;
-    constexpr int STAGE_BYTES = NSUB * SUB_BYTES;
-    constexpr int STAGE_KEYS = NSUB * KVBLK;
-    constexpr int KPT = (NSUB * KT::NCHUNK + NT - 1) / NT;
-    constexpr int VPT = (NSUB * KVBLK * V16_DT * 2 + NT - 1) / NT;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int hi = lane >> 5, l31 = lane & 31;
-    const int BH = p.B * p.H;
-    const int bh = blockIdx.x % BH, qb = blockIdx.x / BH;
-    const int b = bh / p.H, h = bh - b * p.H;
-
-    const T *Qp = reinterpret_cast<const T *>(p.q) + b * p.q_sb + h * p.q_sh;
-    const T *Kp = reinterpret_cast<const T *>(p.k) + b * p.k_sb + h * p.k_sh;
-    const T *Vp = reinterpret_cast<const T *>(p.v) + b * p.v_sb + h * p.v_sh;
-    T *Op = reinterpret_cast<T *>(p.o) + b * p.o_sb + h * p.o_sh;
-
-    const int row0 = (qb * NW + wave) * 32;
-    const int qrow = row0 + l31;
-    V8 qf[KS];
-    load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qrow < p.N, hi, p.D);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) qf[ks][j] = (T)((float)qf[ks][j] * p.scale_log2e);
-
-    f32x4 oacc[2][V16_DT];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int dt = 0; dt < V16_DT; ++dt) oacc[rt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
-    float mref = 0.f;
-    bool first = true;
-
-    for (int i = tid * 16; i < 2 * STAGE_BYTES; i += NT * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0u, 0u, 0u, 0u};
-    __syncthreads();
-    {
-        const T one = (T)1.0f;
-        for (int i = tid; i < 2 * NSUB * KVBLK; i += NT) {
-            const int key = i & 63;
-            *reinterpret_cast<T *>(smem + (i >> 6) * SUB_BYTES + KT::BYTES + key * V16_STRIDE + v16_skew(key) + p.D * 2) = one;
-            *reinterpret_cast<T *>(smem + (i >> 6) * SUB_BYTES + key * KT::STRIDE + p.D * 2) = one;
-        }
-    }
-
-    StagePlan<KPT, VPT> plan;
-    make_plan16<T, KS, NT, NSUB, KPT, VPT>(plan, tid, p.D, p.k_sm, p.v_sm);
-    const auto srd_k = head_srd(Kp, p.M, p.k_sm, p.D);
-    const auto srd_v = head_srd(Vp, p.M, p.v_sm, p.D);
-    const unsigned k_step = (unsigned)(STAGE_KEYS * p.k_sm * 2), v_step = (unsigned)(STAGE_KEYS * p.v_sm * 2);
-    u32x4 kreg[KPT];
-    u32x4 vreg[VPT];
-    const int nstage = (p.M + STAGE_KEYS - 1) / STAGE_KEYS;
-    const int nfull = p.M / STAGE_KEYS;
-
-    stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);
-    stage_store<2, KPT, VPT>(kreg, vreg, plan, smem);
-    stage_load(kreg, vreg, plan, srd_k, srd_v, k_step, v_step);
-    __syncthreads();
-
-    int st = 0;
-    for (; st < nfull; ++st) {
-        char *cur = smem + (st & 1) * STAGE_BYTES;
-        char *nxt = smem + ((st & 1) ^ 1) * STAGE_BYTES;
-        stage_store<2, KPT, VPT>(kreg, vreg, plan, nxt);
-        stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
-        fold16_stage2<T, KS, SUB_BYTES>(oacc, mref, first, qf, cur, l31, hi, lane, p.D);
-        first = false;
-        __syncthreads();
-    }
-    if (st < nstage) {
-        char *cur = smem + (st & 1) * STAGE_BYTES;
-#pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub) {
-            const int key0 = st * STAGE_KEYS + sub * KVBLK;
-            if (key0 < p.M) {
-                fold16_tile<T, KS>(oacc, mref, first, qf, cur + sub * SUB_BYTES, cur + sub * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, lane, p.D);
-                first = false;
-            }
-        }
-    }
-
-    // epilogue: lane (g, n) of tile (rt, dt) holds O^T[d = 16 dt + 4 g + r][row = row0 + 16 rt + n]; the softmax denominator is the
-    // ones column d = D: tile D / 16, g = (D % 16) / 4 = 2, register 0
-    const int g = lane >> 4, n16 = lane & 15;
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        const float lsum = __shfl(oacc[rt][V16_DT - 1][0], 32 + n16);
-        const float inv = 1.f / lsum;
-        const int row = row0 + rt * 16 + n16;
-        if (row < p.N) {
-            T *orow = Op + (long)row * p.o_sn;
-#pragma unroll
-            for (int dt = 0; dt < V16_DT; ++dt) {
-                const int d = dt * 16 + g * 4;
-                if (d < p.D) {
-                    V4 out;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) out[j] = (T)(oacc[rt][dt][j] * inv);
                     *reinterpret_cast<V4 *>(orow + d) = out;
                 }
             }
@@ -861,30 +687,8 @@ static int fold_mode() {   // PWW_ATTN_FOLD: 0 = never, 1 = bf16 only (default),
     return mode;
 }
 
-static int pv16_mode() {   // PWW_ATTN_PV16: 1 = PV product of the d = 40 folded kernel on 16x16x32 MFMAs, 0 = 32x32x16 (A/B testing)
-    static int mode = -2;
-    if (mode == -2) { const char *e = getenv("PWW_ATTN_PV16"); mode = e ? atoi(e) : 0; }
-    return mode;
-}
-
 template <typename T, int KS, int DT, int NW>
 static int launch_attn_fold(const AttnParams &p, hipStream_t stream) {
-    if (p.D == 40 && pv16_mode() == 1) {
-        constexpr size_t lds16 = 2 * 2 * (KTile<KS>::BYTES + V16_BYTES);
-        const int qblocks16 = (p.N + NW * 32 - 1) / (NW * 32);
-        auto kern16 = attn_fwd_fold16_kernel<T, KS, NW>;
-        if (lds16 > 64 * 1024) {
-            static thread_local bool done16 = false;
-            if (!done16) {
-                if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16),
-                              "hipFuncSetAttribute"))
-                    return PWW_EHIP;
-                done16 = true;
-            }
-        }
-        hipLaunchKernelGGL(kern16, dim3((unsigned)(qblocks16 * p.B * p.H)), dim3(NW * 64), lds16, stream, p);
-        return check_hip(hipGetLastError(), "attn_fwd_fold16_kernel launch");
-    }
 
     constexpr size_t lds = 2 * 2 * (KTile<KS>::BYTES + VTile<DT>::BYTES);
     const int qblocks = (p.N + NW * 32 - 1) / (NW * 32);

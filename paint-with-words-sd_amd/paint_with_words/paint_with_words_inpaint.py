@@ -12,8 +12,14 @@ from PIL import Image
 
 import pww_hip
 from pww_hip import ops
+_pw_module_name = __name__.rsplit(".", 1)[0] + ".paint_with_words"      # the function-API module: its DEFAULT_MODE is read at call time
 from .paint_with_words import (LMSDiscreteScheduler, pww_load_tools, preprocess, _pil_from_latents,
-                               _encode_text_color_inputs, _sampler_for, _unet_dtype, _broadcast, DEFAULT_MODE)
+                               _encode_text_color_inputs, _sampler_for, _unet_dtype, _broadcast)
+
+
+def _mode():
+    import sys
+    return sys.modules[_pw_module_name].DEFAULT_MODE
 
 
 def _as_uint8_pixels(image, channels):
@@ -104,7 +110,7 @@ def _generate_inpaint(tools, device, color_contexts, color_map_images, mask_imag
                       num_inference_steps, guidance_scale, weight_function, unconditional_input_prompt, strength, shared):
     vae, unet, text_encoder, tokenizer, scheduler = tools
     n = len(seeds)
-    sampler = _sampler_for(unet, scheduler, DEFAULT_MODE)
+    sampler = _sampler_for(unet, scheduler, _mode())
     conds, unconds = [], []
     for i in range(1 if shared else n):
         width, height = init_images[i].size

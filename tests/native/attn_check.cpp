@@ -35,6 +35,7 @@ struct Case {
     bool self;       // K/V come from the same token set as Q (M == N)
     int row_step;    // check every row_step-th query row
     float qk_gain;   // scales Q so logits get a realistic spread
+    float late_outlier = 0.f;   // != 0: key row M - 5 of every image is multiplied by this (scores far above everything seen before)
 };
 
 template <typename T> static T *dalloc(size_t n) { T *p; HIPCHECK(hipMalloc(&p, n * sizeof(T) + 64)); return p; }
@@ -44,7 +45,11 @@ static void run_case(const Case &c, bool timing) {
     std::vector<uint16_t> q((size_t)B * N * C), k((size_t)B * M * C), v((size_t)B * M * C);
     std::vector<float> qf(q.size()), kf(k.size()), vf(v.size());
     for (size_t i = 0; i < q.size(); ++i) { q[i] = to_t(rng_normal() * c.qk_gain, c.dtype); qf[i] = from_t(q[i], c.dtype); }
-    for (size_t i = 0; i < k.size(); ++i) { k[i] = to_t(rng_normal(), c.dtype); kf[i] = from_t(k[i], c.dtype); }
+    for (size_t i = 0; i < k.size(); ++i) {
+        float kv = rng_normal();
+        if (c.late_outlier != 0.f && (int)((i / C) % M) == M - 5) kv *= c.late_outlier;
+        k[i] = to_t(kv, c.dtype); kf[i] = from_t(k[i], c.dtype);
+    }
     for (size_t i = 0; i < v.size(); ++i) { v[i] = to_t(rng_normal() + 0.1f * (float)(i % 7), c.dtype); vf[i] = from_t(v[i], c.dtype); }
     std::vector<float> bias, coeff;
     pww_attn_desc_t d; memset(&d, 0, sizeof(d));
@@ -404,6 +409,11 @@ int main(int argc, char **argv) {
         {"d40_n520_m129_cold", PWW_DTYPE_F16, 1, 8, 520, 129, 40, 0, false, 3, 0.05f},
         {"d40_n2048_b4_bf16", PWW_DTYPE_BF16, 4, 8, 2048, 2048, 40, 0, true, 61, 2.0f},
         {"d24_self_n200", PWW_DTYPE_BF16, 1, 4, 200, 200, 24, 0, true, 1, 2.0f},
+        // range-free bf16 mode of the folded kernel: one key near the END of the sequence scores ~100 binary orders above the first
+        // stage's maximum for many rows -> exp2 overflows in the fast path -> the workgroup must fall back to the exact online softmax
+        {"d40_late_outlier_bf16", PWW_DTYPE_BF16, 2, 4, 700, 700, 40, 0, true, 1, 1.0f, 120.f},
+        {"d40_late_outlier_n4096_bf16", PWW_DTYPE_BF16, 1, 8, 4096, 4096, 40, 0, true, 31, 1.0f, 120.f},
+        {"d40_mild_outlier_bf16", PWW_DTYPE_BF16, 2, 4, 700, 700, 40, 0, true, 1, 1.0f, 10.f},      // scaled logits to +-40: inside the range, fast path only
     };
     for (auto &c : cases) {
         const bool big = (long)c.N * c.M >= 1024L * 1024L || c.N >= 4096;
