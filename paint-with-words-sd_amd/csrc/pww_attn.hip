@@ -23,12 +23,73 @@
 
 namespace pww {
 
+// The exact path behind the range-free modes (RangeFree<T>, below): the workgroup's rows again, from key 0, with the plain
+// online softmax (running maximum in the raw-score domain; row sum from the ones column of V when ROWSUM_MFMA, else in
+// l_run). Q is re-read unscaled and its fragment columns >= D are zero, so the ones the folded kernel keeps in column D of
+// the K tile contribute nothing.
+template <typename T> struct RangeFree { static constexpr bool value = false; };
+template <> struct RangeFree<bf16> { static constexpr bool value = true; };
+
+template <typename T, int KS, int DT, int NSUB, bool ROWSUM_MFMA, int KPT, int VPT, typename SRD>
+__device__ __forceinline__ void exact_rows(f32x16 (&oacc)[DT], float &l_run, const AttnParams &p, const T *qrow_ptr, bool qvalid, char *smem,
+                                        const StagePlan<KPT, VPT> &plan, SRD srd_k, SRD srd_v, unsigned k_step, unsigned v_step,
+                                        int l31, int hi) {
+    typedef typename Vec<T>::v8 V8;
+    typedef KTile<KS> KT;
+    typedef VTile<DT> VT;
+    constexpr int SUB_BYTES = KT::BYTES + VT::BYTES;
+    constexpr int STAGE_BYTES = NSUB * SUB_BYTES;
+    constexpr int STAGE_KEYS = NSUB * KVBLK;
+    V8 qf[KS];
+    load_q_frags<T, KS>(qf, qrow_ptr, qvalid, hi, p.D);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY;
+    l_run = 0.f;
+    BiasRef bias;
+    const float c1 = p.scale_log2e;
+    const int nstage = (p.M + STAGE_KEYS - 1) / STAGE_KEYS, nfull = p.M / STAGE_KEYS;
+    u32x4 kreg[KPT];
+    u32x4 vreg[VPT];
+    __syncthreads();                                   // every wave is done with the stage buffers
+    stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);
+    stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
+    stage_load(kreg, vreg, plan, srd_k, srd_v, k_step, v_step);
+    __syncthreads();
+    int st = 0;
+    for (; st < nfull; ++st) {
+        char *cur = smem + (st & 1) * STAGE_BYTES;
+        stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem + ((st & 1) ^ 1) * STAGE_BYTES);
+        stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub)
+            attn_tile<T, KS, DT, false, false, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES, cur + sub * SUB_BYTES + KT::BYTES,
+                                                     st * STAGE_KEYS + sub * KVBLK, p.M, l31, hi, bias, 1.f, c1);
+        __syncthreads();
+    }
+    if (st < nstage) {
+        char *cur = smem + (st & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int key0 = st * STAGE_KEYS + sub * KVBLK;
+            if (key0 < p.M)
+                attn_tile<T, KS, DT, false, true, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES, cur + sub * SUB_BYTES + KT::BYTES,
+                                                        key0, p.M, l31, hi, bias, 1.f, c1);
+        }
+    }
+}
+
 // KG = key groups: with KG > 1 the workgroup has NW * KG waves; wave (rg, kg) owns query rows of row group rg and,
 // in every stage of KG sub-tiles, only sub-tile kg -- i.e. the KEYS of a stage are split over wave groups. This is
 // how a launch with few query rows (B = 2: two 32-row waves per SIMD) still fills 3 waves per SIMD; the KG partial
 // (m, O^T) states of a row group are merged once at the end through the (then free) LDS stage buffers.
-template <typename T, int KS, int DT, int NW, int NSUB, int KG, bool HAS_BIAS, bool ROWSUM_MFMA>
+// RF = range-free softmax (pww_attn_core.h: attn_tile_rf; bf16 without bias, KG == 1 only): no running maximum in the loop,
+// one range check at the end, exact_rows as the fallback.
+template <typename T, int KS, int DT, int NW, int NSUB, int KG, bool HAS_BIAS, bool ROWSUM_MFMA, bool RF = false>
 __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, HAS_BIAS>::value)) attn_fwd_kernel(const AttnParams p) {
+    static_assert(!RF || (KG == 1 && !HAS_BIAS && RangeFree<T>::value), "range-free mode: bf16, no bias, no key split");
     typedef typename Vec<T>::v8 V8;
     typedef typename Vec<T>::v4 V4;
     typedef KTile<KS> KT;
@@ -82,6 +143,7 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
     float m_run = -INFINITY;  // running row max of the raw logits, identical in both half-waves
     float l_run = 0.f;        // running row sum (VALU path only), PARTIAL per half-wave
+    float mc = 0.f;           // RF: -(reference * c1) - headroom, set by the row's first tile
 
     // head-dim padding columns are never staged: zero both buffers once; with ROWSUM_MFMA column D of every
     // V row is one (the PV MFMA then accumulates the softmax denominator in O^T row D)
@@ -121,6 +183,11 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
             attn_tile<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + kg * SUB_BYTES,
                                                                cur + kg * SUB_BYTES + KT::BYTES, st * STAGE_KEYS + kg * KVBLK,
                                                                p.M, l31, hi, bias, coeff, c1);
+        } else if constexpr (RF) {
+#pragma unroll
+            for (int sub = 0; sub < NSUB; ++sub)
+                attn_tile_rf<T, KS, DT, false, ROWSUM_MFMA>(oacc, mc, l_run, st == 0 && sub == 0, qf, cur + sub * SUB_BYTES,
+                                                            cur + sub * SUB_BYTES + KT::BYTES, st * STAGE_KEYS + sub * KVBLK, p.M, l31, hi, c1);
         } else {
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub)
@@ -141,9 +208,14 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) {
                 const int key0 = st * STAGE_KEYS + sub * KVBLK;
-                if (key0 < p.M)
-                    attn_tile<T, KS, DT, HAS_BIAS, true, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES,
-                                                                      cur + sub * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
+                if (key0 < p.M) {
+                    if constexpr (RF)
+                        attn_tile_rf<T, KS, DT, true, ROWSUM_MFMA>(oacc, mc, l_run, key0 == 0, qf, cur + sub * SUB_BYTES,
+                                                                   cur + sub * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, c1);
+                    else
+                        attn_tile<T, KS, DT, HAS_BIAS, true, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES,
+                                                                          cur + sub * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
+                }
             }
         }
     }
@@ -183,19 +255,35 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
     }
 
     // softmax denominator
-    float l_tot;
-    if (ROWSUM_MFMA) {   // row D of O^T: tile D / 32, register (D % 32) / 2, held by the hi == 0 half
-        const int rl = p.D & 31, tl = p.D >> 5;
-        float lv = 0.f;
+    auto row_sum = [&]() -> float {
+        if (ROWSUM_MFMA) {   // row D of O^T: tile D / 32, register (D % 32) / 2, held by the hi == 0 half
+            const int rl = p.D & 31, tl = p.D >> 5;
+            float lv = 0.f;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const float c = rl == 8 ? oacc[dt][4] : rl == 16 ? oacc[dt][8] : oacc[dt][12];
-            lv = dt == tl ? c : lv;
+            for (int dt = 0; dt < DT; ++dt) {
+                const float c = rl == 8 ? oacc[dt][4] : rl == 16 ? oacc[dt][8] : oacc[dt][12];
+                lv = dt == tl ? c : lv;
+            }
+            const float other = __shfl_xor(lv, 32);
+            return hi ? other : lv;
         }
-        const float other = __shfl_xor(lv, 32);
-        l_tot = hi ? other : lv;
-    } else {
-        l_tot = l_run + __shfl_xor(l_run, 32);
+        return l_run + __shfl_xor(l_run, 32);
+    };
+    float l_tot = row_sum();
+    if constexpr (RF) {
+        // range check of the range-free mode: finite, positive row sums and finite accumulators mean no exp2 overflowed and
+        // no row vanished; otherwise the workgroup redoes its rows exactly
+        float asum = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asum += fabsf(oacc[dt][r]);
+        const bool bad = qvalid && !(l_tot > 0.f && l_tot < 3.0e38f && asum < 3.0e38f);
+        if (__syncthreads_or(bad)) {
+            exact_rows<T, KS, DT, NSUB, ROWSUM_MFMA, KPT, VPT>(oacc, l_run, p, Qp + (long)qrow * p.q_sn, qvalid, smem, plan, srd_k, srd_v,
+                                                                k_step, v_step, l31, hi);
+            l_tot = row_sum();
+        }
     }
     // epilogue: normalise and write O[row][d]; register r of tile dt is d = dt*32 + (r&3) + 8*(r>>2) + 4*hi
     const float inv = 1.f / l_tot;
@@ -236,11 +324,9 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
 //     N = 4096, B = 2). The only thing that can go wrong is range: a later score more than ~120 binary orders above the
 //     first stage's maximum would overflow exp2. That cannot be excluded for arbitrary inputs, so the row sums are
 //     checked at the end and a workgroup that sees a non-finite (or zero) sum recomputes its rows with the exact online
-//     softmax (exact_rows below): always correct, fast for every input whose logits span less than e^83.
+//     softmax (exact_rows above): always correct, fast for every input whose logits span less than e^83.
 constexpr float FOLD_TAU = 6.f;
 constexpr float FOLD_HEADROOM = 8.f;
-template <typename T> struct RangeFree { static constexpr bool value = false; };
-template <> struct RangeFree<bf16> { static constexpr bool value = true; };
 
 template <typename T, int KS>
 __device__ __forceinline__ void fold_set_ref(typename Vec<T>::v8 (&qf)[KS], float mref, int hi, int D) {
@@ -424,59 +510,6 @@ __device__ __forceinline__ void fold_stage2(f32x16 (&oacc)[DT], float &mref, boo
     pv_frags<T, DT>(pf, oacc, v1);
 }
 
-// The exact path behind the range-free mode: the workgroup's rows again, from key 0, with the plain online softmax of
-// attn_fwd_kernel (running maximum in the raw-score domain, row sum from the ones column of V). Q is re-read unscaled and
-// its fragment column D is zero, so the ones the folded kernel keeps in column D of the K tile contribute nothing.
-template <typename T, int KS, int DT, int NSUB, int KPT, int VPT, typename SRD>
-__device__ __forceinline__ void exact_rows(f32x16 (&oacc)[DT], const AttnParams &p, const T *qrow_ptr, bool qvalid, char *smem,
-                                        const StagePlan<KPT, VPT> &plan, SRD srd_k, SRD srd_v, unsigned k_step, unsigned v_step,
-                                        int l31, int hi) {
-    typedef typename Vec<T>::v8 V8;
-    typedef KTile<KS> KT;
-    typedef VTile<DT> VT;
-    constexpr int SUB_BYTES = KT::BYTES + VT::BYTES;
-    constexpr int STAGE_BYTES = NSUB * SUB_BYTES;
-    constexpr int STAGE_KEYS = NSUB * KVBLK;
-    V8 qf[KS];
-    load_q_frags<T, KS>(qf, qrow_ptr, qvalid, hi, p.D);
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    BiasRef bias;
-    const float c1 = p.scale_log2e;
-    const int nstage = (p.M + STAGE_KEYS - 1) / STAGE_KEYS, nfull = p.M / STAGE_KEYS;
-    u32x4 kreg[KPT];
-    u32x4 vreg[VPT];
-    __syncthreads();                                   // every wave is done with the stage buffers
-    stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);
-    stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
-    stage_load(kreg, vreg, plan, srd_k, srd_v, k_step, v_step);
-    __syncthreads();
-    int st = 0;
-    for (; st < nfull; ++st) {
-        char *cur = smem + (st & 1) * STAGE_BYTES;
-        stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem + ((st & 1) ^ 1) * STAGE_BYTES);
-        stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
-#pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub)
-            attn_tile<T, KS, DT, false, false, true>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES, cur + sub * SUB_BYTES + KT::BYTES,
-                                                     st * STAGE_KEYS + sub * KVBLK, p.M, l31, hi, bias, 1.f, c1);
-        __syncthreads();
-    }
-    if (st < nstage) {
-        char *cur = smem + (st & 1) * STAGE_BYTES;
-#pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub) {
-            const int key0 = st * STAGE_KEYS + sub * KVBLK;
-            if (key0 < p.M)
-                attn_tile<T, KS, DT, false, true, true>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES, cur + sub * SUB_BYTES + KT::BYTES,
-                                                        key0, p.M, l31, hi, bias, 1.f, c1);
-        }
-    }
-}
-
 template <typename T, int KS, int DT, int NW>
 __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false>::value)) attn_fwd_fold_kernel(const AttnParams p) {
     typedef typename Vec<T>::v8 V8;
@@ -599,7 +632,8 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
             for (int r = 0; r < 16; ++r) asum += fabsf(oacc[dt][r]);     // inf or NaN anywhere makes the comparison below false
         const bool bad = qvalid && !(lsum > 0.f && lsum < 3.0e38f && asum < 3.0e38f);
         if (__syncthreads_or(bad)) {
-            exact_rows<T, KS, DT, NSUB, KPT, VPT>(oacc, p, Qp + (long)qrow * p.q_sn, qvalid, smem, plan, srd_k, srd_v, k_step, v_step, l31, hi);
+            float l_unused;
+            exact_rows<T, KS, DT, NSUB, true, KPT, VPT>(oacc, l_unused, p, Qp + (long)qrow * p.q_sn, qvalid, smem, plan, srd_k, srd_v, k_step, v_step, l31, hi);
             float lv = 0.f;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
@@ -631,6 +665,12 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
 
 // ---- host dispatch ---------------------------------------------------------------------------
 
+static int rf_mode() {   // PWW_ATTN_RF=0: bf16 self-attention with the running-maximum softmax instead of the range-free one (A/B testing)
+    static int mode = -2;
+    if (mode == -2) { const char *e = getenv("PWW_ATTN_RF"); mode = e ? atoi(e) : 1; }
+    return mode;
+}
+
 template <typename T, int KS, int DT, int NW, bool HAS_BIAS, bool ROWSUM_MFMA>
 static int launch_attn_rs(const AttnParams &p, hipStream_t stream) {
     // two 64-key sub-tiles per stage (one barrier per 128 keys) while the double buffer stays small enough
@@ -640,7 +680,9 @@ static int launch_attn_rs(const AttnParams &p, hipStream_t stream) {
     constexpr size_t lds = 2 * NSUB * (KTile<KS>::BYTES + VTile<DT>::BYTES);
     const int qblocks = (p.N + NW * 32 - 1) / (NW * 32);
     const dim3 grid((unsigned)(qblocks * p.B * p.H));
-    auto kern = attn_fwd_kernel<T, KS, DT, NW, NSUB, 1, HAS_BIAS, ROWSUM_MFMA>;
+    constexpr bool CAN_RF = !HAS_BIAS && RangeFree<T>::value && NW >= 4;     // (2-wave workgroups: small, latency-bound launches)
+    auto kern = (CAN_RF && rf_mode() == 1) ? attn_fwd_kernel<T, KS, DT, NW, NSUB, 1, HAS_BIAS, ROWSUM_MFMA, CAN_RF>
+                                           : attn_fwd_kernel<T, KS, DT, NW, NSUB, 1, HAS_BIAS, ROWSUM_MFMA, false>;
     if (lds > 64 * 1024) {
         static thread_local bool done = false;
         if (!done) {

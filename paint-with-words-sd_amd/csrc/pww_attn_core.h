@@ -300,4 +300,63 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
     }
 }
 
+// ---- range-free tile (bf16, no bias) ------------------------------------------------------------------------------------
+// A bf16 P keeps its 8 significant bits at any magnitude and O^T / the row sum accumulate in fp32, so the softmax
+// reference does not have to follow the running maximum: it is fixed by the FIRST tile of the row (its maximum plus
+// 2^RF_HEADROOM), and every later tile is  P = exp2(s * c1 + mc)  with no maximum, no compare and no O^T rescale. A
+// later score more than ~120 binary orders above that first maximum would overflow exp2: the kernels check the row
+// sums / accumulators once at the end and recompute the workgroup's rows with the exact online softmax in that case.
+constexpr float RF_HEADROOM = 8.f;
+
+template <typename T, int KS, int DT, bool MASKED, bool ROWSUM_MFMA>
+__device__ __forceinline__ void attn_tile_rf(f32x16 (&oacc)[DT], float &mc, float &l_run, bool first,
+                                             const typename Vec<T>::v8 (&qf)[KS], const char *Ks, const char *Vs,
+                                             int key0, int M, int l31, int hi, float c1) {
+    typedef typename Vec<T>::v8 V8;
+    f32x16 s[2];
+    score_tile<T, KS>(s, qf, Ks, key0, MASKED ? M : 0x7fffffff, l31, hi);
+    if (MASKED) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = key0 + key_of(kb, r, hi) < M ? s[kb][r] : -INFINITY;
+    }
+    if (first) {
+        asm volatile("; attn_tile_rf: reference from the first tile" ::: "memory");    // keep this a branch (no if-conversion into every tile)
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb][r]);
+        tmax = xhalf_max(tmax);                      // finite: key0 < M, at least one live key
+        mc = -(tmax * c1) - RF_HEADROOM;
+    }
+    const char *vl = Vs + vfrag_lane_off<DT>(hi * 32 + l31);
+    float psum = 0.f;
+    V8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c1, mc));
+            if (!ROWSUM_MFMA) psum += pv;
+            pf[kb][r >> 3][r & 7] = (T)pv;
+        }
+    }
+    if (!ROWSUM_MFMA) l_run += psum;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        if (!MASKED || key0 + kb * 32 < M) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const V8 vf = load_vfrag<T, DT>(vl, kb, k2, dt);
+                    oacc[dt] = mfma32(vf, pf[kb][k2], oacc[dt]);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace pww
