@@ -43,7 +43,7 @@ for p in (PKG, REPO, os.path.join(REPO, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")    # lets MIOpen take NHWC tensors as they are (see --nchw)
+os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")    # lets MIOpen take NHWC tensors as they are (see --memory-format)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -367,8 +367,10 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2, help="denoise steps timed for the CPU baseline (0 = skip)")
     ap.add_argument("--no-roofline-pass", action="store_true")
     ap.add_argument("--no-reference-ops", action="store_true", help="skip the unfused-torch-ops-on-this-GPU pass")
-    ap.add_argument("--nchw", action="store_true", help="keep the UNet in PyTorch's default NCHW memory format (default: channels_last, a stock "
-                                                        "PyTorch setting: MIOpen's bf16/fp16 convolutions are NHWC kernels, NCHW pays a transpose either side; +4.6 %%)")
+    ap.add_argument("--memory-format", default="auto", choices=["auto", "nchw", "channels_last"],
+                    help="memory format of the UNet (a stock PyTorch setting: MIOpen's bf16/fp16 convolutions are NHWC kernels, NCHW pays a "
+                         "transpose either side). auto = channels_last for the SD1.5 topologies (measured +4.6 %% at batch 1, +1..3 %% at "
+                         "batch 8), NCHW for SD2.1 at 768x768 (channels_last measured -6 %% there)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: spawn / rendezvous (gloo) / broadcast a 1/8-width model and the request, print the line with value null")
     args = ap.parse_args()
 
@@ -409,7 +411,8 @@ def main():
     tools, build_info = build_tools(device, dtype, cfg["scheduler"], cfg["model"], tiny=not on_gpu)
     log("tools built", build_info)
     vae, unet, text, tok, sched = tools
-    if not args.nchw:
+    channels_last = args.memory_format == "channels_last" or (args.memory_format == "auto" and cfg["model"] != "sd21")
+    if channels_last:
         unet.to(memory_format=torch.channels_last)
 
     # request: rank 0 owns the color map (and, for inpainting, the mask and the init image); every rank builds its own
@@ -442,7 +445,7 @@ def main():
                                "final latent (VAE decode excluded)" % (cfg["name"], cfg["denoise_steps"], cfg["scheduler"].upper(), n_unet_evals,
                                                                         args.guidance, cfg["wf"], cfg["batch"]),
                    "baseline_config": args.config, "mode": args.mode, "images_per_step": n_global,
-                   "stock_op_settings": "MIOpen find mode%s" % ("" if args.nchw else ", UNet in channels_last memory format"),
+                   "stock_op_settings": "MIOpen find mode%s" % (", UNet in channels_last memory format" if channels_last else ""),
                    "parallelism": "image-sharded x%d, no data-path collective" % world,
                    "weight_broadcast": build_info, "request_broadcast_s": round(req_bcast_s, 4)},
     }
