@@ -145,7 +145,7 @@ int pww_cross_attn_fwd_stat(const void *q, const void *k, const void *v, void *o
  *               ZERO before the first call. The kernel leaves it zero again (the last workgroup of an image to leave
  *               clears the image's words), so one buffer serves any number of calls -- of any shape it is large enough
  *               for -- issued on ONE stream, hipGraph replays included; calls that may overlap on different streams
- *               need a buffer each. Word B*H + B is an error flag: it becomes 1 if a hand-off ever timed out (50 ms;
+ *               need a buffer each. Word B*H + B is an error flag: it becomes 1 if a hand-off ever timed out (1 s;
  *               the affected outputs are NaN) -- re-zero the buffer then.
  *   workspace   caller-owned scratch, pww_cross_fused_workspace_bytes(desc) bytes, 8-byte aligned, uninitialised;
  *               only touched by the two-launch path below

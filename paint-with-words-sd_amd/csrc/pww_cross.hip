@@ -40,7 +40,8 @@ struct CrossParams {
     int nchunk;          // workgroups per (image, head)
 };
 
-constexpr unsigned long long SPIN_LIMIT_TICKS = 5000000ull;   // wall_clock64 runs at 100 MHz: 50 ms
+constexpr unsigned long long SPIN_LIMIT_TICKS = 100000000ull;   // wall_clock64 runs at 100 MHz: 1 s (the grid is sized to be resident:
+                                                                // the limit only bounds the impossible case, e.g. state words left dirty by an aborted launch)
 
 // a slot holds ~bits(value): zero = empty (no finite or infinite double has an all-ones bit pattern)
 __device__ __forceinline__ void slot_publish(unsigned long long *p, double v) {
