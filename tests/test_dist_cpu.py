@@ -46,12 +46,21 @@ def _worker(rank, world, port, out_dir):
     assert torch.equal(m2(x, torch.tensor(10.0), torch.zeros(1, 77, 64)).sample, ref2(x, torch.tensor(10.0), torch.zeros(1, 77, 64)).sample)
     # (b) request broadcast: color map + region table
     payload = None
+    rgb = (np.arange(64 * 48 * 3) % 251).astype(np.uint8).reshape(64, 48, 3)
     if rank == 0:
-        rgb = (np.arange(64 * 48 * 3) % 251).astype(np.uint8).reshape(64, 48, 3)
         payload = {"rgb": rgb, "context": {(1, 2, 3): "dog,1.0"}, "prompt": "a dog"}
     got = pdist.broadcast_request(payload, dev, src=0)
     assert got["prompt"] == "a dog" and got["context"] == {(1, 2, 3): "dog,1.0"}
     assert got["rgb"].shape == (64, 48, 3) and int(got["rgb"].sum()) == int(((np.arange(64 * 48 * 3) % 251).astype(np.uint8)).sum())
+    # (b') an inpainting request: color map + mask + init image travel as arrays, the rest pickled (bench.py --config 4)
+    payload = None
+    if rank == 0:
+        payload = {"rgb": rgb, "mask": (np.arange(64 * 48) % 256).astype(np.uint8).reshape(64, 48), "init": rgb[::-1].copy(),
+                   "context": {(1, 2, 3): "dog,1.0,7"}, "prompt": "a dog", "seeds": [81, 82]}
+    got = pdist.broadcast_request(payload, dev, src=0)
+    assert set(got) == {"rgb", "mask", "init", "context", "prompt", "seeds"} and got["seeds"] == [81, 82]
+    assert got["mask"].dtype == np.uint8 and got["mask"].shape == (64, 48) and int(got["mask"][1, 5]) == (48 + 5) % 256
+    assert got["init"].shape == (64, 48, 3) and np.array_equal(got["init"][::-1], got["rgb"])
     # (c) image sharding is contiguous, disjoint, complete, and seeds do not depend on the world size
     seeds = pdist.image_seeds(100, 5, rank, world)
     lat = torch.stack([torch.full((4, 2, 2), float(s)) for s in seeds]) if seeds else torch.zeros(0, 4, 2, 2)
