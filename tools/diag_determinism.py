@@ -11,12 +11,19 @@ import pww_cases as cases
 from gpu_util import install_unfused, uninstall_all
 dev = torch.device("cuda:0"); dt = torch.float16
 g = torch.Generator().manual_seed(0)
-for (B, H, N, M, D) in ((2, 8, 4096, 4096, 40), (1, 8, 4096, 4096, 40), (2, 8, 4096, 77, 40), (2, 4, 4096, 4096, 8), (2, 4, 1024, 77, 16)):
-    q = torch.randn(B, N, H * D, generator=g).to(dev, dt); k = torch.randn(B, M, H * D, generator=g).to(dev, dt); v = torch.randn(B, M, H * D, generator=g).to(dev, dt)
-    bias = torch.rand(N, M, generator=g).to(dev) if M == 77 else None
-    outs = [ops.attention(q, k, v, H, D ** -0.5, bias=bias).clone() for _ in range(4)]
-    st = [ops.qk_stats(q, k, H).clone() for _ in range(4)]
-    print("attention", (B, H, N, M, D), "bitwise equal:", all(torch.equal(outs[0], o) for o in outs[1:]), "| stats equal:", all(torch.equal(st[0], s) for s in st[1:]), flush=True)
+for dt in (torch.float16, torch.bfloat16):
+  for (B, H, N, M, D) in ((2, 8, 4096, 4096, 40), (1, 8, 4096, 4096, 40), (2, 8, 4096, 77, 40), (2, 4, 4096, 4096, 8), (2, 4, 1024, 77, 16)):
+      q = torch.randn(B, N, H * D, generator=g).to(dev, dt); k = torch.randn(B, M, H * D, generator=g).to(dev, dt); v = torch.randn(B, M, H * D, generator=g).to(dev, dt)
+      bias = torch.rand(N, M, generator=g).to(dev) if M == 77 else None
+      outs = [ops.attention(q, k, v, H, D ** -0.5, bias=bias).clone() for _ in range(4)]
+      st = [ops.qk_stats(q, k, H).clone() for _ in range(4)]
+      line = "attention %s bitwise equal: %s | stats equal: %s" % ((B, H, N, M, D), all(torch.equal(outs[0], o) for o in outs[1:]), all(torch.equal(st[0], s) for s in st[1:]))
+      if bias is not None:      # statistic formed in the attention launch (pww_cross_attn_fwd_fused): hand-off order must not leak into the result
+          scratch = ops.FusedScratch()
+          fo = [ops.attention(q, k, v, H, D ** -0.5, bias=bias, stat=(None, ops.STAT_STD, 0.3), scratch=scratch).clone() for _ in range(6)]
+          line += " | fused statistic launch equal: %s" % all(torch.equal(fo[0], o) for o in fo[1:])
+      print(line, flush=True)
+dt = torch.float16
 for name, inst in (("unfused-torch", install_unfused), ("hip", pww_hip.install)):
     vae, unet, text, tok, sch = cases.build_tools("tiny", dtype=dt, device=dev)
     inst(unet)
