@@ -449,7 +449,7 @@ def main():
                    "parallelism": "image-sharded x%d, no data-path collective" % world,
                    "weight_broadcast": build_info, "request_broadcast_s": round(req_bcast_s, 4)},
     }
-    if args.config != 2:
+    if args.config != 2 or cfg["denoise_steps"] != 30:     # (an overridden step count must not carry the headline's "30 steps" label)
         result["metric"] = "%dx%d images/sec (%d steps, CFG) %s+PwW" % (cfg["size"], cfg["size"], cfg["denoise_steps"],
                                                                        {"sd15": "SD1.5", "sd15_inpaint": "SD1.5-inpainting", "sd21": "SD2.1"}[cfg["model"]])
 

@@ -28,8 +28,14 @@ def init_from_env(device_type="cuda"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = "nccl" if device_type == "cuda" else "gloo"
+        # smoke-test hook for boxes with ONE GPU: PWW_DIST_ONE_DEVICE=1 puts every rank on cuda:0 and rendezvous over gloo
+        # (RCCL refuses two ranks on one device). Same code path above the backend; not a production mode.
+        one_device = device_type == "cuda" and os.environ.get("PWW_DIST_ONE_DEVICE") == "1"
+        if one_device:
+            backend, local = "gloo", 0
         if device_type == "cuda":
             torch.cuda.set_device(local)
+        if device_type == "cuda" and not one_device:
             dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
