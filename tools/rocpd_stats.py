@@ -1,5 +1,7 @@
 """Summarise a rocprofv3 rocpd sqlite database (kernel-trace) into a per-kernel stats table (markdown).
-Usage: python tools/rocpd_stats.py <results.db> [--top N] [--grid]"""
+Usage: python tools/rocpd_stats.py <results.db> [--top N] [--grid] [--split-b2b <kernel name substring>]
+--split-b2b: for one kernel, average duration of the launches that directly follow another launch of the SAME kernel
+(bench.py's roofline pass: 40 launches replayed back to back) and of all others (the launches inside the UNet workload)."""
 import sqlite3
 import sys
 
@@ -24,5 +26,22 @@ def main():
             100.0 * r[2] / total, r[2] / 1e6, r[1], r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, r[6], r[7], r[8], grid, r[11], name))
 
 
+def split_b2b(db, sub):
+    rows = db.cursor().execute("select name, start, end from kernels order by start").fetchall()
+    b2b, mixed = [], []
+    prev = None
+    for name, start, end in rows:
+        if sub in name:
+            (b2b if (prev is not None and sub in prev) else mixed).append((end - start) / 1e3)
+        prev = name
+    def stat(v):
+        v = sorted(v)
+        return "n=%d avg %.1f us, median %.1f, p10 %.1f, p90 %.1f" % (len(v), sum(v) / len(v), v[len(v) // 2], v[len(v) // 10], v[len(v) * 9 // 10]) if v else "n=0"
+    print("\n`%s`: launches that directly follow a launch of the same kernel (back-to-back pass): %s; all other launches (inside the workload): %s"
+          % (sub, stat(b2b), stat(mixed)))
+
+
 if __name__ == "__main__":
     main()
+    if "--split-b2b" in sys.argv:
+        split_b2b(sqlite3.connect(sys.argv[1]), sys.argv[sys.argv.index("--split-b2b") + 1])
