@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PWW_VERSION 110 /* 0.1.10: + pww_cross_attn_fwd_fused, pww_gauss_blur, pww_resize_tokens, pww_inpaint_prep */
+#define PWW_VERSION 111 /* 0.1.11: + pww_profile_arm / pww_profile_elapsed_us / pww_profile_reset (0.1.10: fused cross-attention, blur, resize, inpaint prep) */
 
 #define PWW_OK 0
 #define PWW_EINVAL (-22)
@@ -245,6 +245,18 @@ int pww_cfg_combine(const void *cond, const void *uncond, float guidance, float 
 /* Device workspace pww_qk_reduce needs from the caller for this problem (the attention entry points
    need none). */
 size_t pww_workspace_bytes(const pww_attn_desc_t *desc);
+
+/*
+ * Kernel-only timing of attention launches (measurement aid; no counterpart in the reference). pww_profile_arm() reserves a
+ * timing slot (its index >= 0 is returned; negative = error) and arms the calling thread: the NEXT self-/cross-attention kernel
+ * this thread launches through the library stamps the dispatch's own start and end device timestamps into the slot
+ * (hipExtLaunchKernelGGL) -- the duration rocprofv3 reports for that kernel, without host launch latency and without the gap
+ * between dispatches that an event pair recorded around a launch includes. pww_profile_elapsed_us() waits for that kernel and
+ * returns the duration; pww_profile_reset() releases all slots. Not for use during stream capture.
+ */
+int pww_profile_arm(void);
+int pww_profile_elapsed_us(int32_t slot, float *microseconds);
+void pww_profile_reset(void);
 
 #ifdef __cplusplus
 }

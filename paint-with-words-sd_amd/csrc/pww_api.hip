@@ -1,5 +1,7 @@
 // extern "C" surface of libpww_hip.so (declared in include/pww_hip.h) + error plumbing.
 #include <string.h>
+#include <mutex>
+#include <vector>
 #include "pww_common.h"
 
 namespace pww {
@@ -46,6 +48,56 @@ bool arch_ok() {
     return cached == 1;
 }
 
+// ---- kernel-only timing slots (pww_profile_*): event pairs owned by the library, handed to the next attention launch of the
+// arming thread (launch_attn_kernel in pww_common.h)
+struct ProfileSlot { hipEvent_t start, stop; bool used; };
+static std::mutex g_prof_mutex;
+static std::vector<ProfileSlot> g_prof_slots;
+static thread_local int g_prof_armed = -1;
+
+bool profile_take(hipEvent_t *start, hipEvent_t *stop) {
+    if (g_prof_armed < 0) return false;
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    ProfileSlot &sl = g_prof_slots[(size_t)g_prof_armed];
+    g_prof_armed = -1;
+    sl.used = true;
+    *start = sl.start;
+    *stop = sl.stop;
+    return true;
+}
+
+static int profile_arm() {
+    ProfileSlot sl{nullptr, nullptr, false};
+    if (check_hip(hipEventCreate(&sl.start), "hipEventCreate") || check_hip(hipEventCreate(&sl.stop), "hipEventCreate")) return PWW_EHIP;
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    g_prof_slots.push_back(sl);
+    g_prof_armed = (int)g_prof_slots.size() - 1;
+    return g_prof_armed;
+}
+
+static int profile_elapsed_us(int slot, float *us) {
+    hipEvent_t e0, e1;
+    {
+        std::lock_guard<std::mutex> lock(g_prof_mutex);
+        if (!us || slot < 0 || (size_t)slot >= g_prof_slots.size()) { set_error("pww_profile_elapsed_us: no such slot"); return PWW_EINVAL; }
+        if (!g_prof_slots[(size_t)slot].used) { set_error("pww_profile_elapsed_us: slot %d was armed but no attention kernel was launched", slot); return PWW_EINVAL; }
+        e0 = g_prof_slots[(size_t)slot].start;
+        e1 = g_prof_slots[(size_t)slot].stop;
+    }
+    if (int rc = check_hip(hipEventSynchronize(e1), "hipEventSynchronize")) return rc;
+    float ms = 0.f;
+    if (int rc = check_hip(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime")) return rc;
+    *us = ms * 1e3f;
+    return PWW_OK;
+}
+
+static void profile_reset() {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    for (ProfileSlot &sl : g_prof_slots) { (void)hipEventDestroy(sl.start); (void)hipEventDestroy(sl.stop); }
+    g_prof_slots.clear();
+    g_prof_armed = -1;
+}
+
 int attn_fwd(const void *q, const void *k, const void *v, void *o, const float *bias, const float *bias_coeff,
              const pww_attn_desc_t *d, hipStream_t stream, const double *stats = nullptr, int stat_kind = PWW_STAT_NONE,
              double stat_count = 1.0, float coeff_scalar = 1.f);
@@ -75,6 +127,10 @@ int cfg_combine(const void *cond, const void *uncond, float g, float *out, long 
 extern "C" {
 
 int pww_version(void) { return PWW_VERSION; }
+
+int pww_profile_arm(void) { return pww::profile_arm(); }
+int pww_profile_elapsed_us(int slot, float *us) { return pww::profile_elapsed_us(slot, us); }
+void pww_profile_reset(void) { pww::profile_reset(); }
 
 const char *pww_last_error(void) { return pww::g_err; }
 

@@ -693,7 +693,7 @@ static int launch_attn_rs(const AttnParams &p, hipStream_t stream) {
             done = true;
         }
     }
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, stream, p);
+    launch_attn_kernel(kern, grid, dim3(NW * 64), lds, stream, p);
     return check_hip(hipGetLastError(), "attn_fwd_kernel launch");
 }
 
@@ -713,7 +713,7 @@ static int launch_attn_ksplit(const AttnParams &p, hipStream_t stream) {
             return PWW_EHIP;
         done = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(qblocks * p.B * p.H)), dim3(NW * KG * 64), lds, stream, p);
+    launch_attn_kernel(kern, dim3((unsigned)(qblocks * p.B * p.H)), dim3(NW * KG * 64), lds, stream, p);
     return check_hip(hipGetLastError(), "attn_fwd_kernel<key-split> launch");
 }
 
@@ -744,7 +744,7 @@ static int launch_attn_fold(const AttnParams &p, hipStream_t stream) {
             done = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(qblocks * p.B * p.H)), dim3(NW * 64), lds, stream, p);
+    launch_attn_kernel(kern, dim3((unsigned)(qblocks * p.B * p.H)), dim3(NW * 64), lds, stream, p);
     return check_hip(hipGetLastError(), "attn_fwd_fold_kernel launch");
 }
 

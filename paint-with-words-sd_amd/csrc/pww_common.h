@@ -1,6 +1,7 @@
 // Shared device/host helpers for libpww_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -46,5 +47,18 @@ __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1)
 void set_error(const char *fmt, ...);
 int check_hip(hipError_t e, const char *what);
 bool arch_ok();
+
+// Kernel-only timing (pww_profile_*): if this thread armed a timing slot, hand out its event pair once.
+bool profile_take(hipEvent_t *start, hipEvent_t *stop);
+
+// Launch of an attention-class kernel. An armed launch goes through hipExtLaunchKernelGGL, which stamps the dispatch's own
+// start / end device timestamps into the two events: the duration rocprofv3 reports for the kernel, free of host latency and of
+// the gap between dispatches that an event pair AROUND a launch includes.
+template <typename K, typename P>
+static inline void launch_attn_kernel(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const P &params) {
+    hipEvent_t e0, e1;
+    if (profile_take(&e0, &e1)) hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, stream, e0, e1, 0, params);
+    else hipLaunchKernelGGL(kern, grid, block, lds, stream, params);
+}
 
 }  // namespace pww

@@ -366,8 +366,8 @@ static int launch_cross(CrossParams cp, hipStream_t stream, bool *launched) {
     if (nchunk > cp.nqb) nchunk = cp.nqb;
     cp.nchunk = (int)nchunk;
     const dim3 grid((unsigned)(BH * nchunk));
-    if (cp.nchunk == cp.nqb) hipLaunchKernelGGL(k_single, grid, dim3(NW * 64), lds, stream, cp);
-    else hipLaunchKernelGGL(k_multi, grid, dim3(NW * 64), lds, stream, cp);
+    if (cp.nchunk == cp.nqb) launch_attn_kernel(k_single, grid, dim3(NW * 64), lds, stream, cp);
+    else launch_attn_kernel(k_multi, grid, dim3(NW * 64), lds, stream, cp);
     *launched = true;
     return check_hip(hipGetLastError(), "cross_fused_kernel launch");
 }

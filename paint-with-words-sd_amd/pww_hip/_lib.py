@@ -17,7 +17,7 @@ MAX_HEAD_DIM = 160
 EXPORTS = ("pww_version", "pww_last_error", "pww_device_arch", "pww_self_attn_fwd", "pww_cross_attn_fwd",
            "pww_cross_attn_fwd_stat", "pww_cross_attn_fwd_fused", "pww_cross_fused_workspace_bytes", "pww_cross_fused_state_bytes",
            "pww_qk_reduce", "pww_mask_build", "pww_mask_build_rgb", "pww_mask_build_f32", "pww_resize_tokens", "pww_gauss_blur", "pww_inpaint_prep", "pww_cfg_combine",
-           "pww_workspace_bytes")
+           "pww_workspace_bytes", "pww_profile_arm", "pww_profile_elapsed_us", "pww_profile_reset")
 
 
 class AttnDesc(ctypes.Structure):
@@ -75,11 +75,17 @@ def load():
     lib.pww_cfg_combine.argtypes = [vp, vp, f32, vp, i64, i32, vp]
     lib.pww_workspace_bytes.argtypes = [ctypes.POINTER(AttnDesc)]
     lib.pww_workspace_bytes.restype = ctypes.c_size_t
+    lib.pww_profile_arm.argtypes = []
+    lib.pww_profile_arm.restype = ctypes.c_int
+    lib.pww_profile_elapsed_us.argtypes = [i32, ctypes.POINTER(ctypes.c_float)]
+    lib.pww_profile_elapsed_us.restype = ctypes.c_int
+    lib.pww_profile_reset.argtypes = []
+    lib.pww_profile_reset.restype = None
     for name in ("pww_device_arch", "pww_self_attn_fwd", "pww_cross_attn_fwd", "pww_cross_attn_fwd_stat", "pww_cross_attn_fwd_fused", "pww_qk_reduce", "pww_mask_build",
                  "pww_mask_build_rgb", "pww_mask_build_f32", "pww_resize_tokens", "pww_gauss_blur", "pww_inpaint_prep", "pww_cfg_combine"):
         getattr(lib, name).restype = ctypes.c_int
-    if lib.pww_version() // 100 != 1 or lib.pww_version() < 110:
-        raise PwwHipError("libpww_hip ABI version %d is not 1.x >= 1.10 (rebuild: python paint-with-words-sd_amd/build.py)" % lib.pww_version())
+    if lib.pww_version() // 100 != 1 or lib.pww_version() < 111:
+        raise PwwHipError("libpww_hip ABI version %d is not 1.x >= 1.11 (rebuild: python paint-with-words-sd_amd/build.py)" % lib.pww_version())
     _lib = lib
     return lib
 
