@@ -269,7 +269,17 @@ static void run_case(const Case &c, bool timing) {
         for (int i = 0; i < iters; ++i) pww_qk_reduce(dq, dk, &d, dstats, dws, ws_bytes, nullptr);
         HIPCHECK(hipEventRecord(e1, nullptr)); HIPCHECK(hipEventSynchronize(e1));
         float ms2 = 0; HIPCHECK(hipEventElapsedTime(&ms2, e0, e1));
-        printf("TIME %-28s attn %.2f us/call  %.1f TFLOP/s (algorithmic 4BHNMD) | qk_reduce %.2f us/call\n", c.name, us, flops / us * 1e-6, ms2 * 1e3 / iters);
+        // kernel-only duration of one more launch (pww_profile_*: the dispatch's own start / end timestamps)
+        float kus = -1.f;
+        const int slot = pww_profile_arm();
+        c.bias_mode ? pww_cross_attn_fwd(dq, dk, dv, dout, dbias, dcoeff, &d, nullptr) : pww_self_attn_fwd(dq, dk, dv, dout, &d, nullptr);
+        if (slot < 0 || pww_profile_elapsed_us(slot, &kus) != PWW_OK || !(kus > 0.f && kus < 2.f * us + 20.f)) {
+            printf("FAIL %-28s pww_profile_*: slot %d, %.2f us (event-timed loop %.2f us): %s\n", c.name, slot, kus, us, pww_last_error());
+            g_fail++;
+        }
+        pww_profile_reset();
+        printf("TIME %-28s attn %.2f us/call (kernel-only, single launch: %.2f us)  %.1f TFLOP/s (algorithmic 4BHNMD) | qk_reduce %.2f us/call\n", c.name, us, kus,
+               flops / us * 1e-6, ms2 * 1e3 / iters);
     }
     for (void *ptr : {(void *)dws, (void *)dq, (void *)dk, (void *)dv, (void *)dout, (void *)dstats, (void *)dbias, (void *)dcoeff})
         if (ptr) (void)hipFree(ptr);
