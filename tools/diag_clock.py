@@ -21,15 +21,23 @@ def sample(tag, n=6, dt=0.25):
 
 
 def main():
+    run("random N(0,1) inputs", zeros=False)
+    time.sleep(1.0)
+    run("all-zero inputs (same instruction stream, nothing toggles in the operands)", zeros=True)
+
+
+def run(label, zeros):
+    print("====", label, flush=True)
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    q = torch.randn(2, 4096, 320, device=dev, dtype=torch.bfloat16)
-    k = torch.randn(2, 4096, 320, device=dev, dtype=torch.bfloat16)
-    v = torch.randn(2, 4096, 320, device=dev, dtype=torch.bfloat16)
+    mk = (lambda: torch.zeros(2, 4096, 320, device=dev, dtype=torch.bfloat16)) if zeros else \
+         (lambda: torch.randn(2, 4096, 320, device=dev, dtype=torch.bfloat16))
+    q, k, v = mk(), mk(), mk()
     for _ in range(10):
         ops.attention(q, k, v, 8, 40 ** -0.5)
     torch.cuda.synchronize()
-    sample("idle")
+    if not zeros:
+        sample("idle", n=3)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for _ in range(200):
@@ -39,7 +47,7 @@ def main():
     for _ in range(250):          # ~3 s of back-to-back launches, queued asynchronously
         g.replay()
     e1.record()
-    sample("busy")
+    sample("busy", n=4)
     torch.cuda.synchronize()
     print("back-to-back average: %.2f us per launch over %d launches" % (e0.elapsed_time(e1) * 1e3 / (250 * 200), 250 * 200))
 
