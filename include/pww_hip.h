@@ -20,7 +20,10 @@
  *
  * Conventions
  *   - All tensor arguments are DEVICE pointers owned by the caller. The library never allocates,
- *     frees or retains device memory and keeps no global state except a thread-local error string.
+ *     frees or retains device memory. Host-side state: a thread-local error string, per-thread caches of launch
+ *     attributes (occupancy answers), and -- only while the measurement aids at the end of this file are in use -- a
+ *     mutex-guarded pool of at most PWW_PROFILE_SLOTS timing event pairs and one debug pointer; none of it is touched by
+ *     the entry points of the path unless a thread armed a timing slot.
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream). Every function only
  *     enqueues work on that stream and returns; none synchronises, so all of them are legal
  *     inside hipGraph stream capture.
@@ -40,7 +43,8 @@
 extern "C" {
 #endif
 
-#define PWW_VERSION 111 /* 0.1.11: + pww_profile_arm / pww_profile_elapsed_us / pww_profile_reset (0.1.10: fused cross-attention, blur, resize, inpaint prep) */
+#define PWW_VERSION 120 /* 0.1.20: + pww_cross_attn_fwd_fused_ex / pww_cross_attn_fwd_stat_ex (pww_cross_opts_t: device-side coefficient word, bias column bound,
+                           compact bias), pww_debug_timeline (0.1.11: pww_profile_*; 0.1.10: fused cross-attention, blur, resize, inpaint prep) */
 
 #define PWW_OK 0
 #define PWW_EINVAL (-22)
@@ -160,6 +164,44 @@ size_t pww_cross_fused_state_bytes(const pww_attn_desc_t *desc);
 size_t pww_cross_fused_workspace_bytes(const pww_attn_desc_t *desc);
 
 /*
+ * Optional arguments of the *_ex cross-attention entry points. Zero-initialise, then set `size = sizeof(pww_cross_opts_t)`
+ * (fields added by later versions are appended; a library accepts every size it knows).
+ *   coeff_scalar_dev  device word that REPLACES the by-value `coeff_scalar` argument; it is read when the kernel RUNS, so one
+ *                     captured hipGraph serves every denoise step: the host rewrites the word (c0 * g(sigma_i) of
+ *                     paint_with_words.py:402-405 / runner.py:104) before each replay. NULL = use the by-value argument.
+ *   bias_cols         the caller's promise that columns >= bias_cols of the bias map are zero (the map of a prompt is zero past
+ *                     its last region phrase, paint_with_words.py:257-268): only those columns are moved and added. 0 = unknown.
+ *   bias_compact      compact bias: fp32 [B?][N][R] with bias[b][h][n][col_idx[b?][r]] = bias_compact[b][n][r] and
+ *                     every other column zero; addressed  bias_compact + b*compact_stride[0] + n*compact_stride[1] + r.
+ *                     5 - 17 of the 77 columns of a Paint-with-Words map are non-zero. R <= 32. When given it is what the fused
+ *                     kernel reads; the dense `bias` argument is then only used by the two-launch fall-back and may be NULL
+ *                     (a launch that cannot be made resident then fails with PWW_ENOTSUP).
+ *   col_idx           int32 [B?][R] (image stride col_idx_stride, 0 = shared): the column of compact slot r, or -1 = unused.
+ *                     bias_cols must cover max(col_idx) + 1 (0 = M).
+ */
+typedef struct pww_cross_opts {
+    uint32_t size;
+    int32_t bias_cols;
+    const float *coeff_scalar_dev;
+    const float *bias_compact;
+    const int32_t *col_idx;
+    int32_t R;
+    int32_t _pad;
+    int64_t compact_stride[2];   /* image, row (elements) */
+    int64_t col_idx_stride;      /* image (elements) */
+} pww_cross_opts_t;
+
+/* pww_cross_attn_fwd_fused / pww_cross_attn_fwd_stat with the optional arguments above (opts == NULL: identical to the plain forms).
+   pww_cross_attn_fwd_stat_ex reads coeff_scalar_dev only; the other fields concern the fused kernel's LDS bias tile. */
+int pww_cross_attn_fwd_fused_ex(const void *q, const void *k, const void *v, void *o, const float *bias,
+                                int32_t stat_kind, float coeff_scalar, const float *gate, const pww_attn_desc_t *desc,
+                                double *stats_out, void *state, size_t state_bytes, void *workspace, size_t workspace_bytes,
+                                const pww_cross_opts_t *opts, void *stream);
+int pww_cross_attn_fwd_stat_ex(const void *q, const void *k, const void *v, void *o, const float *bias,
+                               const double *stats, int32_t stat_kind, double stat_count, float coeff_scalar,
+                               const float *gate, const pww_attn_desc_t *desc, const pww_cross_opts_t *opts, void *stream);
+
+/*
  * Per-image global statistics of the raw score tensor S = Q K^T over all heads, rows and keys
  * (what weight_function reduces: qk.max(), qk.min(), qk.mean(), qk.std()).
  *   stats      double [B][4] = { max, min, sum, sum of squares } per image b (fully overwritten).
@@ -252,11 +294,21 @@ size_t pww_workspace_bytes(const pww_attn_desc_t *desc);
  * this thread launches through the library stamps the dispatch's own start and end device timestamps into the slot
  * (hipExtLaunchKernelGGL) -- the duration rocprofv3 reports for that kernel, without host launch latency and without the gap
  * between dispatches that an event pair recorded around a launch includes. pww_profile_elapsed_us() waits for that kernel and
- * returns the duration; pww_profile_reset() releases all slots. Not for use during stream capture.
+ * returns the duration; pww_profile_reset() releases all slots. While the calling thread's stream is capturing a hipGraph an armed
+ * slot is ignored (the launch is an ordinary captured node and the slot stays unused).
  */
+#define PWW_PROFILE_SLOTS 4096   /* slots are recycled: arming slot 4096 + i re-uses the event pair of slot i */
 int pww_profile_arm(void);
 int pww_profile_elapsed_us(int32_t slot, float *microseconds);
 void pww_profile_reset(void);
+
+/*
+ * Phase time stamps of the attention kernels (debug / measurement aid). After pww_debug_timeline(buf, bytes) every attention
+ * launch of the PROCESS whose grid fits writes 8 uint64 wall-clock stamps (100 MHz) per workgroup to buf[workgroup][8]:
+ * [0] kernel entry, [1] K/V staged, then per kernel -- fused cross-attention: [2] partials published, [3] statistic folded,
+ * [4] outputs stored, [5] exit; self-attention: [2] key loop done, [3] outputs stored. buf == NULL switches it off (the default).
+ */
+void pww_debug_timeline(void *device_buffer, size_t bytes);
 
 #ifdef __cplusplus
 }

@@ -314,6 +314,48 @@ def gen_forwards(ref):
         np.savez_compressed(os.path.join(GOLDEN, "fwd_sd21_grid768.npz"), **out)
 
 
+def gen_config3(ref):
+    """BASELINE configs[2] pinned end to end: full-size SD1.5 stand-in, 8 stripes, image j of the
+    batch = the stripes map rotated by j stripes (per-image weight maps), seed j.
+      fwd_sd15_stripes8.npz   ONE forward (step 4 of 50 LMS) of the reference's inj_forward for images 0, 3, 6: cond + uncond eps
+      loop_sd15_stripes8_lms50.npz   final latents of the reference's own 50-step paint_with_words loop for images 0 and 5"""
+    import warnings
+    warnings.filterwarnings("ignore")
+    which = os.environ.get("PWW_GOLDEN_ONLY", "fwd loop")
+    if "fwd" in which:
+        tools = cases.build_tools("sd15")
+        vae, unet, text, tok, sch = tools
+        _install_ref(ref, unet)
+        try:
+            sch.set_timesteps(50)
+            i = 4
+            t, sigma = sch.timesteps[i], sch.sigmas[i]
+            out = {"step_index": i, "sigma": float(sigma), "images": np.array([0, 3, 6])}
+            for j in (0, 3, 6):
+                img, ctx, prompt = cases.stripes_batch_case(j)
+                _, _, cond, uncond = ref["_encode_text_color_inputs"](text, tok, "cpu", Image.fromarray(img), dict(ctx), prompt, "")
+                x0 = torch.randn((1, 4, 64, 64), generator=torch.manual_seed(j)) * sch.init_noise_sigma
+                x = sch.scale_model_input(x0, t)
+                t0 = time.time()
+                cond.update({"SIGMA": sigma, "WEIGHT_FUNCTION": cases.weight_fn_runner})
+                out[f"eps_cond_{j}"] = unet(x, t, encoder_hidden_states=cond).sample.numpy()
+                uncond.update({"SIGMA": sigma, "WEIGHT_FUNCTION": lambda w, sigma, qk: 0.0})
+                out[f"eps_uncond_{j}"] = unet(x, t, encoder_hidden_states=uncond).sample.numpy()
+                print("fwd sd15 stripes8 image %d: %.1fs |eps| %.4f gap %.4f" % (j, time.time() - t0, np.abs(out[f"eps_cond_{j}"]).mean(),
+                                                                              np.abs(out[f"eps_cond_{j}"] - out[f"eps_uncond_{j}"]).mean()))
+        finally:
+            _uninstall_ref()
+        np.savez_compressed(os.path.join(GOLDEN, "fwd_sd15_stripes8.npz"), **out)
+    if "loop" in which:
+        out = {"steps": 50, "images": np.array([0, 5])}
+        for j in (0, 5):
+            img, ctx, prompt = cases.stripes_batch_case(j)
+            lat, dt = _run_loop(ref, "sd15", 50, img, ctx, prompt, cases.weight_fn_runner, seed=j)
+            out[f"latents_{j}"] = lat
+            print("loop sd15 stripes8 lms50 image %d: %.1fs latents std %.4f" % (j, dt, lat.std()))
+        np.savez_compressed(os.path.join(GOLDEN, "loop_sd15_stripes8_lms50.npz"), **out)
+
+
 def gen_plms():
     """ORACLE-generated (not reference-generated: the reference cannot run PNDM/PLMS -- no `.sigmas`, a repeated timestep,
     SURVEY.md section 8 a-note): final latent of BASELINE configs[1] -- full-size SD1.5 stand-in, 30 PLMS steps
@@ -390,5 +432,7 @@ if __name__ == "__main__":
         gen_forwards(ref)
     if "plms" in which:
         gen_plms()
+    if "config3" in which:
+        gen_config3(ref)
     if "reftime" in which:
         gen_ref_timing(ref)

@@ -50,16 +50,23 @@ bool arch_ok() {
 
 // ---- kernel-only timing slots (pww_profile_*): event pairs owned by the library, handed to the next attention launch of the
 // arming thread (launch_attn_kernel in pww_common.h)
-struct ProfileSlot { hipEvent_t start, stop; bool used; };
+// The pool is bounded: slot numbers keep counting, the event pair behind slot n is pair n % PWW_PROFILE_SLOTS (created on first
+// use, re-used afterwards), so a long-running process that arms a slot per launch holds at most 2 * PWW_PROFILE_SLOTS events.
+struct ProfileSlot { hipEvent_t start, stop; bool used; int owner; };
 static std::mutex g_prof_mutex;
 static std::vector<ProfileSlot> g_prof_slots;
+static int g_prof_next = 0;
 static thread_local int g_prof_armed = -1;
 
-bool profile_take(hipEvent_t *start, hipEvent_t *stop) {
+bool profile_take(hipEvent_t *start, hipEvent_t *stop, hipStream_t stream) {
     if (g_prof_armed < 0) return false;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;   // event-stamped launches cannot be captured: stay armed
     std::lock_guard<std::mutex> lock(g_prof_mutex);
-    ProfileSlot &sl = g_prof_slots[(size_t)g_prof_armed];
+    ProfileSlot &sl = g_prof_slots[(size_t)(g_prof_armed % PWW_PROFILE_SLOTS)];
+    const bool mine = sl.owner == g_prof_armed;
     g_prof_armed = -1;
+    if (!mine) return false;          // the pair was recycled by a later arm before this launch happened
     sl.used = true;
     *start = sl.start;
     *stop = sl.stop;
@@ -67,22 +74,30 @@ bool profile_take(hipEvent_t *start, hipEvent_t *stop) {
 }
 
 static int profile_arm() {
-    ProfileSlot sl{nullptr, nullptr, false};
-    if (check_hip(hipEventCreate(&sl.start), "hipEventCreate") || check_hip(hipEventCreate(&sl.stop), "hipEventCreate")) return PWW_EHIP;
     std::lock_guard<std::mutex> lock(g_prof_mutex);
-    g_prof_slots.push_back(sl);
-    g_prof_armed = (int)g_prof_slots.size() - 1;
-    return g_prof_armed;
+    const int slot = g_prof_next;
+    const size_t idx = (size_t)(slot % PWW_PROFILE_SLOTS);
+    if (idx >= g_prof_slots.size()) {
+        ProfileSlot sl{nullptr, nullptr, false, -1};
+        if (check_hip(hipEventCreate(&sl.start), "hipEventCreate") || check_hip(hipEventCreate(&sl.stop), "hipEventCreate")) return PWW_EHIP;
+        g_prof_slots.push_back(sl);
+    }
+    g_prof_slots[idx].used = false;
+    g_prof_slots[idx].owner = slot;
+    g_prof_next = slot == 0x7ffffffe ? 0 : slot + 1;
+    g_prof_armed = slot;
+    return slot;
 }
 
 static int profile_elapsed_us(int slot, float *us) {
     hipEvent_t e0, e1;
     {
         std::lock_guard<std::mutex> lock(g_prof_mutex);
-        if (!us || slot < 0 || (size_t)slot >= g_prof_slots.size()) { set_error("pww_profile_elapsed_us: no such slot"); return PWW_EINVAL; }
-        if (!g_prof_slots[(size_t)slot].used) { set_error("pww_profile_elapsed_us: slot %d was armed but no attention kernel was launched", slot); return PWW_EINVAL; }
-        e0 = g_prof_slots[(size_t)slot].start;
-        e1 = g_prof_slots[(size_t)slot].stop;
+        const size_t idx = (size_t)(slot % PWW_PROFILE_SLOTS);
+        if (!us || slot < 0 || idx >= g_prof_slots.size() || g_prof_slots[idx].owner != slot) { set_error("pww_profile_elapsed_us: no such slot (or recycled: the pool holds %d)", PWW_PROFILE_SLOTS); return PWW_EINVAL; }
+        if (!g_prof_slots[idx].used) { set_error("pww_profile_elapsed_us: slot %d was armed but no attention kernel was launched", slot); return PWW_EINVAL; }
+        e0 = g_prof_slots[idx].start;
+        e1 = g_prof_slots[idx].stop;
     }
     if (int rc = check_hip(hipEventSynchronize(e1), "hipEventSynchronize")) return rc;
     float ms = 0.f;
@@ -95,18 +110,25 @@ static void profile_reset() {
     std::lock_guard<std::mutex> lock(g_prof_mutex);
     for (ProfileSlot &sl : g_prof_slots) { (void)hipEventDestroy(sl.start); (void)hipEventDestroy(sl.stop); }
     g_prof_slots.clear();
+    g_prof_next = 0;
     g_prof_armed = -1;
 }
 
+// ---- phase time stamps (pww_debug_timeline): one process-wide debug pointer handed to every attention launch
+static unsigned long long *g_timeline = nullptr;
+static size_t g_timeline_bytes = 0;
+unsigned long long *debug_timeline() { return g_timeline; }
+size_t debug_timeline_bytes() { return g_timeline_bytes; }
+
 int attn_fwd(const void *q, const void *k, const void *v, void *o, const float *bias, const float *bias_coeff,
              const pww_attn_desc_t *d, hipStream_t stream, const double *stats = nullptr, int stat_kind = PWW_STAT_NONE,
-             double stat_count = 1.0, float coeff_scalar = 1.f);
+             double stat_count = 1.0, float coeff_scalar = 1.f, const float *coeff_scalar_dev = nullptr);
 int qk_reduce(const void *q, const void *k, const pww_attn_desc_t *d, double *stats, void *workspace,
               size_t workspace_bytes, hipStream_t stream);
 size_t qk_reduce_workspace_bytes(const pww_attn_desc_t *d);
 int cross_attn_fused(const void *q, const void *k, const void *v, void *o, const float *bias, int stat_kind, float coeff_scalar,
                      const float *gate, const pww_attn_desc_t *d, double *stats_out, void *state, size_t state_bytes,
-                     void *workspace, size_t workspace_bytes, hipStream_t stream);
+                     void *workspace, size_t workspace_bytes, const pww_cross_opts_t *opts, hipStream_t stream);
 size_t cross_fused_workspace_bytes(const pww_attn_desc_t *d);
 size_t cross_fused_state_bytes(const pww_attn_desc_t *d);
 int mask_build(const uint8_t *rgb, int H, int W, const pww_region_t *regions, int R, const int32_t *col_ptr,
@@ -160,7 +182,31 @@ int pww_cross_attn_fwd_fused(const void *q, const void *k, const void *v, void *
                              float coeff_scalar, const float *gate, const pww_attn_desc_t *desc, double *stats_out, void *state,
                              size_t state_bytes, void *workspace, size_t workspace_bytes, void *stream) {
     return pww::cross_attn_fused(q, k, v, o, bias, stat_kind, coeff_scalar, gate, desc, stats_out, state, state_bytes, workspace,
-                                 workspace_bytes, static_cast<hipStream_t>(stream));
+                                 workspace_bytes, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int pww_cross_attn_fwd_fused_ex(const void *q, const void *k, const void *v, void *o, const float *bias, int32_t stat_kind,
+                                float coeff_scalar, const float *gate, const pww_attn_desc_t *desc, double *stats_out, void *state,
+                                size_t state_bytes, void *workspace, size_t workspace_bytes, const pww_cross_opts_t *opts, void *stream) {
+    return pww::cross_attn_fused(q, k, v, o, bias, stat_kind, coeff_scalar, gate, desc, stats_out, state, state_bytes, workspace,
+                                 workspace_bytes, opts, static_cast<hipStream_t>(stream));
+}
+
+int pww_cross_attn_fwd_stat_ex(const void *q, const void *k, const void *v, void *o, const float *bias,
+                               const double *stats, int32_t stat_kind, double stat_count, float coeff_scalar,
+                               const float *gate, const pww_attn_desc_t *desc, const pww_cross_opts_t *opts, void *stream) {
+    const float *dev = nullptr;
+    if (opts) {
+        if (opts->size < 16) { pww::set_error("pww_cross_attn_fwd_stat_ex: pww_cross_opts_t.size = %u is not a known layout", opts->size); return PWW_EINVAL; }
+        dev = opts->coeff_scalar_dev;
+    }
+    return pww::attn_fwd(q, k, v, o, bias, gate, desc, static_cast<hipStream_t>(stream), stats, stat_kind, stat_count,
+                         coeff_scalar, dev);
+}
+
+void pww_debug_timeline(void *device_buffer, size_t bytes) {
+    pww::g_timeline = static_cast<unsigned long long *>(device_buffer);
+    pww::g_timeline_bytes = device_buffer ? bytes : 0;
 }
 
 size_t pww_cross_fused_workspace_bytes(const pww_attn_desc_t *desc) { return pww::cross_fused_workspace_bytes(desc); }

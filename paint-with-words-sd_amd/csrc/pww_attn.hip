@@ -119,6 +119,7 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
 
     const int qrow = (qb * NW + rg) * 32 + l31;
     const bool qvalid = qrow < p.N;
+    tl_stamp(p, 0);
 
     V8 qf[KS];
     load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qvalid, hi, p.D);
@@ -170,6 +171,7 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
     stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
     if (nstage > 1) stage_load(kreg, vreg, plan, srd_k, srd_v, k_step, v_step);
     __syncthreads();
+    tl_stamp(p, 1);
 
     int st = 0;
     for (; st < nfull; ++st) {   // full stages: no key masking anywhere; ONE barrier per stage
@@ -220,6 +222,7 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
         }
     }
 
+    tl_stamp(p, 2);
     if constexpr (KG > 1) {
         // merge the KG partial softmax states of each row group: key groups 1.. publish (m, l, O^T) in LDS,
         // key group 0 folds them:  m = max m_i,  O = sum_i O_i * 2^((m_i - m) c1)  (the row-sum row included)
@@ -303,6 +306,7 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
             }
         }
     }
+    tl_stamp(p, 3);
 }
 
 // ---- folded-reference variant (head dims with D % 16 == 8: SD1.x's d = 40) -----------------------------
@@ -327,6 +331,17 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
 //     softmax (exact_rows above): always correct, fast for every input whose logits span less than e^83.
 constexpr float FOLD_TAU = 6.f;
 constexpr float FOLD_HEADROOM = 8.f;
+
+// MAGNITUDE GUARD. The one approximation of this variant is the extra rounding of Q * scale * log2(e) to T: a relative error of
+// 2^-9 (bf16) / 2^-12 (f16) on every term of a score, i.e. an absolute logit error that grows LINEARLY with the magnitude of the
+// logits that carry the softmax weight -- measured 1.1e-2 of max|O| (bf16, bar 1.6e-2) and 1.3e-3 .. 2.3e-3 (f16, bar 2e-3) at
+// logit maxima of 40 - 45 natural units (tests/test_round2_gpu.py::test_hot_logits), negligible at |logit| < 10. The kernel
+// therefore bounds the row maximum it has seen -- exactly, in the exp2 domain: after the first stage (early exit: the whole
+// workgroup goes straight to the exact path) and at the end (m_ref + log2(row sum) >= the true row maximum) -- and a workgroup
+// with a row beyond FoldLimit<T> recomputes its rows with the exact-scale online softmax (exact_rows). Limits: bf16 72 (= 50
+// natural units: 1.3e-2 of max|O| extrapolated, inside the 1.6e-2 bar), f16 29 (= 20 natural units: <= 1.0e-3, half the 2e-3 bar).
+template <typename T> struct FoldLimit { static constexpr float value = 72.f; };
+template <> struct FoldLimit<f16> { static constexpr float value = 29.f; };
 
 template <typename T, int KS>
 __device__ __forceinline__ void fold_set_ref(typename Vec<T>::v8 (&qf)[KS], float mref, int hi, int D) {
@@ -558,6 +573,8 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
     if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     float mref = 0.f;      // softmax reference of the lane's row (exp2 domain), identical in both half-waves
     bool first = true;     // no tile processed yet: m_ref not established
+    bool early = false;    // magnitude guard tripped after the first stage: skip the fast path
+    tl_stamp(p, 0);
 
     // padding is never staged: zero both buffers once, then column D of every V row = one (softmax denominator
     // from the PV MFMA) and column D of every K row = one (the folded -m_ref term of the score MFMA)
@@ -594,9 +611,14 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
         stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
         fold_stage2<T, KS, DT, SUB_BYTES>(oacc, mref, first, qf, cur, st * STAGE_KEYS, l31, hi, p.D);
         first = false;
-        __syncthreads();
+        if (st == 0) {       // magnitude guard, early form: the first stage's row maximum (m_ref minus the range-free headroom)
+            const float m0 = mref - (RangeFree<T>::value ? FOLD_HEADROOM : 0.f);
+            if (__syncthreads_or(qvalid && !(fabsf(m0) <= FoldLimit<T>::value))) { early = true; break; }
+        } else {
+            __syncthreads();
+        }
     }
-    if (st < nstage) {           // ragged tail stage (already in LDS)
+    if (st < nstage && !early) {           // ragged tail stage (already in LDS)
         char *cur = smem + (st & 1) * STAGE_BYTES;
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
@@ -608,6 +630,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
             }
         }
     }
+    tl_stamp(p, 2);
 
     // softmax denominator: row D of O^T (tile D / 32, register (D % 32) / 2, held by the hi == 0 half)
     const int rl = p.D & 31, tl = p.D >> 5;
@@ -622,16 +645,18 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
         const float other = __shfl_xor(lv, 32);
         lsum = hi ? other : lv;
     }
-    if constexpr (RangeFree<T>::value) {
-        // range check of the range-free mode: a finite, positive row sum means no exp2 overflowed and no row vanished
-        // (and the accumulated O^T itself: a P just below the float range times |V| > 1 overflows the product, not the sum)
+    {
+        // Range check (range-free bf16 mode): a finite, positive row sum means no exp2 overflowed and no row vanished (and the
+        // accumulated O^T itself: a P just below the float range times |V| > 1 overflows the product, not the sum).
+        // Magnitude guard, final form (every dtype): m_ref + log2(row sum) bounds the row maximum from above (by at most log2 M).
         float asum = 0.f;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) asum += fabsf(oacc[dt][r]);     // inf or NaN anywhere makes the comparison below false
-        const bool bad = qvalid && !(lsum > 0.f && lsum < 3.0e38f && asum < 3.0e38f);
-        if (__syncthreads_or(bad)) {
+        const float est_max = mref + __builtin_amdgcn_logf(lsum);        // v_log_f32 = log2
+        const bool bad = qvalid && !(lsum > 0.f && lsum < 3.0e38f && asum < 3.0e38f && fabsf(est_max) <= FoldLimit<T>::value);
+        if (early || __syncthreads_or(bad)) {
             float l_unused;
             exact_rows<T, KS, DT, NSUB, true, KPT, VPT>(oacc, l_unused, p, Qp + (long)qrow * p.q_sn, qvalid, smem, plan, srd_k, srd_v, k_step, v_step, l31, hi);
             float lv = 0.f;
@@ -661,6 +686,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
             }
         }
     }
+    tl_stamp(p, 3);
 }
 
 // ---- host dispatch ---------------------------------------------------------------------------
@@ -723,7 +749,7 @@ static int ksplit_mode() {   // PWW_ATTN_KSPLIT=0/1 (A/B testing); default on
     return mode;
 }
 
-static int fold_mode() {   // PWW_ATTN_FOLD: 0 = never, 1 = bf16 only (default), 2 = bf16 and f16 (A/B testing)
+static int fold_mode() {   // PWW_ATTN_FOLD (A/B testing only -- accuracy is guarded in the kernel): 0 = never, 1 = bf16 and f16 (default), 2 = bf16 only
     static int mode = -2;
     if (mode == -2) { const char *e = getenv("PWW_ATTN_FOLD"); mode = e ? atoi(e) : 1; }
     return mode;
@@ -753,11 +779,9 @@ static int launch_attn(const AttnParams &p, hipStream_t stream) {
     if constexpr (!HAS_BIAS && KS == 3 && DT == 2) {
         // d = 40 (and 8, 24): a free head-dim padding column in the K tile -> folded-reference softmax
         // (also beats the key-split variant below at B = 1, N = 4096: 47 vs 52 us)
-        // bf16 only by default: the variant rounds Q * scale * log2(e) to T once more, which at trained-model logit
-        // ranges (scaled-logit std 4, maxima 40-45) costs 5x the plain kernel's error -- 1.1e-2 of max|O| against the
-        // 1.6e-2 bf16 bar, but 1.3e-3..2.3e-3 against the 2e-3 f16 bar (tests/test_round2_gpu.py::test_hot_logits).
-        // f16 callers chose f16 for its precision and get the exact-scale kernel; PWW_ATTN_FOLD=2 folds f16 too (A/B).
-        const bool fold_ok = fold_mode() == 2 || (fold_mode() == 1 && sizeof(T) == 2 && !__is_same(T, f16));
+        // The variant rounds Q * scale * log2(e) to T once more; the error that costs grows with the logit magnitude, and the
+        // kernel itself sends every workgroup whose rows exceed FoldLimit<T> through the exact-scale path (magnitude guard).
+        const bool fold_ok = fold_mode() == 1 || (fold_mode() == 2 && !__is_same(T, f16));
         if ((p.D & 15) == 8 && fold_ok) return launch_attn_fold<T, KS, DT, NW>(p, stream);
     }
     if constexpr (!HAS_BIAS && DT <= 2 && NW == 4) {
@@ -884,11 +908,13 @@ void attn_fill_params(AttnParams &p, const void *q, const void *k, const void *v
     p.b_sb = d->bias_stride[0]; p.b_sh = d->bias_stride[1]; p.b_sn = d->bias_stride[2]; p.b_sm = d->bias_stride[3];
     p.scale_log2e = d->scale * 1.4426950408889634f;
     p.stats = nullptr; p.stat_kind = PWW_STAT_NONE; p.stat_count = 1.0; p.coeff_scalar = 1.f;
+    p.coeff_scalar_dev = nullptr; p.bias_cols = 0; p.timeline = debug_timeline();
+    p.timeline_wgs = (unsigned)(debug_timeline_bytes() / (TL_SLOTS * sizeof(unsigned long long)));
 }
 
 int attn_fwd(const void *q, const void *k, const void *v, void *o, const float *bias,
              const float *bias_coeff, const pww_attn_desc_t *d, hipStream_t stream,
-             const double *stats, int stat_kind, double stat_count, float coeff_scalar) {
+             const double *stats, int stat_kind, double stat_count, float coeff_scalar, const float *coeff_scalar_dev) {
     if (int rc = attn_validate(q, k, v, o, bias, d)) return rc;
     AttnParams p;
     attn_fill_params(p, q, k, v, o, bias, bias_coeff, d);
@@ -898,6 +924,7 @@ int attn_fwd(const void *q, const void *k, const void *v, void *o, const float *
     }
     p.stats = bias ? stats : nullptr; p.stat_kind = bias ? stat_kind : PWW_STAT_NONE; p.stat_count = stat_count;
     p.coeff_scalar = coeff_scalar;
+    p.coeff_scalar_dev = bias ? coeff_scalar_dev : nullptr;
     return d->dtype == PWW_DTYPE_F16 ? dispatch_nw<f16>(p, stream) : dispatch_nw<bf16>(p, stream);
 }
 

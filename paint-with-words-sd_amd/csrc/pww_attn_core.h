@@ -23,7 +23,23 @@ struct AttnParams {
     int stat_kind;
     double stat_count;
     float coeff_scalar;
+    const float *coeff_scalar_dev;   // optional device word that REPLACES coeff_scalar (read when the kernel runs: one captured
+                                     // hipGraph serves every denoise step, the host rewrites the word before each replay)
+    int bias_cols;                   // columns >= bias_cols of the bias map are zero (multiple of 16, <= M rounded up); 0 = unknown
+    unsigned long long *timeline;    // debug: per-workgroup phase time stamps (pww_debug_timeline), normally null
+    unsigned timeline_wgs;           // workgroups the debug buffer has room for
 };
+
+// the Python scalar c0 * g(sigma) of the weight function: baked into the launch, or read from a device word
+__device__ __forceinline__ float coeff_scalar_of(const AttnParams &p) {
+    return p.coeff_scalar_dev ? *p.coeff_scalar_dev : p.coeff_scalar;
+}
+
+// debug time stamps (100 MHz wall clock), [workgroup][TL_SLOTS]
+constexpr int TL_SLOTS = 8;
+__device__ __forceinline__ void tl_stamp(const AttnParams &p, int slot) {
+    if (p.timeline && threadIdx.x == 0 && blockIdx.x < p.timeline_wgs) p.timeline[(long)blockIdx.x * TL_SLOTS + slot] = wall_clock64();
+}
 
 // c * stat(st), the statistic selected from one image's { max, min, sum, sum of squares } (fp64) and rounded to fp32 first
 __device__ __forceinline__ float stat_coefficient(float c, int kind, const double *st, double count) {
@@ -46,7 +62,7 @@ __device__ __forceinline__ float stat_coefficient(float c, int kind, const doubl
 
 // c[b] = coeff_scalar * stat(stats[b]) * gate[b]   (fp32 products in this order: what the host's elementwise ops gave)
 __device__ __forceinline__ float bias_coefficient(const AttnParams &p, int b) {
-    float c = p.coeff_scalar;
+    float c = coeff_scalar_of(p);
     if (p.stat_kind != PWW_STAT_NONE) c = stat_coefficient(c, p.stat_kind, p.stats + (long)b * 4, p.stat_count);
     if (p.bias_coeff) c = c * p.bias_coeff[b];
     return c;
@@ -190,14 +206,18 @@ struct BiasRef {
     unsigned row_off;
     unsigned key_stride;   // bytes
     bool unit;             // key_stride == 4
+    // BIAS == 2: the query block's bias rows sit in LDS (pww_cross.hip stages the contiguous [rows, cols] span with coalesced
+    // 16-byte loads): the lane's row starts at lds_row, columns >= lds_cols (a multiple of 16) are known to be zero
+    const char *lds_row;
+    int lds_cols;
 };
 
-template <typename T, int KS, int DT, bool HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
+template <typename T, int KS, int DT, int HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
 __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[DT], float &m_run, float &l_run, const char *Vs,
                                                 int key0, int M, int l31, int hi, const BiasRef &bias,
                                                 float coeff, float c1);
 
-template <typename T, int KS, int DT, bool HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
+template <typename T, int KS, int DT, int HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
 __device__ __forceinline__ void attn_tile(f32x16 (&oacc)[DT], float &m_run, float &l_run,
                                           const typename Vec<T>::v8 (&qf)[KS], const char *Ks, const char *Vs,
                                           int key0, int M, int l31, int hi, const BiasRef &bias,
@@ -208,7 +228,8 @@ __device__ __forceinline__ void attn_tile(f32x16 (&oacc)[DT], float &m_run, floa
 }
 
 // scores (already in `s`) -> (bias) -> online softmax -> PV against the V tile at Vs
-template <typename T, int KS, int DT, bool HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
+// HAS_BIAS: 0 none, 1 bias rows read from global memory (per-lane buffer loads), 2 bias rows read from the LDS tile
+template <typename T, int KS, int DT, int HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
 __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[DT], float &m_run, float &l_run, const char *Vs,
                                                 int key0, int M, int l31, int hi, const BiasRef &bias,
                                                 float coeff, float c1) {
@@ -218,7 +239,38 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
     // raw-domain logits x = s + c*bias (scale > 0, so the row max commutes with the scaling)
     // (a 4-way max tree and packed v_pk_fma_f32 for the exp arguments were measured: neutral to -3%)
     float tmax = -INFINITY;
-    if (HAS_BIAS && bias.unit) {
+    if (HAS_BIAS == 2) {
+        // the lane's 8 consecutive keys of each (block, half) are 32 contiguous bytes of its row in the LDS tile; a 16-key
+        // group past the last non-zero column of the map (wave-uniform test) gets no loads and no multiply-adds at all
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int col0 = key0 + kb * 32 + 16 * g;
+                if (col0 < bias.lds_cols) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bias.lds_row + (col0 + 8 * hi) * 4);
+                    const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bias.lds_row + (col0 + 8 * hi) * 4 + 16);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = g * 8 + j;
+                        float x = fmaf(j < 4 ? b0[j] : b1[j - 4], coeff, s[kb][r]);
+                        if (MASKED) x = key0 + key_of(kb, r, hi) < M ? x : -INFINITY;
+                        s[kb][r] = x;
+                        tmax = fmaxf(tmax, x);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = g * 8 + j;
+                        float x = s[kb][r];
+                        if (MASKED) x = key0 + key_of(kb, r, hi) < M ? x : -INFINITY;
+                        s[kb][r] = x;
+                        tmax = fmaxf(tmax, x);
+                    }
+                }
+            }
+        }
+    } else if (HAS_BIAS && bias.unit) {
         // unit key stride (the PwW [N, 77] maps): a lane's 8 consecutive keys of each (block, half) are 32 contiguous
         // bytes of its bias row -> two 16-byte loads instead of eight 4-byte ones (the row stride makes every lane hit
         // its own cache line either way, so the texture-address work per tile drops 4x). Dword-aligned only, which

@@ -18,6 +18,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // ADDRESSES and forces both operands into scratch memory; on a native vector it is a register select.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -49,7 +50,11 @@ int check_hip(hipError_t e, const char *what);
 bool arch_ok();
 
 // Kernel-only timing (pww_profile_*): if this thread armed a timing slot, hand out its event pair once.
-bool profile_take(hipEvent_t *start, hipEvent_t *stop);
+bool profile_take(hipEvent_t *start, hipEvent_t *stop, hipStream_t stream);
+
+// Phase time stamps (pww_debug_timeline): the process-wide debug buffer, or null.
+unsigned long long *debug_timeline();
+size_t debug_timeline_bytes();
 
 // Launch of an attention-class kernel. An armed launch goes through hipExtLaunchKernelGGL, which stamps the dispatch's own
 // start / end device timestamps into the two events: the duration rocprofv3 reports for the kernel, free of host latency and of
@@ -57,7 +62,7 @@ bool profile_take(hipEvent_t *start, hipEvent_t *stop);
 template <typename K, typename P>
 static inline void launch_attn_kernel(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t stream, const P &params) {
     hipEvent_t e0, e1;
-    if (profile_take(&e0, &e1)) hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, stream, e0, e1, 0, params);
+    if (profile_take(&e0, &e1, stream)) hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, stream, e0, e1, 0, params);
     else hipLaunchKernelGGL(kern, grid, block, lds, stream, params);
 }
 

@@ -26,6 +26,7 @@
 // The launch is sized so that every workgroup is resident at once (the host clamps the grid to the occupancy
 // answer, at most two workgroups per CU, and gives each workgroup several query blocks when the batch is large);
 // a launch that could not be made resident takes the two-launch path instead -- same result, bit for bit.
+#include <string.h>
 #include "pww_attn_core.h"
 
 namespace pww {
@@ -38,10 +39,18 @@ struct CrossParams {
     double *stats_out;   // optional [B][4]: the folded statistics of the gated-in images
     int nqb;             // query blocks per (image, head)
     int nchunk;          // workgroups per (image, head)
+    // bias rows of a query block staged in LDS (tile_stride > 0): [NW * 32 rows][tile_stride floats], filled either from the
+    // dense map (columns < a.bias_cols; the rows of a block are one contiguous span of the [N, M] map) or from the compact form
+    int tile_stride;             // floats per tile row = bias_cols + 4 (row -> bank map odd: conflict-free 16-byte reads); 0 = per-lane global loads
+    const float *compact;        // compact bias [B?][N][R] (or null): bias[b][n][col_idx[b?][r]] = compact[b][n][r], every other column zero
+    const int *col_idx;          // [B?][R], -1 = unused slot
+    int R;
+    long c_sb, c_sn, ci_sb;      // compact strides (image, row) and col_idx image stride, in elements
 };
 
 constexpr unsigned long long SPIN_LIMIT_TICKS = 100000000ull;   // wall_clock64 runs at 100 MHz: 1 s (the grid is sized to be resident:
                                                                 // the limit only bounds the impossible case, e.g. state words left dirty by an aborted launch)
+constexpr int COMPACT_MAX_R = 32;    // compact bias: at most 32 non-zero columns (16 staged values per thread)
 
 // a slot holds ~bits(value): zero = empty (no finite or infinite double has an all-ones bit pattern)
 __device__ __forceinline__ void slot_publish(unsigned long long *p, double v) {
@@ -51,6 +60,77 @@ __device__ __forceinline__ unsigned long long slot_read(const unsigned long long
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ double slot_value(unsigned long long x) { return __longlong_as_double((long long)~x); }
+
+// ---- bias tile staging -------------------------------------------------------------------------------------------------
+// A query block's bias rows are ONE contiguous span of the [N, M] fp32 map (rows x 308 bytes for the 77 prompt tokens). Loading
+// them per lane (each lane its own row: 32 cache lines per wave-load, repeated by every head's workgroup) was what held the
+// batched launch at 13 % of HBM peak; here the workgroup copies the span with coalesced 16-byte loads -- a thread's 4 chunks of a
+// 32-column slab: 8 consecutive threads cover 128 contiguous bytes of a row -- into an LDS tile and every lane reads its row from
+// there. Only the columns below bias_cols are moved (the map of a prompt is zero past the last region phrase).
+template <int NT, typename SRD>
+__device__ __forceinline__ void tile_slab_load(u32x4 (&reg)[4], SRD srd, long row0, int N, long b_sn, int slab, int bias_cols, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = tid + i * NT, row = g >> 3, col = slab * 32 + (g & 7) * 4;
+        const bool ok = col < bias_cols && row0 + row < N;
+        reg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd, ok ? (unsigned)(((row0 + row) * b_sn + col) * 4) : OOB_OFF, 0, 0);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void tile_slab_store(const u32x4 (&reg)[4], char *tile, int tile_stride, int slab, int bias_cols, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = tid + i * NT, row = g >> 3, col = slab * 32 + (g & 7) * 4;
+        if (col < bias_cols) *reinterpret_cast<u32x4 *>(tile + ((long)row * tile_stride + col) * 4) = reg[i];
+    }
+}
+// compact form: rows x R contiguous floats of the block, scattered to their columns (the tile was zeroed once: columns outside
+// col_idx stay zero for the whole launch)
+// Thread mapping: two threads per tile row (the tile has NT / 2 rows), thread t moves slots r = (t & 1) + 2 i of row t >> 1 --
+// every address is a per-thread base plus an immediate, no index arithmetic is kept in registers. col_idx sits in LDS (cidx_lds,
+// COMPACT_MAX_R ints, -1 = unused) so the scatter reads its column right before the store.
+template <int NT>
+__device__ __forceinline__ void compact_load(u32x4 (&reg)[4], const float *cbase, long row0, int N, long c_sn, int R, int tid) {
+    const long row = row0 + (tid >> 1);
+    const float *src = cbase + row * c_sn + (tid & 1);
+    const bool row_ok = row < N;
+#pragma unroll
+    for (int i = 0; i < COMPACT_MAX_R / 2; ++i) {
+        const float v = (row_ok && (tid & 1) + 2 * i < R) ? src[2 * i] : 0.f;
+        reg[i >> 2][i & 3] = __float_as_uint(v);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void compact_store(const u32x4 (&reg)[4], float *tile, int tile_stride, const int *cidx_lds, int R, int tid) {
+    float *trow = tile + (long)(tid >> 1) * tile_stride;
+    const int *ci = cidx_lds + (tid & 1);
+#pragma unroll
+    for (int i = 0; i < COMPACT_MAX_R / 2; ++i) {
+        if ((tid & 1) + 2 * i < R) {
+            const int col = ci[2 * i];
+            if (col >= 0) trow[col] = __uint_as_float(reg[i >> 2][i & 3]);
+        }
+    }
+}
+
+// request / park one query block's bias rows (slab 0 of the dense form, or the compact values)
+template <int NT, typename SRD>
+__device__ __forceinline__ void tile_request(u32x4 (&reg)[4], bool compact, const float *cbase, SRD srd, long row0, int N, long c_sn, long b_sn,
+                                             int R, int bias_cols, int tid) {
+    if (compact) compact_load<NT>(reg, cbase, row0, N, c_sn, R, tid);
+    else tile_slab_load<NT>(reg, srd, row0, N, b_sn, 0, bias_cols, tid);
+}
+template <int NT, typename SRD>
+__device__ __forceinline__ void tile_park(u32x4 (&reg)[4], bool compact, char *tile, int tile_stride, const int *cidx, SRD srd, long row0, int N,
+                                          long b_sn, int R, int bias_cols, int tid) {
+    if (compact) { compact_store<NT>(reg, reinterpret_cast<float *>(tile), tile_stride, cidx, R, tid); return; }
+    tile_slab_store<NT>(reg, tile, tile_stride, 0, bias_cols, tid);
+    const int nslab = (bias_cols + 31) >> 5;
+    for (int slab = 1; slab < nslab; ++slab) {     // maps wider than 32 columns: the further slabs are not prefetched
+        tile_slab_load<NT>(reg, srd, row0, N, b_sn, slab, bias_cols, tid);
+        tile_slab_store<NT>(reg, tile, tile_stride, slab, bias_cols, tid);
+    }
+}
 
 template <typename T, int KS, int DT, int NW, bool SINGLE>
 __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel(const CrossParams cp) {
@@ -66,16 +146,19 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     constexpr int VPT = (NSUB * VT::NCHUNK + NT - 1) / NT;
     const AttnParams &p = cp.a;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [K|V stage][fin: NW x 4 f64][final: 4 f64][red: NW x 4 f32][flag]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [K|V stage][fin: NW x 4 f64][final: 4 f64][red: NW x 4 f32][flag][col_idx][bias tile]
     double *fin = reinterpret_cast<double *>(smem + STAGE_BYTES);
     double *final_st = fin + NW * 4;
     float *red = reinterpret_cast<float *>(final_st + 4);
     volatile int *ok_flag = reinterpret_cast<volatile int *>(red + NW * 4);
+    int *cidx_lds = reinterpret_cast<int *>(red + NW * 4) + 4;                 // COMPACT_MAX_R ints
+    char *tile = reinterpret_cast<char *>(cidx_lds + COMPACT_MAX_R);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
     const int BH = p.B * p.H;
+    tl_stamp(p, 0);
     // Workgroup -> (image, head, query chunk). The hardware deals workgroup i to XCD i % 8, and the only bytes two workgroups of this
     // kernel share are the bias rows of a query block (the same [rows, 77] fp32 tile for all H heads of an image). With the plain
     // order (heads fastest) every XCD's L2 ends up fetching the whole map (measured: 11.9 MB fetched per launch for 6.7 MB of
@@ -92,22 +175,49 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     const int b = bh / p.H, h = bh - b * p.H;
 
     const float gate = p.bias_coeff ? p.bias_coeff[b] : 1.f;
-    const bool biased = p.bias != nullptr && gate != 0.f;                 // workgroup-uniform
+    const bool biased = (p.bias != nullptr || cp.compact != nullptr) && gate != 0.f;      // workgroup-uniform
     const bool need_stat = biased && p.stat_kind != PWW_STAT_NONE;
+    const bool use_tile = biased && cp.tile_stride > 0;
+    const bool use_compact = use_tile && cp.compact != nullptr;
 
     const T *Qp = reinterpret_cast<const T *>(p.q) + b * p.q_sb + h * p.q_sh;
     const T *Kp = reinterpret_cast<const T *>(p.k) + b * p.k_sb + h * p.k_sh;
     const T *Vp = reinterpret_cast<const T *>(p.v) + b * p.v_sb + h * p.v_sh;
     T *Op = reinterpret_cast<T *>(p.o) + b * p.o_sb + h * p.o_sh;
 
+    // first query block of this workgroup: its Q fragments are requested before anything else (SINGLE: they stay in
+    // registers for both passes; otherwise every iteration requests the NEXT block's fragments before it computes)
     V8 qf[KS];
-    if constexpr (SINGLE) {   // one query block per workgroup: its Q fragments stay in registers for both passes
+    {
         const int qrow = (chunk * NW + wave) * 32 + l31;
         load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qrow < p.N, hi, p.D);
     }
 
+    BiasRef bias;
+    bias.lds_row = tile + (long)(wave * 32 + l31) * cp.tile_stride * 4;
+    bias.lds_cols = p.bias_cols;
+    const float *cbase = nullptr;
+    const int *cidx = nullptr;
+    if (biased && !use_compact) {
+        const float *bbase = p.bias + b * p.b_sb + h * p.b_sh;
+        const unsigned bytes = (unsigned)((((long)(p.N - 1) * p.b_sn + (long)(p.M - 1) * p.b_sm) + 1) * 4);
+        bias.srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bbase), 0, bytes, 0x00020000);
+        bias.key_stride = (unsigned)(p.b_sm * 4);
+        bias.unit = p.b_sm == 1;
+    }
+    if (use_compact) {
+        cbase = cp.compact + b * cp.c_sb;
+        if (tid < COMPACT_MAX_R) cidx_lds[tid] = tid < cp.R ? cp.col_idx[b * cp.ci_sb + tid] : -1;     // (visible after the prologue's barrier)
+        cidx = cidx_lds;
+    }
+    u32x4 treg[4];                          // staging registers of the bias tile
+
     // K and V of this head -> LDS (rows past M and the head-dim padding are zeros)
     for (int i = tid * 16; i < STAGE_BYTES; i += NT * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0u, 0u, 0u, 0u};
+    if (use_compact) {
+        const int tbytes = NW * 32 * cp.tile_stride * 4;
+        for (int i = tid * 16; i < tbytes; i += NT * 16) *reinterpret_cast<u32x4 *>(tile + i) = u32x4{0u, 0u, 0u, 0u};
+    }
     {
         StagePlan<KPT, VPT> plan;
         make_plan<T, KS, DT, NT, NSUB, KPT, VPT>(plan, tid, p.D, p.k_sm, p.v_sm);
@@ -116,19 +226,27 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
         u32x4 kreg[KPT];
         u32x4 vreg[VPT];
         stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);
+        // SINGLE: the (only) block's bias rows travel with K and V (one latency for all three)
+        if (SINGLE && use_tile) tile_request<NT>(treg, use_compact, cbase, bias.srd, (long)chunk * NW * 32, p.N, cp.c_sn, p.b_sn, cp.R, p.bias_cols, tid);
         __syncthreads();                      // the zero fill is complete
         stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
+        if (SINGLE && use_tile) tile_park<NT>(treg, use_compact, tile, cp.tile_stride, cidx, bias.srd, (long)chunk * NW * 32, p.N, p.b_sn, cp.R, p.bias_cols, tid);
     }
     __syncthreads();
+    tl_stamp(p, 1);
 
     float coeff = 0.f;
     unsigned depart_prev = 0u;     // lane 0 of the workgroup: how many workgroups of the image had left before this one
     if (need_stat) {
         // ---- pass 1: per query block (max, min, sum, sum of squares) of the raw scores, as pww_qk_reduce computes them
+        V8 qn[KS];
         for (int qb = chunk; qb < cp.nqb; qb += cp.nchunk) {
             const int qrow = (qb * NW + wave) * 32 + l31;
             const bool qvalid = qrow < p.N;
-            if constexpr (!SINGLE) load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qvalid, hi, p.D);
+            if constexpr (!SINGLE) {       // next block's fragments fly while this block is scored
+                const int nrow = ((qb + cp.nchunk) * NW + wave) * 32 + l31;
+                load_q_frags<T, KS>(qn, Qp + (long)nrow * p.q_sn, qb + cp.nchunk < cp.nqb && nrow < p.N, hi, p.D);
+            }
             float vmax = -INFINITY, vmin = INFINITY, vsum = 0.f, vsq = 0.f;
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) {
@@ -175,6 +293,15 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
                 slot_publish(slot + 0, dmax); slot_publish(slot + 1, dmin);
                 slot_publish(slot + 2, dsum); slot_publish(slot + 3, dsq);
             }
+            if constexpr (!SINGLE) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
+            }
+        }
+        tl_stamp(p, 2);
+        if constexpr (!SINGLE) {   // pass 2 starts over at the first block: request its fragments before the hand-off
+            const int qrow = (chunk * NW + wave) * 32 + l31;
+            load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qrow < p.N, hi, p.D);
         }
         // ---- hand-off + fold: every workgroup folds the image's partials itself (the order of pww_qk_reduce's
         // last-arriver fold), re-reading them until none is empty
@@ -230,45 +357,57 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
             }
             __syncthreads();
             const double st[4] = {final_st[0], final_st[1], final_st[2], final_st[3]};
-            coeff = stat_coefficient(p.coeff_scalar, p.stat_kind, st, p.stat_count);
+            coeff = stat_coefficient(coeff_scalar_of(p), p.stat_kind, st, p.stat_count);
             if (p.bias_coeff) coeff = coeff * gate;
             if (!*ok_flag) coeff = __builtin_nanf("");     // a hand-off that timed out must not look like a result
         }
+        tl_stamp(p, 3);
     } else if (biased) {
-        coeff = p.coeff_scalar;
+        coeff = coeff_scalar_of(p);
         if (p.bias_coeff) coeff = coeff * gate;
     }
 
     // ---- pass 2: bias -> softmax -> PV per query block
-    BiasRef bias;
-    if (biased) {
-        const float *bbase = p.bias + b * p.b_sb + h * p.b_sh;
-        const unsigned bytes = (unsigned)((((long)(p.N - 1) * p.b_sn + (long)(p.M - 1) * p.b_sm) + 1) * 4);
-        bias.srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bbase), 0, bytes, 0x00020000);
-        bias.key_stride = (unsigned)(p.b_sm * 4);
-        bias.unit = p.b_sm == 1;
-    }
     const float c1 = p.scale_log2e;
+    V8 qn[KS];
     for (int qb = chunk; qb < cp.nqb; qb += cp.nchunk) {
         const int qrow = (qb * NW + wave) * 32 + l31;
         const bool qvalid = qrow < p.N;
-        if constexpr (!SINGLE) load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qvalid, hi, p.D);
-        if (biased) bias.row_off = qvalid ? (unsigned)((long)qrow * p.b_sn * 4) : OOB_OFF;
+        if constexpr (!SINGLE) {
+            const int nrow = ((qb + cp.nchunk) * NW + wave) * 32 + l31;
+            load_q_frags<T, KS>(qn, Qp + (long)nrow * p.q_sn, qb + cp.nchunk < cp.nqb && nrow < p.N, hi, p.D);
+            // this block's bias rows: requested now, they land under the first sub-tile's score MFMAs
+            if (use_tile) tile_request<NT>(treg, use_compact, cbase, bias.srd, (long)qb * NW * 32, p.N, cp.c_sn, p.b_sn, cp.R, p.bias_cols, tid);
+        }
+        if (biased && !use_tile) bias.row_off = qvalid ? (unsigned)((long)qrow * p.b_sn * 4) : OOB_OFF;
         f32x16 oacc[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;
+        if (use_tile) {
+            f32x16 s0[2];
+            score_tile<T, KS>(s0, qf, smem, 0, p.M, l31, hi);
+            if constexpr (!SINGLE) {
+                __syncthreads();            // every wave is done reading the previous block's rows
+                tile_park<NT>(treg, use_compact, tile, cp.tile_stride, cidx, bias.srd, (long)qb * NW * 32, p.N, p.b_sn, cp.R, p.bias_cols, tid);
+                __syncthreads();
+            }
+            attn_tile_sm_pv<T, KS, DT, 2, true, false>(s0, oacc, m_run, l_run, smem + KT::BYTES, 0, p.M, l31, hi, bias, coeff, c1);
+            if (KVBLK < p.M)
+                attn_tile<T, KS, DT, 2, true, false>(oacc, m_run, l_run, qf, smem + SUB_BYTES, smem + SUB_BYTES + KT::BYTES, KVBLK, p.M, l31, hi, bias, coeff, c1);
+        } else {
 #pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub) {
-            const int key0 = sub * KVBLK;
-            if (key0 < p.M) {
-                const char *Ks = smem + sub * SUB_BYTES;
-                if (biased)
-                    attn_tile<T, KS, DT, true, true, false>(oacc, m_run, l_run, qf, Ks, Ks + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
-                else
-                    attn_tile<T, KS, DT, false, true, false>(oacc, m_run, l_run, qf, Ks, Ks + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
+            for (int sub = 0; sub < NSUB; ++sub) {
+                const int key0 = sub * KVBLK;
+                if (key0 < p.M) {
+                    const char *Ks = smem + sub * SUB_BYTES;
+                    if (biased)
+                        attn_tile<T, KS, DT, 1, true, false>(oacc, m_run, l_run, qf, Ks, Ks + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
+                    else
+                        attn_tile<T, KS, DT, 0, true, false>(oacc, m_run, l_run, qf, Ks, Ks + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
+                }
             }
         }
         const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -289,7 +428,12 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
                 }
             }
         }
+        if constexpr (!SINGLE) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
+        }
     }
+    tl_stamp(p, 4);
 
     // ---- the last workgroup of an image to leave puts the image's state words back to zero. (Every other workgroup of
     // the image has finished reading the slots: a workgroup leaves only after its fold. Last of its head -> bumps the
@@ -312,13 +456,14 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
             if (tid == 0) __hip_atomic_store(cp.sync + p.B * p.H + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    tl_stamp(p, 5);
 }
 
 // ---- host side -------------------------------------------------------------------------------
 
 int attn_fwd(const void *q, const void *k, const void *v, void *o, const float *bias, const float *bias_coeff,
              const pww_attn_desc_t *d, hipStream_t stream, const double *stats, int stat_kind, double stat_count,
-             float coeff_scalar);
+             float coeff_scalar, const float *coeff_scalar_dev);
 int attn_validate(const void *q, const void *k, const void *v, void *o, const float *bias, const pww_attn_desc_t *d);
 void attn_fill_params(AttnParams &p, const void *q, const void *k, const void *v, void *o, const float *bias,
                       const float *bias_coeff, const pww_attn_desc_t *d);
@@ -338,24 +483,51 @@ static int device_cus() {
     return cus;
 }
 
+static int fused_wg_cap() {   // PWW_CROSS_WG_PER_CU: upper bound on the resident workgroups per CU the fused launch counts on (A/B testing)
+    static int cap = -1;
+    if (cap < 0) { const char *e = getenv("PWW_CROSS_WG_PER_CU"); cap = e ? atoi(e) : 4; if (cap < 1) cap = 1; }
+    return cap;
+}
+static int fused_assume_resident() {   // PWW_CROSS_ASSUME_RESIDENT=n: TEST HOOK -- count on n workgroups per CU whatever the occupancy query says
+    static int n = -1;                 // (tests/test_round3_gpu.py drives the hand-off's time-out / error-word path with it)
+    if (n < 0) { const char *e = getenv("PWW_CROSS_ASSUME_RESIDENT"); n = e ? atoi(e) : 0; if (n < 0) n = 0; }
+    return n;
+}
+
 template <typename T, int KS, int DT, int NW>
 static int launch_cross(CrossParams cp, hipStream_t stream, bool *launched) {
-    constexpr size_t lds = 2 * (KTile<KS>::BYTES + VTile<DT>::BYTES) + NW * 4 * 8 + 4 * 8 + NW * 4 * 4 + 16;
+    constexpr size_t lds_fixed = 2 * (KTile<KS>::BYTES + VTile<DT>::BYTES) + NW * 4 * 8 + 4 * 8 + NW * 4 * 4 + 16 + COMPACT_MAX_R * 4;
+    const size_t lds = lds_fixed + (size_t)NW * 32 * cp.tile_stride * 4;
     auto k_single = cross_fused_kernel<T, KS, DT, NW, true>;
     auto k_multi = cross_fused_kernel<T, KS, DT, NW, false>;
-    static thread_local int per_cu = -1;
+    // resident workgroups per CU for this LDS size (the tile width is a run-time value): asked once per size
+    static thread_local size_t lds_seen[8];
+    static thread_local int per_cu_seen[8];
+    static thread_local int n_seen = 0;
+    static thread_local size_t lds_attr = 0;
+    int per_cu = -1;
+    for (int i = 0; i < n_seen; ++i) if (lds_seen[i] == lds) per_cu = per_cu_seen[i];
     if (per_cu < 0) {
-        for (auto kern : {k_single, k_multi})
-            if (lds > 64 * 1024 && check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"))
-                return PWW_EHIP;
+        if (lds > 160 * 1024) { *launched = false; return PWW_OK; }
+        if (lds > 64 * 1024 && lds > lds_attr) {
+            for (auto kern : {k_single, k_multi})
+                if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)),
+                              "hipFuncSetAttribute"))
+                    return PWW_EHIP;
+            lds_attr = 160 * 1024;
+        }
         int n1 = 0, n2 = 0;
         if (check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_single, NW * 64, lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor") ||
             check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, k_multi, NW * 64, lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor"))
             return PWW_EHIP;
-        // never count on more than two resident workgroups per CU (the API can be one high near an SGPR edge -- MI355X_MICROARCH.md)
+        // every workgroup of the launch must be resident at once (the hand-off spins on partials of workgroups that have to be
+        // running). The occupancy answer can be one high near an SGPR edge when it says 7 or 8 (MI355X_MICROARCH.md); this
+        // kernel's answers are LDS / VGPR bound (<= 4) and taken as they are, up to 4.
         per_cu = n1 < n2 ? n1 : n2;
-        per_cu = per_cu > 2 ? 2 : per_cu;
+        if (per_cu >= 7) per_cu -= 1;
+        if (per_cu > fused_wg_cap()) per_cu = fused_wg_cap();
+        if (fused_assume_resident()) per_cu = fused_assume_resident();
+        if (n_seen < 8) { lds_seen[n_seen] = lds; per_cu_seen[n_seen] = per_cu; ++n_seen; }
     }
     const AttnParams &p = cp.a;
     const long cap = (long)per_cu * device_cus();
@@ -399,11 +571,24 @@ size_t cross_fused_state_bytes(const pww_attn_desc_t *d) {
     return state_sync_bytes(d) + (size_t)d->B * ((d->N + 63) / 64) * d->H * 4 * sizeof(unsigned long long);
 }
 
+static int bias_tile_mode() {   // PWW_CROSS_BIAS_LDS=0: per-lane global bias loads as in round 2 (A/B testing); default: LDS tile
+    static int mode = -2;
+    if (mode == -2) { const char *e = getenv("PWW_CROSS_BIAS_LDS"); mode = e ? atoi(e) : 1; }
+    return mode;
+}
+
 int cross_attn_fused(const void *q, const void *k, const void *v, void *o, const float *bias, int stat_kind, float coeff_scalar,
                      const float *gate, const pww_attn_desc_t *d, double *stats_out, void *state, size_t state_bytes,
-                     void *workspace, size_t workspace_bytes, hipStream_t stream) {
+                     void *workspace, size_t workspace_bytes, const pww_cross_opts_t *opts, hipStream_t stream) {
     if (int rc = attn_validate(q, k, v, o, bias, d)) return rc;
-    if (!bias) { set_error("cross_attn_fused: bias map required"); return PWW_EINVAL; }
+    pww_cross_opts_t op;
+    memset(&op, 0, sizeof(op));
+    if (opts) {
+        if (opts->size < 16 || opts->size > sizeof(op)) { set_error("cross_attn_fused: pww_cross_opts_t.size = %u is not a known layout", opts->size); return PWW_EINVAL; }
+        memcpy(&op, opts, opts->size);
+    }
+    const bool compact = op.bias_compact != nullptr;
+    if (!bias && !compact) { set_error("cross_attn_fused: bias map required (dense, compact or both)"); return PWW_EINVAL; }
     if (d->M > 2 * KVBLK) { set_error("cross_attn_fused: at most %d keys (got %d)", 2 * KVBLK, d->M); return PWW_ENOTSUP; }
     if (stat_kind < PWW_STAT_NONE || stat_kind > PWW_STAT_ABSMAX) { set_error("cross_attn_fused: bad statistic selector %d", stat_kind); return PWW_EINVAL; }
     if (!state || state_bytes < cross_fused_state_bytes(d) || (reinterpret_cast<uintptr_t>(state) & 7)) {
@@ -414,13 +599,33 @@ int cross_attn_fused(const void *q, const void *k, const void *v, void *o, const
         set_error("cross_attn_fused: workspace missing, misaligned or too small (need %zu bytes, 8-byte aligned)", cross_fused_workspace_bytes(d));
         return PWW_EINVAL;
     }
+    const int m16 = (d->M + 15) & ~15;
+    int bias_cols = op.bias_cols > 0 ? ((op.bias_cols + 15) & ~15) : m16;
+    if (bias_cols > m16) bias_cols = m16;
+    if (compact) {
+        if (!op.col_idx || op.R < 1 || op.R > COMPACT_MAX_R) { set_error("cross_attn_fused: compact bias needs col_idx and 1 <= R <= %d (got %d)", COMPACT_MAX_R, op.R); return PWW_EINVAL; }
+        if ((reinterpret_cast<uintptr_t>(op.bias_compact) & 3) || (reinterpret_cast<uintptr_t>(op.col_idx) & 3) || op.compact_stride[0] < 0 ||
+            op.compact_stride[1] < op.R || op.col_idx_stride < 0) {
+            set_error("cross_attn_fused: compact bias must be 4-byte aligned with row stride >= R and non-negative image strides");
+            return PWW_EINVAL;
+        }
+    }
     CrossParams cp;
     attn_fill_params(cp.a, q, k, v, o, bias, gate, d);
+    cp.a.bias_coeff = gate;     // (attn_fill_params drops the coefficient pointer when the dense map is absent)
     cp.a.stats = nullptr; cp.a.stat_kind = stat_kind; cp.a.stat_count = (double)d->H * d->N * d->M; cp.a.coeff_scalar = coeff_scalar;
+    cp.a.coeff_scalar_dev = op.coeff_scalar_dev;
+    cp.a.bias_cols = bias_cols;
     cp.sync = reinterpret_cast<unsigned *>(state);
     cp.slots = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(state) + state_sync_bytes(d));
     cp.stats_out = stats_out;
     cp.nqb = cp.nchunk = 0;
+    // the LDS tile needs unit key stride (dense form) or the compact form; PWW_CROSS_BIAS_LDS=0 keeps the per-lane loads (dense only)
+    const bool tile_ok = compact || (d->bias_stride[3] == 1 && bias_tile_mode() == 1);
+    cp.tile_stride = tile_ok ? bias_cols + 4 : 0;
+    cp.compact = compact ? op.bias_compact : nullptr;
+    cp.col_idx = op.col_idx; cp.R = op.R;
+    cp.c_sb = op.compact_stride[0]; cp.c_sn = op.compact_stride[1]; cp.ci_sb = op.col_idx_stride;
     bool launched = false;
     const bool wide = attn_wide_groups(d);
     int rc;
@@ -428,13 +633,14 @@ int cross_attn_fused(const void *q, const void *k, const void *v, void *o, const
     else rc = wide ? dispatch_cross_d<bf16, 4>(cp, stream, &launched) : dispatch_cross_d<bf16, 2>(cp, stream, &launched);
     if (rc || launched) return rc;
     // more (image, head) pairs than resident workgroups: statistic and attention as two launches, same arithmetic
+    if (!bias) { set_error("cross_attn_fused: this launch cannot be made resident (B*H = %d) and the two-launch path needs the dense bias map", d->B * d->H); return PWW_ENOTSUP; }
     char *ws = reinterpret_cast<char *>(workspace);
     const size_t red_bytes = (qk_reduce_workspace_bytes(d) + 63) & ~(size_t)63;
     double *stats = stats_out ? stats_out : reinterpret_cast<double *>(ws + red_bytes);
     if (stat_kind != PWW_STAT_NONE)
         if (int rc2 = qk_reduce(q, k, d, stats, ws, red_bytes, stream)) return rc2;
     return attn_fwd(q, k, v, o, bias, gate, d, stream, stat_kind != PWW_STAT_NONE ? stats : nullptr, stat_kind,
-                    (double)d->H * d->N * d->M, coeff_scalar);
+                    (double)d->H * d->N * d->M, coeff_scalar, op.coeff_scalar_dev);
 }
 
 }  // namespace pww

@@ -88,9 +88,12 @@ def prepare_mask_latents(vae, mask, masked_image, batch_size, height, width, dty
     return mask.repeat(reps, 1, 1, 1), latent.repeat(reps, 1, 1, 1).to(device=device, dtype=dtype)
 
 
-def _inpaint_inputs(vae, init_image, mask_image, seed, scheduler, timesteps, device):
-    """One request's (noised latents [1,4,h,w], extra channels [1,5,h,w]) -- reference :201-228."""
+def _inpaint_inputs(vae, init_image, mask_image, seed, scheduler, timesteps, device, mask_hw=None):
+    """One request's (noised latents [1,4,h,w], extra channels [1,5,h,w]) -- reference :201-228. `mask_hw`: the pipeline
+    class sizes the latent mask by its `height` / `width` arguments (:498-508) instead of by the init image."""
     width, height = init_image.size
+    if mask_hw is not None:
+        height, width = mask_hw
     generator = torch.manual_seed(seed)
     image = preprocess(init_image).to(device=device)
     init_latents = 0.18215 * vae.encode(image.to(vae.dtype)).latent_dist.sample().float()
@@ -100,6 +103,10 @@ def _inpaint_inputs(vae, init_image, mask_image, seed, scheduler, timesteps, dev
     rgb, m8 = _as_uint8_pixels(init_image, 3), _as_uint8_pixels(mask_image, 1)
     _, masked_image, mask_lat = _prep_on_device(rgb, m8, device, lat_hw=(height // 8, width // 8))
     masked_latents = 0.18215 * vae.encode(masked_image.to(vae.dtype)).latent_dist.sample().to(latents.dtype)
+    if mask_hw is not None and (mask_lat.shape[-2:] != latents.shape[-2:] or masked_latents.shape[-2:] != latents.shape[-2:]):
+        # the reference's pipeline fails in torch.cat here (:532): `height` / `width` must be the size of `image`
+        raise ValueError(f"`height` x `width` = {height} x {width} gives a {tuple(mask_lat.shape[-2:])} latent mask but `image` gives "
+                         f"{tuple(latents.shape[-2:])} latents: pass the size of `image` (a multiple of 32)")
     if mask_lat.shape[-2:] != latents.shape[-2:]:      # sizes that `preprocess` rounds down to a multiple of 32 (:213-214)
         mask_lat = F.interpolate(mask_lat, size=latents.shape[-2:], mode="nearest")
         masked_latents = F.interpolate(masked_latents, size=latents.shape[-2:], mode="nearest")
@@ -107,16 +114,21 @@ def _inpaint_inputs(vae, init_image, mask_image, seed, scheduler, timesteps, dev
 
 
 def _generate_inpaint(tools, device, color_contexts, color_map_images, mask_images, init_images, prompts, seeds,
-                      num_inference_steps, guidance_scale, weight_function, unconditional_input_prompt, strength, shared):
+                      num_inference_steps, guidance_scale, weight_function, unconditional_input_prompt, strength, shared,
+                      on_step=None, mask_hw=None, resize_inputs=True, use_region_sigma=True):
+    """Shared body of paint_with_words_inpaint / _batch / the inpaint pipeline class. The function API resizes color map and
+    mask to the init image (:172-173, `resize_inputs`); the pipeline class does not and sizes the latent mask by `mask_hw`."""
     vae, unet, text_encoder, tokenizer, scheduler = tools
     n = len(seeds)
     sampler = _sampler_for(unet, scheduler, _mode())
     conds, unconds = [], []
     for i in range(1 if shared else n):
         width, height = init_images[i].size
-        color_map = color_map_images[i].resize((width, height), Image.NEAREST)      # :172
+        color_map = color_map_images[i]
+        if resize_inputs and color_map is not None:
+            color_map = color_map.resize((width, height), Image.NEAREST)            # :172
         _, _, cond, uncond = _encode_text_color_inputs(text_encoder, tokenizer, device, color_map, color_contexts[i], prompts[i],
-                                                       unconditional_input_prompt, dtype=_unet_dtype(unet))
+                                                       unconditional_input_prompt, dtype=_unet_dtype(unet), use_sigma=use_region_sigma)
         conds.append(cond), unconds.append(uncond)
     if shared:
         conds, unconds = conds[0], unconds[0]
@@ -130,8 +142,10 @@ def _generate_inpaint(tools, device, color_contexts, color_map_images, mask_imag
     lats, extras = [], []
     for i in range(n):
         width, height = init_images[i].size
-        mask_image = mask_images[i].resize((width, height), Image.NEAREST)          # :173
-        lat, extra = _inpaint_inputs(vae, init_images[i], mask_image, seeds[i], scheduler, timesteps, device)
+        mask_image = mask_images[i].resize((width, height), Image.NEAREST) if resize_inputs else mask_images[i]      # :173
+        if mask_image.size != init_images[i].size:
+            raise AssertionError("Image and Mask must have the same spatial dimensions")                            # :72-73
+        lat, extra = _inpaint_inputs(vae, init_images[i], mask_image, seeds[i], scheduler, timesteps, device, mask_hw=mask_hw)
         lats.append(lat), extras.append(extra)
     latents, extra = torch.cat(lats, dim=0), torch.cat(extras, dim=0)
 
@@ -143,7 +157,7 @@ def _generate_inpaint(tools, device, color_contexts, color_map_images, mask_imag
             f"channels but received {n_lat} latent + 1 mask + {n_extra - 1} masked-image latent channels = {n_lat + n_extra}. "
             "Please verify the config of `pipeline.unet` or your `mask_image` or `image` input.")
     with pww_hip.miopen_find():
-        return sampler.sample(conds, unconds, latents, timesteps, guidance_scale, weight_function, extra_channels=extra)
+        return sampler.sample(conds, unconds, latents, timesteps, guidance_scale, weight_function, extra_channels=extra, on_step=on_step)
 
 
 @torch.no_grad()

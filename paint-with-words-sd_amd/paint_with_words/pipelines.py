@@ -9,6 +9,9 @@ Behaviour the reference's pipeline variant has and the function API has not, kep
   * the per-region blur sigma is parsed and dropped (:574); `eta` doubles as the img2img strength (:735);
   * `latents`, `generator` and `num_images_per_prompt` are accepted and not used (:744-753 is commented out in the
     reference; the latents always come from `seed`): passing a non-default value warns once instead of failing;
+  * the inpaint class takes color map and mask as given (no resize to the init image, unlike the function API :172-173),
+    sizes the latent mask by `height` / `width` (paint_with_words_inpaint.py:427-432, :498-508 -- they must be the size of
+    `image`) and calls `callback(i, t, latents)` every `callback_steps` steps (:555-559);
   * the safety checker never runs (`nsfw_content_detected` is False, :829).
 """
 import math
@@ -169,20 +172,27 @@ class PaintWithWord_StableDiffusionInpaintPipeline(PaintWithWord_StableDiffusion
         callback: Optional[Callable[[int, int, torch.FloatTensor], None]] = None,
         callback_steps: Optional[int] = 1,
     ):
-        """reference paint_with_words_inpaint.py:389-575."""
+        """reference paint_with_words_inpaint.py:340-575 (same parameter list, order and defaults)."""
         if image is None or mask_image is None:
             raise ValueError("`image` and `mask_image` are required for inpainting")
+        height = height or self._default_side()                      # :427-428
+        width = width or self._default_side()
+        if height % 8 or width % 8:                                   # check_inputs of the diffusers base class (:431)
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if callback_steps is None or not isinstance(callback_steps, int) or callback_steps <= 0:
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type {type(callback_steps)}.")
         if not isinstance(prompt, str):
             if not isinstance(prompt, (list, tuple)) or len(prompt) != 1:
                 raise ValueError("`prompt` has to be a str (the reference's pipeline generates one image per call)")
             prompt = prompt[0]
         if isinstance(negative_prompt, (list, tuple)):
             negative_prompt = negative_prompt[0] if negative_prompt else ""
-        for name, value, default in (("height", height, None), ("width", width, None), ("num_images_per_prompt", num_images_per_prompt, 1),
-                                     ("generator", generator, None), ("latents", latents, None), ("callback", callback, None)):
+        for name, value, default in (("num_images_per_prompt", num_images_per_prompt, 1), ("generator", generator, None), ("latents", latents, None)):
             _unused(name, value, default)
         lat = _inp._generate_inpaint(self._tools(), str(self.device), [color_context], [color_map_image], [mask_image], [image], [prompt],
-                                     [seed], num_inference_steps, guidance_scale, weight_function, negative_prompt or "", eta, shared=True)
+                                     [seed], num_inference_steps, guidance_scale, weight_function, negative_prompt or "", eta, shared=True,
+                                     on_step=self._callback_adapter(callback, callback_steps), mask_hw=(height, width), resize_inputs=False,
+                                     use_region_sigma=False)
         images = _decode(self.vae, lat, output_type)
         if not return_dict:
             return (images, False)

@@ -15,9 +15,10 @@ MAX_HEAD_DIM = 160
 
 # every symbol include/pww_hip.h declares (tests check the library exports all of them)
 EXPORTS = ("pww_version", "pww_last_error", "pww_device_arch", "pww_self_attn_fwd", "pww_cross_attn_fwd",
-           "pww_cross_attn_fwd_stat", "pww_cross_attn_fwd_fused", "pww_cross_fused_workspace_bytes", "pww_cross_fused_state_bytes",
+           "pww_cross_attn_fwd_stat", "pww_cross_attn_fwd_fused", "pww_cross_attn_fwd_stat_ex", "pww_cross_attn_fwd_fused_ex",
+           "pww_cross_fused_workspace_bytes", "pww_cross_fused_state_bytes",
            "pww_qk_reduce", "pww_mask_build", "pww_mask_build_rgb", "pww_mask_build_f32", "pww_resize_tokens", "pww_gauss_blur", "pww_inpaint_prep", "pww_cfg_combine",
-           "pww_workspace_bytes", "pww_profile_arm", "pww_profile_elapsed_us", "pww_profile_reset")
+           "pww_workspace_bytes", "pww_profile_arm", "pww_profile_elapsed_us", "pww_profile_reset", "pww_debug_timeline")
 
 
 class AttnDesc(ctypes.Structure):
@@ -27,6 +28,13 @@ class AttnDesc(ctypes.Structure):
                 ("q_stride", ctypes.c_int64 * 3), ("k_stride", ctypes.c_int64 * 3),
                 ("v_stride", ctypes.c_int64 * 3), ("o_stride", ctypes.c_int64 * 3),
                 ("scale", ctypes.c_float), ("bias_stride", ctypes.c_int64 * 4)]
+
+
+class CrossOpts(ctypes.Structure):
+    """struct pww_cross_opts (optional arguments of the *_ex cross-attention entry points)."""
+    _fields_ = [("size", ctypes.c_uint32), ("bias_cols", ctypes.c_int32), ("coeff_scalar_dev", ctypes.c_void_p),
+                ("bias_compact", ctypes.c_void_p), ("col_idx", ctypes.c_void_p), ("R", ctypes.c_int32), ("_pad", ctypes.c_int32),
+                ("compact_stride", ctypes.c_int64 * 2), ("col_idx_stride", ctypes.c_int64)]
 
 
 class Region(ctypes.Structure):
@@ -61,6 +69,12 @@ def load():
     lib.pww_cross_attn_fwd_stat.argtypes = [vp, vp, vp, vp, vp, vp, i32, ctypes.c_double, f32, vp, ctypes.POINTER(AttnDesc), vp]
     lib.pww_cross_attn_fwd_fused.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp, ctypes.POINTER(AttnDesc), vp, vp, ctypes.c_size_t, vp,
                                              ctypes.c_size_t, vp]
+    lib.pww_cross_attn_fwd_stat_ex.argtypes = [vp, vp, vp, vp, vp, vp, i32, ctypes.c_double, f32, vp, ctypes.POINTER(AttnDesc),
+                                               ctypes.POINTER(CrossOpts), vp]
+    lib.pww_cross_attn_fwd_fused_ex.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp, ctypes.POINTER(AttnDesc), vp, vp, ctypes.c_size_t, vp,
+                                                ctypes.c_size_t, ctypes.POINTER(CrossOpts), vp]
+    lib.pww_debug_timeline.argtypes = [vp, ctypes.c_size_t]
+    lib.pww_debug_timeline.restype = None
     lib.pww_cross_fused_workspace_bytes.argtypes = [ctypes.POINTER(AttnDesc)]
     lib.pww_cross_fused_workspace_bytes.restype = ctypes.c_size_t
     lib.pww_cross_fused_state_bytes.argtypes = [ctypes.POINTER(AttnDesc)]
@@ -81,11 +95,12 @@ def load():
     lib.pww_profile_elapsed_us.restype = ctypes.c_int
     lib.pww_profile_reset.argtypes = []
     lib.pww_profile_reset.restype = None
-    for name in ("pww_device_arch", "pww_self_attn_fwd", "pww_cross_attn_fwd", "pww_cross_attn_fwd_stat", "pww_cross_attn_fwd_fused", "pww_qk_reduce", "pww_mask_build",
+    for name in ("pww_device_arch", "pww_self_attn_fwd", "pww_cross_attn_fwd", "pww_cross_attn_fwd_stat", "pww_cross_attn_fwd_fused",
+                 "pww_cross_attn_fwd_stat_ex", "pww_cross_attn_fwd_fused_ex", "pww_qk_reduce", "pww_mask_build",
                  "pww_mask_build_rgb", "pww_mask_build_f32", "pww_resize_tokens", "pww_gauss_blur", "pww_inpaint_prep", "pww_cfg_combine"):
         getattr(lib, name).restype = ctypes.c_int
-    if lib.pww_version() // 100 != 1 or lib.pww_version() < 111:
-        raise PwwHipError("libpww_hip ABI version %d is not 1.x >= 1.11 (rebuild: python paint-with-words-sd_amd/build.py)" % lib.pww_version())
+    if lib.pww_version() // 100 != 1 or lib.pww_version() < 120:
+        raise PwwHipError("libpww_hip ABI version %d is not 1.x >= 1.20 (rebuild: python paint-with-words-sd_amd/build.py)" % lib.pww_version())
     _lib = lib
     return lib
 

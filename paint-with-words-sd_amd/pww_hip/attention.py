@@ -24,7 +24,13 @@ _HALF = (torch.float16, torch.bfloat16)
 ROW_GATE = "_PWW_ROW_GATE"   # private context key: fp32 [B] per-row bias coefficient (see pww_hip/sampler.py)
 _LAZY_W = True               # hand weight_function a ScaledW instead of the raw map (see ScaledW)
 KV_CACHE = "_PWW_KV_CACHE"   # private context key: {id(attn): (attn, [B, 77, 2C] fused K|V projection)} for one request
-FUSED_CROSS = os.environ.get("PWW_FUSED_CROSS", "1") != "0"   # statistic + attention in one launch (pww_cross_attn_fwd_fused); 0 = two launches (A/B)
+COEFF_SLOTS = "_PWW_COEFF_SLOTS"   # private context key: CoeffSlots (hipGraph mode: the weight function's per-step scalars live in device words)
+BIAS_COLS = "_PWW_BIAS_COLS"       # private context key: int, columns >= this of every weight map of the context are zero
+COMPACT_W = "_PWW_COMPACT_W_"      # private context key prefix: compact form [N, R] (or [B, N, R]) of CROSS_ATTENTION_WEIGHT_<N>
+COMPACT_IDX = "_PWW_COMPACT_IDX"   # private context key: int32 [R] (or [B, R]) columns of the compact slots, -1 = unused
+# statistic + attention in one launch (pww_cross_attn_fwd_fused); 0 = two launches (A/B). The fused launch needs all its workgroups
+# resident at once: two ranks sharing one device (PWW_DIST_ONE_DEVICE, a test mode) take the two-launch path.
+FUSED_CROSS = os.environ.get("PWW_FUSED_CROSS", "1") != "0" and os.environ.get("PWW_DIST_ONE_DEVICE", "0") != "1"
 _warned = set()
 
 
@@ -335,6 +341,98 @@ class ScaledW:
         return func(*[conv(a) for a in args], **{k: conv(v) for k, v in (kwargs or {}).items()})
 
 
+class _ProbeProxy(QKProxy):
+    """QKProxy without tensors behind it: the per-step re-evaluation of a weight function on the host (CoeffSlots.update) only
+    needs the symbolic result; anything that would touch the scores says so."""
+
+    def __init__(self, shape, dtype, device):   # noqa: super().__init__ deliberately not called (no q / k here)
+        self._q = self._k = None
+        self._heads, self._stats, self._full = 1, None, None
+        self.shape, self.dtype, self.device = torch.Size(shape), dtype, device
+
+    def _st(self):
+        raise _NotSymbolic()
+
+    def _materialize(self):
+        raise _NotSymbolic()
+
+
+class _NotSymbolic(Exception):
+    pass
+
+
+def _symbolic_scalar(result):
+    """(STAT_* kind, python scalar) if a weight function's result is `c * w * stat(qk)` / `c * w` with a Python number c, else None."""
+    if isinstance(result, ScaledW) and not torch.is_tensor(result.coeff) and torch.is_tensor(result.w):
+        if result.stat is None:
+            return ops.STAT_NONE, float(result.coeff)
+        return result.stat.kind, float(result.coeff) * float(result.stat.scale)
+    return None
+
+
+class CoeffSlots:
+    """hipGraph mode: one device word per cross-attention call site holds the Python scalar `c0 * g(sigma)` of the weight
+    function (the kernels read it when they RUN: pww_cross_opts_t.coeff_scalar_dev), so ONE captured graph serves every
+    denoise step and every weight function of the same shape -- the host re-evaluates the user's function per site and step
+    on symbolic stand-ins (microseconds) and rewrites the words before each replay (reference: paint_with_words.py:479-482
+    refreshes SIGMA / WEIGHT_FUNCTION in the dict every step). A weight function that is not of the form
+    c * w * reduce(qk) marks the slots `unsupported`; the sampler then falls back to one graph per step."""
+    MAX = 64
+
+    def __init__(self, device):
+        self.dev = torch.zeros(self.MAX, dtype=torch.float32, device=device)
+        self.host = torch.zeros(self.MAX, dtype=torch.float32)
+        if torch.cuda.is_available():
+            self.host = self.host.pin_memory()
+        self.sites = []            # per call site, in call order: dict(kind, w, qk_shape, dtype)
+        self.cursor = 0
+        self.discover = True       # eager pass: sites are (re)registered and their words written in place
+        self.unsupported = False
+
+    def begin_forward(self):
+        self.cursor = 0
+
+    def reset(self):
+        self.sites, self.cursor, self.discover, self.unsupported = [], 0, True, False
+
+    def site(self, kind, scalar, w, qk_shape, dtype):
+        """Called by pww_attention for a symbolic bias: returns the site's device word. In a discovery (eager) pass the word is
+        written here; under capture it already holds this step's value (update() ran before)."""
+        i = self.cursor
+        self.cursor += 1
+        if i >= self.MAX:
+            self.unsupported = True
+            return None
+        if self.discover:
+            rec = dict(kind=kind, w=w, qk_shape=tuple(qk_shape), dtype=dtype)
+            if i < len(self.sites):
+                self.sites[i] = rec
+            else:
+                self.sites.append(rec)
+            self.dev[i:i + 1].fill_(scalar)
+        elif i >= len(self.sites) or self.sites[i]["kind"] != kind or self.sites[i]["w"] is not w:
+            raise PwwHipError("cross-attention call sites changed between hipGraph capture passes (site %d)" % i)
+        return self.dev[i:i + 1]
+
+    def update(self, weight_function, sigma):
+        """Re-evaluate the weight function for every registered site at this step's sigma and move the scalars to the device
+        words (one pinned copy). Returns False if the function no longer has the captured structure (the caller re-captures)."""
+        if not self.sites:
+            return True
+        for i, rec in enumerate(self.sites):
+            try:
+                res = weight_function(ScaledW(rec["w"]), sigma, _ProbeProxy(rec["qk_shape"], rec["dtype"], rec["w"].device))
+            except _NotSymbolic:
+                return False
+            sym = _symbolic_scalar(res)
+            if sym is None or sym[0] != rec["kind"]:
+                return False
+            self.host[i] = sym[1]
+        n = len(self.sites)
+        self.dev[:n].copy_(self.host[:n], non_blocking=True)
+        return True
+
+
 def _orig_weight_to_tokens(w_orig, n_tokens):
     """The reference's fallback when no CROSS_ATTENTION_WEIGHT_<N> key exists (:96-101): bilinear
     (align_corners=True) by 1/sqrt(H*W/N), then 1-D nearest to N -- pww_resize_tokens on the device map. A batched
@@ -365,17 +463,26 @@ def _half(t, like_dtype):
     return t.to(like_dtype)
 
 
-def _fused_weight(attn, names):
-    """Concatenated projection weight ([sum C_out, C_in]) of bias-free Linear layers, cached on the module and
-    rebuilt when any source weight changes (one GEMM instead of three / two)."""
+def _compute_dtype(attn):
+    """dtype the projections run in: the autocast dtype under `torch.autocast("cuda")` (the reference's inj_forward and
+    paint_with_words are decorated with it, :60 / :392: fp16 matmuls whatever the module dtype), else the weights' dtype."""
+    if torch.is_autocast_enabled():
+        return torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
+    return attn.to_q.weight.dtype
+
+
+def _fused_weight(attn, names, dtype=None):
+    """Concatenated projection weight ([sum C_out, C_in]) of bias-free Linear layers in `dtype` (default: as stored), cached on
+    the module and rebuilt when any source weight changes (one GEMM instead of three / two)."""
     mods = [getattr(attn, n) for n in names]
     if any(getattr(m, "bias", None) is not None for m in mods):
         return None
-    key = tuple((m.weight.data_ptr(), m.weight._version, m.weight.dtype, m.weight.device) for m in mods)
+    dtype = dtype or mods[0].weight.dtype
+    key = tuple((m.weight.data_ptr(), m.weight._version, m.weight.dtype, m.weight.device) for m in mods) + (dtype,)
     cache = attn.__dict__.setdefault("_pww_fused", {})
     ent = cache.get(names)
     if ent is None or ent[0] != key:
-        ent = (key, torch.cat([m.weight.detach() for m in mods], dim=0).contiguous())
+        ent = (key, torch.cat([m.weight.detach().to(dtype) for m in mods], dim=0).contiguous())
         cache[names] = ent
     return ent[1]
 
@@ -388,7 +495,7 @@ def refresh_kv_cache(context):
         return
     ctx = context["CONTEXT_TENSOR"]
     for attn, kv in cache.values():
-        w = _fused_weight(attn, ("to_k", "to_v"))
+        w = _fused_weight(attn, ("to_k", "to_v"), kv.dtype)
         kv.copy_(F.linear(ctx.to(w.dtype), w))
 
 
@@ -414,16 +521,19 @@ def pww_attention(attn, hidden_states, context=None):
     if hidden_states.dtype != wdt and not torch.is_autocast_enabled():
         hidden_states = hidden_states.to(wdt)
     C = attn.to_q.weight.shape[0]
-    fuse = not torch.is_autocast_enabled()
-    if context is None and fuse and (w_qkv := _fused_weight(attn, ("to_q", "to_k", "to_v"))) is not None:
-        qkv = F.linear(hidden_states, w_qkv)                    # self-attention: ONE GEMM, q/k/v are strided views
+    # Fused projections in the dtype the reference's path computes in: under torch.autocast("cuda") (how the reference runs,
+    # :60 / :392: fp16 UNet or not, fp32 text encoder :171) that is the autocast dtype, and the concatenated weights are kept
+    # in it, so autocast has nothing left to cast per call.
+    pdt = _compute_dtype(attn)
+    if context is None and (w_qkv := _fused_weight(attn, ("to_q", "to_k", "to_v"), pdt)) is not None:
+        qkv = F.linear(hidden_states.to(pdt), w_qkv)            # self-attention: ONE GEMM, q/k/v are strided views
         query, key, value = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
-    elif context is not None and fuse and (w_kv := _fused_weight(attn, ("to_k", "to_v"))) is not None:
+    elif context is not None and (w_kv := _fused_weight(attn, ("to_k", "to_v"), pdt)) is not None:
         query = attn.to_q(hidden_states)
         kv_cache = context.get(KV_CACHE) if is_dict else None
         ent = kv_cache.get(id(attn)) if kv_cache is not None else None
         if ent is None:
-            kv = F.linear(context_tensor, w_kv)                 # cross-attention: K|V in one GEMM ...
+            kv = F.linear(context_tensor.to(pdt), w_kv)         # cross-attention: K|V in one GEMM ...
             if kv_cache is not None:
                 kv_cache[id(attn)] = (attn, kv)                 # ... and once per request: the prompt is constant over the steps
         else:
@@ -459,22 +569,37 @@ def pww_attention(attn, hidden_states, context=None):
     coeff = None
     stat = None
     scratch = None
+    coeff_dev = None
+    bias_cols = 0
+    compact = None
+    slots = context.get(COEFF_SLOTS) if (context is not None and is_dict) else None
     if isinstance(bias, LazyStat):     # a bare statistic: a per-image constant on every logit of a row cancels in softmax
         bias = None
-    if isinstance(bias, ScaledW) and bias.stat is not None and not torch.is_tensor(bias.coeff) and torch.is_tensor(bias.w):
-        # c0 * w * g(sigma) * reduce(qk): map, statistic selector and Python scalar go to the kernel as they are. Over
+    sym = _symbolic_scalar(bias)
+    if sym is not None and (bias.stat is not None or slots is not None):
+        # c0 * w * g(sigma) [* reduce(qk)]: map, statistic selector and Python scalar go to the kernel as they are. Over
         # the prompt tokens (M <= 128) the statistic is formed in the attention launch itself, unless the weight
-        # function already forced it to exist as a tensor.
-        scalar = float(bias.coeff) * float(bias.stat.scale)
-        if FUSED_CROSS and bias.stat._proxy._stats is None and key.shape[1] <= ops.FUSED_MAX_KEYS:
-            stat = (None, bias.stat.kind, scalar)
+        # function already forced it to exist as a tensor. In hipGraph mode the scalar travels in a device word.
+        kind, scalar = sym
+        n_img, w_map = query.shape[1], bias.w
+        bias_cols = int(context.get(BIAS_COLS, 0) or 0)
+        wc, ci = context.get(COMPACT_W + str(n_img)), context.get(COMPACT_IDX)
+        if torch.is_tensor(wc) and torch.is_tensor(ci) and context.get(f"CROSS_ATTENTION_WEIGHT_{n_img}") is w_map:
+            compact = (wc, ci)
+        if slots is not None and not slots.unsupported:
+            coeff_dev = slots.site(kind, scalar, w_map, (query.shape[0] * attn.heads, n_img, key.shape[1]), query.dtype)
+        have_stats = bias.stat is not None and bias.stat._proxy._stats is not None
+        if FUSED_CROSS and not have_stats and key.shape[1] <= ops.FUSED_MAX_KEYS:
+            stat = (None, kind, scalar)
             scratch = attn.__dict__.get("_pww_fused_scratch")
             if scratch is None:
                 scratch = attn.__dict__["_pww_fused_scratch"] = ops.FusedScratch()
         else:
-            stat = (bias.stat.stats(), bias.stat.kind, scalar)
-        bias = bias.w
-    elif isinstance(bias, ScaledW):    # coeff * w: keep the map, pass the coefficient to the kernel
+            stat = (bias.stat.stats() if bias.stat is not None else None, kind, scalar)
+        bias = w_map
+    elif isinstance(bias, ScaledW):    # coeff * w with a tensor coefficient: keep the map, pass the coefficient vector to the kernel
+        if slots is not None:
+            slots.unsupported = True   # (sigma reached the kernel arguments through torch ops: one graph per step)
         if bias.stat is not None:
             bias = ScaledW(bias.w, bias.coeff * bias.stat.materialize())
         c = bias.coeff
@@ -494,8 +619,12 @@ def pww_attention(attn, hidden_states, context=None):
         # python scalar / 0-dim tensor: a constant added to every logit of a row cancels in softmax
         # (the unconditional pass returns 0.0, :493)
         bias = None
-    return ops.attention(query, key, value, attn.heads, attn.scale, bias=bias, bias_coeff=gate if bias is not None else None,
-                         stat=stat if bias is not None else None, scratch=scratch)
+    elif slots is not None and stat is None:
+        slots.unsupported = True       # a materialised bias tensor depends on sigma through torch ops
+    if bias is None:
+        return ops.attention(query, key, value, attn.heads, attn.scale)
+    return ops.attention(query, key, value, attn.heads, attn.scale, bias=bias, bias_coeff=gate, stat=stat, scratch=scratch,
+                         coeff_dev=coeff_dev, bias_cols=bias_cols, compact=compact)
 
 
 def inj_forward(self, hidden_states, context=None, mask=None):

@@ -109,6 +109,7 @@ def build_weight_maps(color_map_rgb, table, token_lis, device, extra_sigmas=None
     if with_orig:
         maps["ORIG"] = outs[1].reshape(H, W, len(token_lis))
     maps["_BLURRED"] = blurred      # region ordinal -> blurred float mask (region seeding thresholds these, :300-304)
+    maps["_COLS"] = [c for c, lst in enumerate(cols) if lst]     # prompt positions that carry any region weight (:257-268)
     return maps
 
 
@@ -132,19 +133,26 @@ def _encode_text_color_inputs(text_encoder, tokenizer, device, color_map_image, 
     color_context, extra_seeds, extra_sigmas = _extract_seed_and_sigma_from_context(color_context)
     if not use_sigma:      # the pipeline classes parse the sigma tail and drop it (reference :574): no blur there
         extra_sigmas = {}
-    rgb = np.array(color_map_image.convert("RGB")) if hasattr(color_map_image, "convert") else np.asarray(color_map_image)
-    height, width = rgb.shape[:2]
-    table = _parse_regions(color_context, tokenizer)
+    if color_map_image is None:
+        # the reference's _image_context_seperator(None, ...) (:239-243): one dummy region over a 512 x 512 all-zero map --
+        # plain Stable Diffusion (the pipeline class's default call, `pipe(prompt)`)
+        rgb, height, width, table = None, 512, 512, []
+    else:
+        rgb = np.array(color_map_image.convert("RGB")) if hasattr(color_map_image, "convert") else np.asarray(color_map_image)
+        height, width = rgb.shape[:2]
+        table = _parse_regions(color_context, tokenizer)
     token_lis = text_input["input_ids"][0].tolist()
     keys = [always_round(height / r) * always_round(width / r) for r in (8, 16, 32, 64)]
     if table:
         _warn_missing_colors(rgb, table)
         maps = build_weight_maps(rgb, table, token_lis, device, extra_sigmas)
         blurred = maps.pop("_BLURRED")
+        nz_cols = maps.pop("_COLS")
     else:   # empty color_context (:242-243): all-zero maps
         maps = {k: torch.zeros((k, len(token_lis)), dtype=torch.float32, device=device) for k in keys}
         maps["ORIG"] = torch.zeros((height, width, len(token_lis)), dtype=torch.float32, device=device)
         blurred = {}
+        nz_cols = None
 
     cond_embeddings = text_encoder(text_input.input_ids.to(device))[0]
     uncond_input = tokenizer([unconditional_input_prompt], padding="max_length",
@@ -158,6 +166,23 @@ def _encode_text_color_inputs(text_encoder, tokenizer, device, color_map_image, 
     for k in keys:
         encoder_hidden_states[f"CROSS_ATTENTION_WEIGHT_{k}"] = maps[k]
         uncond_encoder_hidden_states[f"CROSS_ATTENTION_WEIGHT_{k}"] = 0
+    if nz_cols is not None:
+        # Private, optional hints for the fused kernel (SURVEY.md 8b "may add private keys, must not require them"): only the
+        # prompt positions covered by a region phrase are non-zero in ANY of the maps (5 - 17 of 77 for the shipped examples) --
+        # the column bound, and the compact [N, R] + col_idx form of every per-resolution map.
+        from .attention import BIAS_COLS, COMPACT_W, COMPACT_IDX
+        # (both are kernel-launch geometry, i.e. part of a captured hipGraph's identity: rounded up -- the bound to 16 columns,
+        # the compact width to 8 slots with unused ones marked -1 -- so that similar prompts replay the same graph)
+        encoder_hidden_states[BIAS_COLS] = ((max(nz_cols) + 16) // 16 * 16) if nz_cols else 16
+        if 1 <= len(nz_cols) <= ops.COMPACT_MAX_R:
+            R = (len(nz_cols) + 7) // 8 * 8
+            idx = torch.tensor(nz_cols, dtype=torch.int64, device=device)
+            pad = torch.full((R - len(nz_cols),), -1, dtype=torch.int32, device=device)
+            encoder_hidden_states[COMPACT_IDX] = torch.cat([idx.to(torch.int32), pad])
+            for k in keys:
+                wc = maps[k].new_zeros((maps[k].shape[0], R))
+                wc[:, :len(nz_cols)] = maps[k].index_select(1, idx)
+                encoder_hidden_states[COMPACT_W + str(k)] = wc
     return extra_seeds, (table, rgb, blurred), encoder_hidden_states, uncond_encoder_hidden_states
 
 

@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import AttnDesc, Region, PwwHipError
+from ._lib import AttnDesc, CrossOpts, Region, PwwHipError
 
 _DT = {torch.float16: _lib.DTYPE_F16, torch.bfloat16: _lib.DTYPE_BF16}
 
@@ -77,18 +77,22 @@ class FusedScratch:
     """Device buffers of pww_cross_attn_fwd_fused for one call site (one attention layer): the persistent state words
     (zeroed ONCE here -- the kernel leaves them zero after every launch, so captured hipGraphs replay without a memset
     node) and the scratch of the two-launch path. Allocated outside stream capture (the first, eager call of a layer
-    creates them) and kept alive by their owner, because captured graphs hold their addresses."""
+    creates them) and kept alive by their owner, because captured graphs hold their addresses: a buffer that has to grow
+    is RETIRED, never freed (graphs captured for the smaller geometry keep replaying into it)."""
 
     def __init__(self):
         self.state = None
         self.ws = None
         self._err_index = 0
+        self._retired = []
 
     def _alloc(self, current, nbytes, device, zero):
         if current is not None and current.device == device and current.numel() * 8 >= nbytes:
             return current
         if torch.cuda.is_current_stream_capturing():
             raise PwwHipError("fused cross-attention buffers must exist before hipGraph capture (run one eager call first)")
+        if current is not None:
+            self._retired.append(current)
         n = (nbytes + 7) // 8
         return (torch.zeros if zero else torch.empty)((n,), dtype=torch.int64, device=device)
 
@@ -98,23 +102,82 @@ class FusedScratch:
         self._err_index = d.B * d.H + d.B
         return self.state, self.ws
 
+    def error_word(self):
+        """The error word of the last call's geometry as a 0-dim device tensor (non-zero: a hand-off inside the fused kernel
+        timed out and the affected outputs are NaN), or None before the first call. No synchronisation."""
+        return None if self.state is None else self.state.view(torch.int32)[self._err_index]
+
     def error(self):
-        """True if a hand-off inside the fused kernel timed out in the last call's geometry (synchronises; diagnostics /
-        tests only). The state words must then be re-zeroed: `reset()`."""
-        return self.state is not None and bool(self.state.view(torch.int32)[self._err_index].item() != 0)
+        """True if a hand-off timed out (synchronises). The state words must then be re-zeroed: `reset()`."""
+        return self.state is not None and bool(self.error_word().item() != 0)
 
     def reset(self):
-        if self.state is not None:
-            self.state.zero_()
+        for t in [self.state] + self._retired:
+            if t is not None:
+                t.zero_()
 
 
-def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None, scratch=None, stats_out=None):
+def check_fused_errors(modules):
+    """One device -> host read for a whole request: raise PwwHipError if any fused cross-attention launch of the given
+    modules' scratch buffers timed out in its hand-off (the launch needs every workgroup resident at once: another process or
+    stream holding compute units can starve it; PWW_FUSED_CROSS=0 selects the two-launch path). Dirty state is re-zeroed so
+    that the next request starts clean."""
+    scratches = [m.__dict__["_pww_fused_scratch"] for m in modules if "_pww_fused_scratch" in getattr(m, "__dict__", {})]
+    words = [w for w in (s.error_word() for s in scratches) if w is not None]
+    if not words:
+        return
+    if bool(torch.stack(words).ne(0).any().item()):
+        torch.cuda.synchronize()
+        for s in scratches:
+            s.reset()
+        raise PwwHipError("a fused cross-attention launch timed out waiting for its own workgroups (the GPU is shared with another "
+                          "process or stream?); its outputs are NaN and were discarded. State re-zeroed. Set PWW_FUSED_CROSS=0 to "
+                          "use the two-launch path on a shared device.")
+
+
+def _cross_opts(B, N, coeff_dev, bias_cols, compact, keep):
+    """pww_cross_opts_t for the *_ex entry points (None if nothing optional is asked for)."""
+    if coeff_dev is None and not bias_cols and compact is None:
+        return None
+    op = CrossOpts()
+    op.size = ctypes.sizeof(CrossOpts)
+    op.bias_cols = int(bias_cols or 0)
+    if coeff_dev is not None:
+        if coeff_dev.dtype != torch.float32 or coeff_dev.numel() != 1 or not coeff_dev.is_cuda:
+            raise PwwHipError("coeff_dev must be a one-element float32 device tensor")
+        op.coeff_scalar_dev = coeff_dev.data_ptr()
+    if compact is not None:
+        wc, idx = compact
+        if wc.dtype != torch.float32 or idx.dtype != torch.int32 or wc.stride(-1) != 1 or idx.stride(-1) != 1:
+            raise PwwHipError("compact bias: float32 values and int32 column indices, innermost stride 1")
+        if wc.dim() == 2:
+            wc = wc.unsqueeze(0)
+        if idx.dim() == 1:
+            idx = idx.unsqueeze(0)
+        R = wc.shape[-1]
+        if wc.shape[1] != N or wc.shape[0] not in (1, B) or idx.shape[-1] != R or idx.shape[0] not in (1, B):
+            raise PwwHipError("compact bias shapes %s / %s do not fit B=%d N=%d" % (tuple(wc.shape), tuple(idx.shape), B, N))
+        op.bias_compact, op.col_idx, op.R = wc.data_ptr(), idx.data_ptr(), R
+        op.compact_stride[:] = [wc.stride(0) if wc.shape[0] == B and B > 1 else 0, wc.stride(1)]
+        op.col_idx_stride = idx.stride(0) if idx.shape[0] == B and B > 1 else 0
+        keep.extend([wc, idx])
+    return op
+
+
+COMPACT_MAX_R = 32     # pww_cross.hip: the compact form holds at most 32 non-zero columns
+
+
+def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None, scratch=None, stats_out=None, coeff_dev=None,
+              bias_cols=0, compact=None):
     """softmax((Q K^T + c * bias) * scale) V on [B, tokens, heads*D] tensors (diffusers layout, no
     head-split copies). bias: fp32 tensor broadcastable to [B, heads, N, M] or None;
     bias_coeff: optional fp32 [B] device tensor of per-image coefficients (with `stat`: the row gate);
     stat: optional (stats, STAT_* kind, python scalar): the kernel forms c[b] = scalar * stat(stats[b]) * bias_coeff[b]
     itself. `stats` is either the float64 [B,4] tensor of qk_stats (pww_cross_attn_fwd_stat) or None together with a
-    FusedScratch in `scratch`: the statistic is then computed in the same launch (pww_cross_attn_fwd_fused, M <= 128)."""
+    FusedScratch in `scratch`: the statistic is then computed in the same launch (pww_cross_attn_fwd_fused, M <= 128).
+    With `stat`: coeff_dev = one-element fp32 device tensor that replaces the python scalar when the kernel runs (hipGraph
+    replays across denoise steps); bias_cols = columns >= bias_cols of the map are zero; compact = (values [B?, N, R] fp32,
+    col_idx [B?, R] int32) the compact form of the same map (fused launch only)."""
     _require_gpu(q, k, v, bias, bias_coeff)
     if not (q.dtype == k.dtype == v.dtype):
         raise PwwHipError("q/k/v dtypes differ: %s %s %s" % (q.dtype, k.dtype, v.dtype))
@@ -141,24 +204,30 @@ def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None, scra
                     bias_coeff = bias_coeff.expand(B).contiguous()
                 if bias_coeff.numel() != B:
                     raise PwwHipError("bias_coeff must have B=%d elements" % B)
-            if stat is not None and stat[0] is None:
+            if stat is not None and stat[0] is None and (scratch is not None or stat[1] != STAT_NONE):
                 _, kind, scalar = stat
                 if scratch is None or M > FUSED_MAX_KEYS:
                     raise PwwHipError("fused statistic needs a FusedScratch and at most %d keys" % FUSED_MAX_KEYS)
                 state, ws = scratch.ensure(lib, d, q.device)
                 if stats_out is not None and (stats_out.dtype != torch.float64 or tuple(stats_out.shape) != (B, 4) or not stats_out.is_contiguous()):
                     raise PwwHipError("stats_out must be a contiguous float64 [B, 4] tensor")
-                rc = lib.pww_cross_attn_fwd_fused(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(bias), int(kind), float(scalar),
-                                                  _ptr(bias_coeff), ctypes.byref(d), _ptr(stats_out), _ptr(state), state.numel() * 8,
-                                                  _ptr(ws), ws.numel() * 8, _stream())
-                _lib.check(rc, "pww_cross_attn_fwd_fused")
+                keep = []
+                if compact is not None and compact[0].shape[-1] > COMPACT_MAX_R:
+                    compact = None
+                op = _cross_opts(B, N, coeff_dev, bias_cols, compact, keep)
+                rc = lib.pww_cross_attn_fwd_fused_ex(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(bias), int(kind), float(scalar),
+                                                     _ptr(bias_coeff), ctypes.byref(d), _ptr(stats_out), _ptr(state), state.numel() * 8,
+                                                     _ptr(ws), ws.numel() * 8, ctypes.byref(op) if op is not None else None, _stream())
+                _lib.check(rc, "pww_cross_attn_fwd_fused_ex")
             elif stat is not None:
                 stats, kind, scalar = stat
-                if stats.dtype != torch.float64 or tuple(stats.shape) != (B, 4) or not stats.is_contiguous():
+                if stats is not None and (stats.dtype != torch.float64 or tuple(stats.shape) != (B, 4) or not stats.is_contiguous()):
                     raise PwwHipError("stat: stats must be a contiguous float64 [B, 4] tensor")
-                rc = lib.pww_cross_attn_fwd_stat(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(bias), _ptr(stats), int(kind),
-                                                 float(heads * N * M), float(scalar), _ptr(bias_coeff), ctypes.byref(d), _stream())
-                _lib.check(rc, "pww_cross_attn_fwd_stat")
+                op = _cross_opts(B, N, coeff_dev, 0, None, [])
+                rc = lib.pww_cross_attn_fwd_stat_ex(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(bias), _ptr(stats), int(kind),
+                                                    float(heads * N * M), float(scalar), _ptr(bias_coeff), ctypes.byref(d),
+                                                    ctypes.byref(op) if op is not None else None, _stream())
+                _lib.check(rc, "pww_cross_attn_fwd_stat_ex")
             else:
                 rc = lib.pww_cross_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(bias), _ptr(bias_coeff),
                                             ctypes.byref(d), _stream())

@@ -7,15 +7,18 @@ Three execution modes over the SAME arithmetic:
   "folded"  cond and uncond rows of all images in ONE UNet call ([cond rows..., uncond rows...]); the
             PwW bias is gated per row by the `_PWW_ROW_GATE` coefficients (kernel arg bias_coeff), and
             the qk reductions stay per image (QKProxy).
-  "graph"   "folded", with each step's UNet call captured once into a hipGraph (torch.cuda.CUDAGraph
-            on ROCm) and replayed: at batch 1 the UNet is launch-bound (~1.5k kernels per call), so
-            replay removes the host launch cost. One graph per step index because the user's
-            weight_function bakes the step's sigma into kernel arguments as a Python float.
+  "graph"   "folded", with the UNet call captured ONCE into a hipGraph (torch.cuda.CUDAGraph on ROCm) and
+            replayed for every step of every request of the same geometry: at batch 1 the UNet is
+            launch-bound (~1.5k kernels per call), so replay removes the host launch cost. The only
+            step-dependent kernel arguments -- the Python scalars c0 * g(sigma) the user's
+            weight_function produces -- live in device words (attention.CoeffSlots) that the host
+            rewrites before each replay. A weight function that is not of the form
+            c * w * reduce(qk) bakes sigma into torch ops; the sampler then keeps one graph per step.
 """
 import torch
 
 from . import ops
-from .attention import install, refresh_kv_cache, refresh_orig_cache, ROW_GATE, KV_CACHE
+from .attention import install, refresh_kv_cache, refresh_orig_cache, ROW_GATE, KV_CACHE, COEFF_SLOTS, CoeffSlots, COMPACT_W, COMPACT_IDX
 
 
 def initial_latents(seed, in_channels, height, width, region_masks=None, extra_seeds=None, batch_seeds=None):
@@ -74,34 +77,89 @@ def _fold_context(cond, uncond, n_images, device):
             w = torch.stack(maps, dim=0)                       # [n, N, 77]  (ORIG: [n, H, W, 77])
             w = torch.cat([w, torch.zeros_like(w)], dim=0)
             folded[key] = w if key.endswith("_ORIG") else w.unsqueeze(1)
+        # private hints: the column bound is the largest of the images'; the compact forms are padded to one width
+        # (unused slots: column index -1) and stacked like the maps
+        folded["_PWW_BIAS_COLS"] = max((int(c.get("_PWW_BIAS_COLS", 0) or 0) for c in conds), default=0) if all(c.get("_PWW_BIAS_COLS") for c in conds) else 0
+        idxs = [c.get(COMPACT_IDX) for c in conds]
+        for key in [k for k in list(folded) if k.startswith(COMPACT_W) or k == COMPACT_IDX]:
+            folded.pop(key)
+        if all(torch.is_tensor(i) for i in idxs):
+            R = max(int(i.numel()) for i in idxs)
+            pad_i = [torch.cat([i, i.new_full((R - i.numel(),), -1)]) for i in idxs]
+            idx = torch.stack(pad_i + [torch.full_like(pad_i[0], -1)] * n_images, dim=0)          # [2n, R]
+            ok = True
+            stacked = {}
+            for key in [k for k in conds[0] if k.startswith(COMPACT_W)]:
+                ws = [c.get(key) for c in conds]
+                if not all(torch.is_tensor(w) for w in ws):
+                    ok = False
+                    break
+                ws = [torch.cat([w, w.new_zeros(w.shape[0], R - w.shape[1])], dim=1) for w in ws]
+                w = torch.stack(ws, dim=0)                                                         # [n, N, R]
+                stacked[key] = torch.cat([w, torch.zeros_like(w)], dim=0).contiguous()
+            if ok:
+                folded.update(stacked)
+                folded[COMPACT_IDX] = idx.contiguous()
     return folded
 
 
 def weight_function_signature(f):
-    """What a captured hipGraph depends on in a weight function: its code and the constants it can see (closure cells,
-    defaults, numeric globals it names). The reference's callers pass a FRESH lambda per request (runner.py:104,
-    gradio_pww.py:43), so identity is useless as a cache key; two lambdas with the same code and constants replay the
-    same graphs, and a changed constant (the graphs bake `c0 * g(sigma)` into kernel arguments) re-captures. Values that
-    are not plain numbers / strings are keyed by identity."""
+    """Cache key of the FALL-BACK path only (weight functions that are not c * w * reduce(qk): one hipGraph per step with
+    sigma baked into torch ops). What such graphs depend on in the function: its code and every constant it can see --
+    closure cells, defaults, the constants of nested code objects (inner lambdas, comprehensions), numeric globals. A function
+    that reaches anything else (a non-numeric global such as a helper function or a config object, a closure over a mutable
+    object, a callable object) is keyed by a fresh token, i.e. it never matches a cached key and is re-captured: slower, never
+    stale. (The regular path needs none of this: the host re-evaluates the function every step, attention.CoeffSlots.)"""
+    fresh = ("fresh", object())
+
     def atom(v):
         if isinstance(v, (int, float, str, bool, bytes, type(None))):
             return ("v", type(v).__name__, v)
         if isinstance(v, tuple) and all(isinstance(x, (int, float, str, bool, type(None))) for x in v):
             return ("t", v)
-        return ("id", id(v))
+        return None
+
+    def code_key(code):
+        consts = []
+        for c in code.co_consts:
+            if hasattr(c, "co_code"):
+                consts.append(code_key(c))
+            else:
+                a = atom(c)
+                consts.append(a if a is not None else ("repr", repr(c)))     # frozenset / Ellipsis ...: immutable constants
+        return ("code", code.co_code, tuple(consts), code.co_names, code.co_varnames[:code.co_argcount])
+
+    def names_of(code):
+        out = set(code.co_names)
+        for c in code.co_consts:
+            if hasattr(c, "co_code"):
+                out |= names_of(c)
+        return out
+
     code = getattr(f, "__code__", None)
-    if code is None:       # callable object / builtin: identity
-        return ("callable", id(f))
-    consts = tuple(atom(c) if not hasattr(c, "co_code") else ("code", c.co_code, c.co_names) for c in code.co_consts)
+    if code is None:       # callable object / builtin
+        return fresh
     cells = tuple(atom(c.cell_contents) for c in (f.__closure__ or ()))
-    defaults = tuple(atom(v) for v in (f.__defaults__ or ())) + tuple(sorted((k, atom(v)) for k, v in (f.__kwdefaults__ or {}).items()))
+    dvals = tuple(atom(v) for v in (f.__defaults__ or ()))
+    kvals = tuple((k, atom(v)) for k, v in sorted((f.__kwdefaults__ or {}).items()))
+    if any(c is None for c in cells) or any(d is None for d in dvals) or any(v is None for _, v in kvals):
+        return fresh
+    defaults = dvals + kvals
+    import types
     g = getattr(f, "__globals__", {})
-    globs = tuple((n, atom(g[n])) for n in code.co_names if n in g and isinstance(g[n], (int, float, str, bool)))
-    return ("code", code.co_code, consts, code.co_names, code.co_varnames[:code.co_argcount], cells, defaults, globs)
+    globs = []
+    for n in sorted(names_of(code)):       # (co_names also holds attribute names -- log, max, std ...: only real globals count)
+        if n in g:
+            a = atom(g[n])
+            if a is None and not isinstance(g[n], types.ModuleType):
+                return fresh       # helper function, config object ...: cannot be proven constant
+            globs.append((n, a if a is not None else ("module", g[n].__name__)))
+    return (code_key(code), cells, defaults, tuple(globs))
 
 
 class _GraphedUNet:
-    """Capture-once / replay-many wrapper of one folded UNet call per step index."""
+    """Capture-once / replay-many wrapper of the folded UNet call: key "all" (one graph for every step) while the weight
+    function's scalars travel in device words, else one graph per step index."""
 
     def __init__(self, unet):
         self.unet = unet
@@ -109,6 +167,7 @@ class _GraphedUNet:
         self.pool = None
         self.static_in = None
         self.static_t = None
+        self.captures = 0
 
     def reset(self):
         """Drop every captured graph AND the memory pool they shared: once the last graph of a pool is gone the
@@ -116,21 +175,30 @@ class _GraphedUNet:
         self.graphs.clear()
         self.pool = None
 
-    def __call__(self, key, x, t_value, context):
+    def __call__(self, step, x, t_value, context):
         if self.static_in is None or self.static_in.shape != x.shape or self.static_in.dtype != x.dtype:
             self.reset()
             self.static_in = torch.empty_like(x)
             self.static_t = torch.zeros((), dtype=torch.float32, device=x.device)
         self.static_in.copy_(x)
         self.static_t.fill_(float(t_value))
+        slots = context.get(COEFF_SLOTS)
+        key = "all" if slots is not None and not slots.unsupported else step
         entry = self.graphs.get(key)
         if entry is None:
-            # warm-up on a side stream (required before capture), then capture
+            # warm-up on a side stream (required before capture; also the discovery pass of the coefficient slots), then capture
+            if slots is not None:
+                slots.discover = True
+                slots.begin_forward()
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 self.unet(self.static_in, self.static_t, encoder_hidden_states=context)
             torch.cuda.current_stream().wait_stream(s)
+            if slots is not None:
+                slots.discover = False
+                slots.begin_forward()
+                key = "all" if not slots.unsupported else step
             g = torch.cuda.CUDAGraph()
             if self.pool is None:
                 self.pool = torch.cuda.graph_pool_handle()
@@ -138,6 +206,7 @@ class _GraphedUNet:
                 out = self.unet(self.static_in, self.static_t, encoder_hidden_states=context).sample
             entry = (g, out)
             self.graphs[key] = entry
+            self.captures += 1
         g, out = entry
         g.replay()
         return out
@@ -153,25 +222,36 @@ class PwWSampler:
         install(unet)
         self._graphed = _GraphedUNet(unet) if mode == "graph" else None
         self._graph_sig = None
+        self._fallback_sig = None
         self._static_folded = None
+        self._scratch_modules = None
 
     def _static_context(self, folded, weight_function, latents, timesteps):
-        """Captured graphs read the context tensors by ADDRESS: keep one set of static tensors alive
-        and copy each new request's values into them; rebuild the graphs when the geometry, the
-        weight function (code or constants: they are baked into kernel arguments) or the schedule changes."""
+        """Captured graphs read the context tensors by ADDRESS: keep one set of static tensors alive and copy each new
+        request's values into them; rebuild the graphs when the geometry changes. The weight function and the schedule are
+        NOT part of the key while the function's scalars travel in device words (CoeffSlots) -- fresh lambdas, other
+        constants, another step count all replay the same graph; only the per-step fall-back keys them."""
         def tensor_sig(d):
             return tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in d.items() if torch.is_tensor(v)))
-        sig = (weight_function_signature(weight_function), tuple(latents.shape), tuple(float(t) for t in timesteps), tensor_sig(folded))
+        sig = (tuple(latents.shape), tensor_sig(folded), tuple(sorted((k, v) for k, v in folded.items() if isinstance(v, int) and not isinstance(v, bool))))
         if sig != self._graph_sig:
             self._graphed.reset()
             self._graph_sig = sig
+            self._fallback_sig = None
             self._static_folded = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in folded.items()}
+            self._static_folded[COEFF_SLOTS] = CoeffSlots(latents.device)
         else:
             for k, v in folded.items():
                 if torch.is_tensor(v):
                     self._static_folded[k].copy_(v)
             refresh_kv_cache(self._static_folded)     # new prompt embedding -> new K|V, same addresses
             refresh_orig_cache(self._static_folded)   # new color map -> new fallback maps, same addresses
+        slots = self._static_folded[COEFF_SLOTS]
+        if slots.unsupported:      # one graph per step: those do depend on the function's constants and on the schedule
+            fsig = (weight_function_signature(weight_function), tuple(float(t) for t in timesteps))
+            if fsig != self._fallback_sig:
+                self._graphed.reset()
+                self._fallback_sig = fsig
         return self._static_folded
 
     def _sigma_and_index(self, i, t):
@@ -221,6 +301,11 @@ class PwWSampler:
                 folded.update({"SIGMA": sigma, "WEIGHT_FUNCTION": weight_function})
                 x2 = torch.cat([x, x], dim=0).to(udt)
                 if self.mode == "graph":
+                    slots = folded[COEFF_SLOTS]
+                    if not slots.unsupported and not slots.update(weight_function, sigma):
+                        # the function changed its structure (another statistic, not symbolic any more): capture again
+                        self._graphed.reset()
+                        slots.reset()
                     out = self._graphed(i, x2, float(t), folded)
                 else:
                     out = unet(x2, t, encoder_hidden_states=folded).sample
@@ -232,4 +317,8 @@ class PwWSampler:
             latents = sch.step(noise_pred, t, latents).prev_sample
             if on_step is not None:
                 on_step(i, t, latents)
+        # one 4-byte device -> host read per request: did any fused cross-attention launch time out in its hand-off?
+        if self._scratch_modules is None:
+            self._scratch_modules = [m for m in unet.modules() if m.__class__.__name__ in ("CrossAttention", "Attention")]
+        ops.check_fused_errors(self._scratch_modules)
         return latents

@@ -28,6 +28,31 @@ static uint16_t to_t(float f, int dt) { return dt == PWW_DTYPE_F16 ? to_f16(f) :
 static float from_t(uint16_t u, int dt) { return dt == PWW_DTYPE_F16 ? from_f16(u) : from_bf16(u); }
 
 static int g_fail = 0;
+static bool g_timeline = false;      // --timeline: print the phase time stamps of the case's launches (pww_debug_timeline)
+
+// one launch under pww_debug_timeline: per stamp slot, microseconds since the earliest kernel-entry stamp of the launch
+template <typename F> static void timeline_report(const char *name, const char *what, F launch) {
+    const size_t wgs = 1 << 16, bytes = wgs * 8 * sizeof(unsigned long long);
+    unsigned long long *buf; HIPCHECK(hipMalloc(&buf, bytes));
+    for (int rep = 0; rep < 3; ++rep) launch();                       // warm
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemset(buf, 0, bytes));
+    pww_debug_timeline(buf, bytes);
+    launch();
+    HIPCHECK(hipDeviceSynchronize());
+    pww_debug_timeline(nullptr, 0);
+    std::vector<unsigned long long> h(wgs * 8);
+    HIPCHECK(hipMemcpy(h.data(), buf, bytes, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull; size_t n = 0;
+    for (size_t w = 0; w < wgs; ++w) if (h[w * 8]) { t0 = std::min(t0, h[w * 8]); n = w + 1; }
+    printf("TIMELINE %-28s %s: %zu workgroups; us since the first workgroup's entry, per stamp [n mean min max]\n", name, what, n);
+    for (int sl = 0; sl < 8; ++sl) {
+        double sum = 0, mn = 1e30, mx = 0; long cnt = 0;
+        for (size_t w = 0; w < n; ++w) if (h[w * 8 + sl]) { const double us = (double)(h[w * 8 + sl] - t0) * 0.01; sum += us; mn = std::min(mn, us); mx = std::max(mx, us); ++cnt; }
+        if (cnt) printf("TIMELINE %-28s   stamp %d: n=%ld mean %.2f min %.2f max %.2f\n", name, sl, cnt, sum / cnt, mn, mx);
+    }
+    (void)hipFree(buf);
+}
 
 struct Case {
     const char *name; int dtype, B, H, N, M, D;
@@ -36,6 +61,8 @@ struct Case {
     int row_step;    // check every row_step-th query row
     float qk_gain;   // scales Q so logits get a realistic spread
     float late_outlier = 0.f;   // != 0: key row M - 5 of every image is multiplied by this (scores far above everything seen before)
+    int bias_cols = 0;          // bias_mode 1: columns >= bias_cols of the map are zero and the *_ex call says so (0 = every column may be non-zero)
+    int compact_R = 0;          // bias_mode 1: only compact_R columns (< bias_cols) are non-zero; the *_ex call also gets the compact form
 };
 
 template <typename T> static T *dalloc(size_t n) { T *p; HIPCHECK(hipMalloc(&p, n * sizeof(T) + 64)); return p; }
@@ -59,9 +86,19 @@ static void run_case(const Case &c, bool timing) {
     d.v_stride[0] = (int64_t)M * C; d.v_stride[1] = D; d.v_stride[2] = C;
     d.o_stride[0] = (int64_t)N * C; d.o_stride[1] = D; d.o_stride[2] = C;
     d.scale = 1.0f / sqrtf((float)D);
+    std::vector<int> ccols;           // compact form: the non-zero columns
     if (c.bias_mode == 1) {
         bias.resize((size_t)N * M); coeff.resize(B);
         for (auto &x : bias) x = (rng_uniform() < 0.3f) ? rng_uniform() * 1.5f : 0.f;
+        const int bc = c.bias_cols > 0 ? c.bias_cols : M;
+        if (c.compact_R > 0) {        // every (bc / R)-th column below bc, last one = bc - 1
+            for (int r = 0; r < c.compact_R; ++r) ccols.push_back(r == c.compact_R - 1 ? bc - 1 : (int)((long)r * bc / c.compact_R));
+        }
+        for (int n = 0; n < N; ++n) for (int m = 0; m < M; ++m) {
+            bool keep = m < bc;
+            if (keep && !ccols.empty()) keep = std::find(ccols.begin(), ccols.end(), m) != ccols.end();
+            if (!keep) bias[(size_t)n * M + m] = 0.f;
+        }
         for (int b = 0; b < B; ++b) coeff[b] = 2.0f + 3.0f * b;
         d.bias_stride[0] = 0; d.bias_stride[1] = 0; d.bias_stride[2] = M; d.bias_stride[3] = 1;
     } else if (c.bias_mode == 2) {
@@ -166,11 +203,72 @@ static void run_case(const Case &c, bool timing) {
                 if (!ok) g_fail++;
             }
         }
+        // pww_cross_attn_fwd_fused_ex: the optional arguments must not change a single bit -- (a) the coefficient scalar read from a
+        // device word, (b) the promise that columns >= bias_cols are zero, (c) the compact form of the same map (with and without
+        // the dense map beside it), (d) all of them together
+        {
+            std::vector<float> gate(coeff); if (B > 1) gate[B - 1] = 0.f;
+            HIPCHECK(hipMemcpy(dgate, gate.data(), B * 4, hipMemcpyHostToDevice));
+            const float s0 = 0.37f;
+            float *dscalar = dalloc<float>(4); HIPCHECK(hipMemcpy(dscalar, &s0, 4, hipMemcpyHostToDevice));
+            float *dcompact = nullptr; int32_t *dcidx = nullptr; const int R = (int)ccols.size();
+            if (R) {
+                std::vector<float> comp((size_t)N * R);
+                for (int n = 0; n < N; ++n) for (int r = 0; r < R; ++r) comp[(size_t)n * R + r] = bias[(size_t)n * M + ccols[r]];
+                std::vector<int32_t> ci(ccols.begin(), ccols.end());
+                dcompact = dalloc<float>(comp.size()); dcidx = dalloc<int32_t>(R);
+                HIPCHECK(hipMemcpy(dcompact, comp.data(), comp.size() * 4, hipMemcpyHostToDevice));
+                HIPCHECK(hipMemcpy(dcidx, ci.data(), R * 4, hipMemcpyHostToDevice));
+            }
+            HIPCHECK(hipMemset(o1, 0xff, q.size() * 2));
+            int r1 = pww_cross_attn_fwd_fused(dq, dk, dv, o1, dbias, PWW_STAT_MAX, s0, dgate, &d, nullptr, dsync, sync_bytes, fws, fws_bytes, nullptr);
+            HIPCHECK(hipDeviceSynchronize());
+            std::vector<uint16_t> h1(q.size()), h2(q.size());
+            HIPCHECK(hipMemcpy(h1.data(), o1, h1.size() * 2, hipMemcpyDeviceToHost));
+            for (int variant = 0; variant < 5; ++variant) {
+                pww_cross_opts_t op; memset(&op, 0, sizeof(op)); op.size = sizeof(op);
+                const float *use_bias = dbias;
+                const char *what = "";
+                if (variant == 0) { op.coeff_scalar_dev = dscalar; what = "coeff_scalar_dev"; }
+                else if (variant == 1) { if (!c.bias_cols) continue; op.bias_cols = c.bias_cols; what = "bias_cols"; }
+                else if (variant == 2) { if (!R) continue; op.bias_compact = dcompact; op.col_idx = dcidx; op.R = R; op.compact_stride[1] = R; op.bias_cols = c.bias_cols; what = "compact + dense"; }
+                else if (variant == 3) { if (!R) continue; op.bias_compact = dcompact; op.col_idx = dcidx; op.R = R; op.compact_stride[1] = R; op.bias_cols = c.bias_cols; use_bias = nullptr; what = "compact only"; }
+                else { op.coeff_scalar_dev = dscalar; op.bias_cols = c.bias_cols; if (R) { op.bias_compact = dcompact; op.col_idx = dcidx; op.R = R; op.compact_stride[1] = R; } what = "all options"; }
+                HIPCHECK(hipMemset(o2, 0xee, q.size() * 2));
+                int r2 = pww_cross_attn_fwd_fused_ex(dq, dk, dv, o2, use_bias, PWW_STAT_MAX, op.coeff_scalar_dev ? -1.f : s0, dgate, &d, nullptr, dsync, sync_bytes, fws, fws_bytes, &op, nullptr);
+                HIPCHECK(hipDeviceSynchronize());
+                if (r2 == PWW_ENOTSUP && !use_bias) { printf("SKIP %-28s fused_ex %s: not resident without the dense map (%s)\n", c.name, what, pww_last_error()); continue; }
+                HIPCHECK(hipMemcpy(h2.data(), o2, h2.size() * 2, hipMemcpyDeviceToHost));
+                long diff = 0; for (size_t i = 0; i < h1.size(); ++i) diff += h1[i] != h2[i];
+                const bool ok = r1 == 0 && r2 == 0 && diff == 0;
+                printf("%s %-28s fused_ex [%s]: %ld differing outputs vs the plain fused call (rc %d %d%s%s)\n", ok ? "PASS" : "FAIL", c.name, what, diff, r1, r2, r2 ? " " : "", r2 ? pww_last_error() : "");
+                if (!ok) g_fail++;
+            }
+            // pww_cross_attn_fwd_stat_ex with the device word == pww_cross_attn_fwd_stat with the value
+            {
+                pww_cross_opts_t op; memset(&op, 0, sizeof(op)); op.size = sizeof(op); op.coeff_scalar_dev = dscalar;
+                int r3 = pww_cross_attn_fwd_stat(dq, dk, dv, o1, dbias, dstats, PWW_STAT_STD, (double)H * N * M, s0, dgate, &d, nullptr);
+                int r4 = pww_cross_attn_fwd_stat_ex(dq, dk, dv, o2, dbias, dstats, PWW_STAT_STD, (double)H * N * M, -1.f, dgate, &d, &op, nullptr);
+                HIPCHECK(hipDeviceSynchronize());
+                HIPCHECK(hipMemcpy(h1.data(), o1, h1.size() * 2, hipMemcpyDeviceToHost));
+                HIPCHECK(hipMemcpy(h2.data(), o2, h2.size() * 2, hipMemcpyDeviceToHost));
+                long diff = 0; for (size_t i = 0; i < h1.size(); ++i) diff += h1[i] != h2[i];
+                const bool ok = r3 == 0 && r4 == 0 && diff == 0;
+                printf("%s %-28s stat_ex [coeff_scalar_dev]: %ld differing outputs (rc %d %d)\n", ok ? "PASS" : "FAIL", c.name, diff, r3, r4);
+                if (!ok) g_fail++;
+            }
+            for (void *ptr : {(void *)dscalar, (void *)dcompact, (void *)dcidx}) if (ptr) (void)hipFree(ptr);
+        }
         if (timing) {
             hipEvent_t e0, e1; HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
             const int iters = 50;
             std::vector<float> gate(coeff); if (B > 1) for (int b = B / 2; b < B; ++b) gate[b] = 0.f;     // folded CFG batch: second half unconditional
             HIPCHECK(hipMemcpy(dgate, gate.data(), B * 4, hipMemcpyHostToDevice));
+            if (g_timeline) {
+                pww_cross_opts_t op; memset(&op, 0, sizeof(op)); op.size = sizeof(op); op.bias_cols = c.bias_cols;
+                timeline_report(c.name, "fused cross-attention (stamps: 0 entry, 1 K/V staged, 2 partials published, 3 statistic folded, 4 outputs stored, 5 exit)", [&]() {
+                    pww_cross_attn_fwd_fused_ex(dq, dk, dv, o2, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, nullptr, dsync, sync_bytes, fws, fws_bytes, &op, nullptr); });
+            }
             float ms_f = 0, ms_s = 0;
             for (int pass = 0; pass < 2; ++pass) {
                 for (int i = 0; i < 5 + iters; ++i) {
@@ -183,6 +281,17 @@ static void run_case(const Case &c, bool timing) {
             }
             printf("TIME %-28s fused statistic+attention %.2f us/call | pww_qk_reduce + pww_cross_attn_fwd_stat %.2f us/call (gates: first half 1, second half 0)\n",
                    c.name, ms_f * 1e3 / iters, ms_s * 1e3 / iters);
+            if (c.bias_cols) {
+                pww_cross_opts_t op; memset(&op, 0, sizeof(op)); op.size = sizeof(op); op.bias_cols = c.bias_cols;
+                float ms_e = 0;
+                for (int i = 0; i < 5 + iters; ++i) {
+                    if (i == 5) HIPCHECK(hipEventRecord(e0, nullptr));
+                    pww_cross_attn_fwd_fused_ex(dq, dk, dv, o2, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, nullptr, dsync, sync_bytes, fws, fws_bytes, &op, nullptr);
+                }
+                HIPCHECK(hipEventRecord(e1, nullptr)); HIPCHECK(hipEventSynchronize(e1));
+                HIPCHECK(hipEventElapsedTime(&ms_e, e0, e1));
+                printf("TIME %-28s fused_ex with bias_cols=%d: %.2f us/call\n", c.name, c.bias_cols, ms_e * 1e3 / iters);
+            }
         }
         for (void *ptr : {(void *)fws, (void *)dsync, (void *)fstats, (void *)o1, (void *)o2, (void *)dgate}) (void)hipFree(ptr);
     }
@@ -256,6 +365,9 @@ static void run_case(const Case &c, bool timing) {
            max_err, tol, max_ref, nan_count, nchk, stat_err, ok_stats ? "ok" : "BAD");
     if (!(ok_attn && ok_stats)) g_fail++;
 
+    if (timing && g_timeline)
+        timeline_report(c.name, "attention kernel (stamps: 0 entry, 1 first stage staged, 2 key loop done, 3 outputs stored)", [&]() {
+            c.bias_mode ? pww_cross_attn_fwd(dq, dk, dv, dout, dbias, dcoeff, &d, nullptr) : pww_self_attn_fwd(dq, dk, dv, dout, &d, nullptr); });
     if (timing) {
         hipEvent_t e0, e1; HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
         const int iters = 50;
@@ -371,6 +483,7 @@ static void check_errors() {
 }
 
 int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "--timeline")) { g_timeline = true; --argc; ++argv; }
     const bool quick = argc > 1 && !strcmp(argv[1], "--quick");
     const char *only = (argc > 2 && !strcmp(argv[1], "--only")) ? argv[2] : nullptr;
     const char *match = (argc > 2 && !strcmp(argv[1], "--match")) ? argv[2] : nullptr;     // substring of the case name
@@ -393,6 +506,19 @@ int main(int argc, char **argv) {
         {"sd15_self_n4096_d40_bf16_b2", PWW_DTYPE_BF16, 2, 8, 4096, 4096, 40, 0, true, 193, 1.0f},   // the bench's dominant launch (bf16, 2 folded rows)
         {"sd15_cross_n4096_d40", PWW_DTYPE_BF16, 2, 8, 4096, 77, 40, 1, false, 97, 1.0f},
         {"sd15_cross_n4096_d40_b16", PWW_DTYPE_BF16, 16, 8, 4096, 77, 40, 1, false, 397, 1.0f},     // 8 images folded: several query blocks per workgroup
+        // bias column bound + compact bias (pww_cross_attn_fwd_fused_ex): the map of a prompt is zero past its last region phrase
+        {"sd15_cross_n4096_d40_cols32", PWW_DTYPE_BF16, 2, 8, 4096, 77, 40, 1, false, 97, 1.0f, 0.f, 32, 9},
+        {"sd15_cross_n4096_d40_b16_cols32", PWW_DTYPE_BF16, 16, 8, 4096, 77, 40, 1, false, 397, 1.0f, 0.f, 32, 9},
+        {"sd15_cross_n4096_f16_b16_cols48", PWW_DTYPE_F16, 16, 8, 4096, 77, 40, 1, false, 397, 1.0f, 0.f, 48, 17},
+        {"sd15_cross_n1024_d80_cols32", PWW_DTYPE_BF16, 2, 8, 1024, 77, 80, 1, false, 17, 0.7f, 0.f, 32, 5},
+        {"sd15_cross_n1024_d80_b16_cols48", PWW_DTYPE_F16, 16, 8, 1024, 77, 80, 1, false, 67, 0.7f, 0.f, 48, 17},
+        {"sd15_cross_n256_d160_cols32", PWW_DTYPE_F16, 2, 8, 256, 77, 160, 1, false, 3, 0.5f, 0.f, 32, 9},
+        {"sd15_cross_n256_d160_b16_cols32", PWW_DTYPE_BF16, 16, 8, 256, 77, 160, 1, false, 5, 0.5f, 0.f, 32, 9},
+        {"sd15_cross_n64_d160_cols16", PWW_DTYPE_BF16, 2, 8, 64, 77, 160, 1, false, 1, 0.5f, 0.f, 16, 3},
+        {"sd21_cross_n9216_d64_b8_cols32", PWW_DTYPE_BF16, 8, 5, 9216, 77, 64, 1, false, 1531, 0.8f, 0.f, 32, 12},
+        {"cross_n200_m128_d64_cols112", PWW_DTYPE_BF16, 3, 5, 200, 128, 64, 1, false, 1, 0.8f, 0.f, 112, 32},
+        {"cross_n100_m40_d80_cols16", PWW_DTYPE_F16, 2, 4, 100, 40, 80, 1, false, 1, 0.8f, 0.f, 16, 1},
+        {"cross_n333_m77_d96_cols80", PWW_DTYPE_BF16, 2, 3, 333, 77, 96, 1, false, 1, 0.6f, 0.f, 77, 20},
         {"cross_n64_d160_b72_split", PWW_DTYPE_F16, 72, 8, 64, 77, 160, 1, false, 7, 0.5f},        // more (image, head) pairs than resident workgroups: two-launch path
         {"cross_n200_m128_d64", PWW_DTYPE_BF16, 3, 5, 200, 128, 64, 1, false, 1, 0.8f},
         {"cross_n100_m40_d80", PWW_DTYPE_F16, 2, 4, 100, 40, 80, 1, false, 1, 0.8f},
@@ -428,6 +554,15 @@ int main(int argc, char **argv) {
         {"d160_late_outlier_bf16", PWW_DTYPE_BF16, 2, 8, 300, 300, 160, 0, true, 3, 0.5f, 90.f},
         {"d64_self_n2304_bf16_b8", PWW_DTYPE_BF16, 8, 10, 2304, 2304, 64, 0, true, 193, 0.8f},
         {"d40_mild_outlier_bf16", PWW_DTYPE_BF16, 2, 4, 700, 700, 40, 0, true, 1, 1.0f, 10.f},      // scaled logits to +-40: inside the range, fast path only
+        // magnitude guard of the folded-reference kernel: row maxima of ~80 and ~120 natural units (gain g gives scaled logits ~ N(0, g^2)):
+        // far beyond where the extra rounding of Q * scale * log2(e) keeps the bar -- the kernel has to take its exact path by itself
+        {"d40_logit80_bf16", PWW_DTYPE_BF16, 2, 4, 700, 700, 40, 0, true, 1, 24.f},
+        {"d40_logit80_f16", PWW_DTYPE_F16, 2, 4, 700, 700, 40, 0, true, 1, 24.f},
+        {"d40_logit120_bf16", PWW_DTYPE_BF16, 2, 4, 1100, 1100, 40, 0, true, 3, 36.f},
+        {"d40_logit120_f16", PWW_DTYPE_F16, 2, 4, 1100, 1100, 40, 0, true, 3, 36.f},
+        {"d40_logit30_f16", PWW_DTYPE_F16, 2, 8, 1024, 1024, 40, 0, true, 7, 8.f},                   // f16: above the f16 limit (20), below the bf16 one
+        {"d40_logit12_f16", PWW_DTYPE_F16, 2, 8, 1024, 1024, 40, 0, true, 7, 3.0f},                  // f16 fast path (folded), realistic logit spread
+        {"d40_n4096_hot_f16_b2", PWW_DTYPE_F16, 2, 8, 4096, 4096, 40, 0, true, 193, 3.0f},
     };
     for (auto &c : cases) {
         const bool big = (long)c.N * c.M >= 1024L * 1024L || c.N >= 4096;

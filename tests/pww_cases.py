@@ -71,6 +71,13 @@ def stripes_case(n_regions=8, size=512):
     return img, ctx, prompt
 
 
+def stripes_batch_case(j, n_regions=8, size=512):
+    """Image j of BASELINE config 3's batch: the stripes map rotated by j stripes (so every image of the batch has its
+    OWN weight maps -- the per-image bias path), same color_context and prompt, seed j."""
+    img, ctx, prompt = stripes_case(n_regions, size)
+    return np.ascontiguousarray(np.roll(img, j * (size // n_regions), axis=1)), ctx, prompt
+
+
 def grid_case(rows=3, cols=4, height=768, width=768, seeds=True):
     """BASELINE config 5: rows x cols grid, per-region seeds 1000 + i."""
     words = ["alpha", "bravo", "charlie", "delta", "echo", "foxtrot", "golf", "hotel", "india", "juliet",

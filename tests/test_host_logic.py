@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol(built_lib):
     raw = ctypes.CDLL(built_lib)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.pww_version() == 111
+    assert lib.pww_version() == 120
     assert lib.pww_last_error() == b"" or isinstance(lib.pww_last_error(), bytes)
     assert lib.pww_workspace_bytes(None) == 0
 
@@ -290,10 +290,19 @@ def test_pipeline_call_signatures_match_reference():
     assert P2 is P and PI2 is PI
 
 
+_SIG_GLOBAL_K = 2.0
+
+
+def _sig_helper(x):
+    return 2.0 * x
+
+
 def test_weight_function_signature_survives_fresh_lambdas():
-    """The hipGraph cache key (pww_hip/sampler.py): the reference's callers build a fresh lambda per request
-    (runner.py:104, gradio_pww.py:43) -- same code and constants must give the same key, a changed constant (in the
-    code, a closure cell, a default or a numeric global) a different one."""
+    """The cache key of the per-step FALL-BACK graphs (pww_hip/sampler.py; the regular hipGraph path re-evaluates the weight
+    function on the host every step and needs no key): the reference's callers build a fresh lambda per request (runner.py:104,
+    gradio_pww.py:43) -- same code and constants must give the same key, a changed constant (in the code, in a NESTED code
+    object, a closure cell, a default or a numeric global) a different one, and anything that cannot be proven constant (a
+    helper function, a mutable object in a closure, a callable object) never matches: re-capture instead of a stale replay."""
     from pww_hip.sampler import weight_function_signature as sig
 
     def make(c):
@@ -312,7 +321,50 @@ def test_weight_function_signature_survives_fresh_lambdas():
     assert sig(f1) != sig(f2)
     assert sig(cases.weight_fn_runner) == sig(cases.weight_fn_runner) != sig(cases.weight_fn_std)
     t = torch.ones(2)
-    assert sig(lambda w, s, qk: t * w) == sig(lambda w, s, qk: t * w)       # same captured object: same key
+    assert sig(lambda w, s, qk: t * w) != sig(lambda w, s, qk: t * w)       # a captured tensor / list / config object may have been mutated
+    cfg = {"k": 0.4}
+    fc = lambda w, s, qk: cfg["k"] * w * qk.max()   # noqa: E731
+    assert sig(fc) != sig(fc)
+    # constants inside nested code objects (inner lambdas / comprehensions) are part of the key
+    n1 = lambda w, s, qk: (lambda: 0.4)() * w * qk.max()   # noqa: E731
+    n1b = lambda w, s, qk: (lambda: 0.4)() * w * qk.max()   # noqa: E731
+    n2 = lambda w, s, qk: (lambda: 0.5)() * w * qk.max()   # noqa: E731
+    assert sig(n1) == sig(n1b) != sig(n2)
+    # numeric globals are keyed by value, helper functions make the key unmatchable
+    g1 = lambda w, s, qk: _SIG_GLOBAL_K * w * qk.max()   # noqa: E731
+    assert sig(g1) == sig(lambda w, s, qk: _SIG_GLOBAL_K * w * qk.max())
+    assert sig(lambda w, s, qk: _sig_helper(w) * qk.max()) != sig(lambda w, s, qk: _sig_helper(w) * qk.max())
+
+    class Callable_:
+        def __call__(self, w, s, qk):
+            return 0.4 * w
+    c = Callable_()
+    assert sig(c) != sig(c)
+
+
+def test_coeff_slots_reevaluate_the_weight_function_on_the_host():
+    """hipGraph mode keeps the weight function's per-step Python scalar in device words (attention.CoeffSlots): the host
+    re-evaluates the function on symbolic stand-ins each step. Checked here without a GPU: the symbolic evaluation returns the
+    same scalar / statistic the real call forms, follows changed constants, and reports functions it cannot decompose."""
+    from pww_hip.attention import ScaledW, _ProbeProxy, _symbolic_scalar, _NotSymbolic
+    from pww_hip import ops
+    w = torch.rand(16, 77)
+    probe = lambda: _ProbeProxy((8, 16, 77), torch.float16, "cpu")   # noqa: E731
+    sigma = torch.tensor(7.84)
+    kind, scalar = _symbolic_scalar(cases.weight_fn_runner(ScaledW(w), sigma, probe()))
+    assert kind == ops.STAT_MAX and abs(scalar - 0.4 * math.log(1 + 7.84)) < 1e-6
+    kind, scalar = _symbolic_scalar(cases.weight_fn_std(ScaledW(w), sigma, probe()))
+    assert kind == ops.STAT_STD and abs(scalar - 0.4 * math.log(1 + 7.84 ** 2)) < 1e-5
+    kind, scalar = _symbolic_scalar((lambda w, s, qk: 0.25 * w)(ScaledW(w), sigma, probe()))
+    assert kind == ops.STAT_NONE and scalar == 0.25
+    assert _symbolic_scalar((lambda w, s, qk: 0.0)(ScaledW(w), sigma, probe())) is None
+    assert _symbolic_scalar((lambda w, s, qk: torch.log(s + 1) * w)(ScaledW(w), sigma, probe())) is None              # tensor coefficient
+    with pytest.raises(_NotSymbolic):
+        (lambda w, s, qk: torch.log(s + 1) * w * qk.max())(ScaledW(w), sigma, probe())   # tensor coefficient times the statistic: needs its value
+    with pytest.raises(_NotSymbolic):
+        (lambda w, s, qk: w * qk.max() + qk.mean().sqrt())(ScaledW(w), sigma, probe())    # needs the statistic's value
+    with pytest.raises(_NotSymbolic):
+        (lambda w, s, qk: w * qk[0, 0, 0])(ScaledW(w), sigma, probe())                    # needs the scores themselves
 
 
 def test_fold_context_per_image_maps():
@@ -407,3 +459,41 @@ def test_reference_runner_script_resolves_against_this_package(tmp_path):
     assert "pww_load_tools" in err and "CompVis/stable-diffusion-v1-4" in out.stdout          # got as far as loading and placing the modules
     assert ("Torch not compiled with CUDA enabled" in err or "No HIP GPUs are available" in err or "HIP" in err.splitlines()[-1]
             or "CUDA" in err.splitlines()[-1]), err[-1500:]
+
+
+def test_reference_runner_inpaint_script_resolves_against_this_package(tmp_path):
+    """The reference's own runner_inpaint.py (:40-92), unmodified, like runner.py above: `from paint_with_words import
+    paint_with_words_inpaint, PaintWithWord_StableDiffusionInpaintPipeline` and its keyword call must resolve against this
+    package, pww_load_tools must run for "runwayml/stable-diffusion-inpainting" (stand-in modules with a 9-channel UNet), and
+    without a GPU the run stops where the modules move to "cuda:0". The GPU box runs tests/scripts/runner_inpaint_like.py to
+    the saved images (tests/test_round3_gpu.py::test_runner_inpaint_script_end_to_end)."""
+    import subprocess
+    import sys
+    runner = "/root/reference/runner_inpaint.py"
+    if not os.path.isfile(runner):
+        pytest.skip("reference checkout not present (GPU box)")
+    os.symlink("/root/reference/contents", tmp_path / "contents")
+    out = subprocess.run([sys.executable, os.path.join(cases.REPO, "tests", "scripts", "reference_env.py"), runner], cwd=tmp_path,
+                         capture_output=True, text=True, timeout=600)
+    if torch.cuda.is_available():
+        assert out.returncode == 0, out.stderr[-3000:]
+        return
+    err = out.stderr
+    assert out.returncode != 0
+    assert "ImportError" not in err and "TypeError" not in err and "AttributeError" not in err, err[-3000:]
+    assert "pww_load_tools" in err and "runwayml/stable-diffusion-inpainting" in out.stdout
+    assert ("Torch not compiled with CUDA enabled" in err or "No HIP GPUs are available" in err or "HIP" in err.splitlines()[-1]
+            or "CUDA" in err.splitlines()[-1]), err[-1500:]
+
+
+def test_pipeline_accepts_a_missing_color_map():
+    """`pipe(prompt)` with the reference's defaults (color_map_image=None, color_context={}): its _image_context_seperator
+    builds one dummy region over a 512 x 512 all-zero map (paint_with_words.py:239-243), i.e. plain Stable Diffusion. The
+    conditioning builder must do the same instead of failing on `None`."""
+    import sd_standin as S
+    from pww_hip.conditioning import _encode_text_color_inputs
+    text, tok = S.TinyTextEncoder(64, seed=1235), S.HashTokenizer()
+    seeds, info, cond, uncond = _encode_text_color_inputs(text, tok, "cpu", None, {}, "a photo of a cat", "")
+    assert seeds == {} and cond["CONTEXT_TENSOR"].shape == (1, 77, 64)
+    assert cond["CROSS_ATTENTION_WEIGHT_4096"].shape == (4096, 77) and float(cond["CROSS_ATTENTION_WEIGHT_4096"].abs().sum()) == 0.0
+    assert cond["CROSS_ATTENTION_WEIGHT_ORIG"].shape == (512, 512, 77) and uncond["CROSS_ATTENTION_WEIGHT_64"] == 0
