@@ -29,7 +29,14 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
   "kernels"      the same pass's table for EVERY pww launch class: average duration, algorithmic TFLOP/s and GB/s,
                  bounding roofline and fraction; plus a hot-logit run of the dominant shape;
   "cpu_baseline" the CPU oracle (port of the reference path) timed on this box's host cores on a bounded sample
-                 (rank 0, N=1 only), with the AST-loaded reference's own timing from the build box beside it.
+                 (rank 0, N=1 only): torch thread counts 8 / 16 / 32 / 64 / 128 are swept on one UNet forward each and the
+                 BEST one is used for the timed denoise step(s) -- the 256-vCPU bench box is slower oversubscribed --, with the
+                 AST-loaded reference's own timing from the build box beside it.
+
+Test infrastructure used as bench infrastructure (deliberately, so that bench and parity tests see the same inputs):
+`tests/pww_cases.py` (workload definitions: color maps, color_contexts, prompts, weight functions, stand-in builders) and
+`tests/gpu_util.py` (install_unfused: the reference's op sequence as unfused torch ops, the "reference ops on this GPU" bar);
+`oracle/pww_oracle.py` only inside the `cpu_baseline` leg.
 """
 import argparse
 import json
@@ -107,15 +114,17 @@ def build_tools(device, dtype, scheduler_name, model, tiny=False):
     if tiny:      # dry run on a box without GPUs: same block structure at 1/8 width
         cfg = dict(S.TINY_SD2_CONFIG if model == "sd21" else S.TINY_CONFIG, in_channels=cfg["in_channels"])
     t0 = time.time()
+    timing = {}
     unet, nbytes = pdist.build_and_broadcast(lambda: S.build_unet(cfg, seed=1234, dtype=dtype, device="cpu", qk_gain=2.0),
-                                             lambda: S.UNet2DConditionModel(**cfg), device, dtype, src=0)
+                                             lambda: S.UNet2DConditionModel(**cfg), device, dtype, src=0, timing=timing)
     if torch.device(device).type == "cuda":
         torch.cuda.synchronize()
     text = S.TinyTextEncoder(cfg["cross_attention_dim"], seed=1235).to(device=device, dtype=dtype)
     vae = S.TinyVAE(4, seed=1236).to(device=device, dtype=dtype)
     sched = (S.PLMSScheduler() if scheduler_name == "plms" else
              S.LMSDiscreteScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000))
-    info = {"build_and_broadcast_s": round(time.time() - t0, 2), "broadcast_bytes": int(nbytes)}
+    info = {"build_and_broadcast_s": round(time.time() - t0, 2), "rank0_build_s": timing.get("build_s"), "weight_broadcast_s": timing.get("broadcast_s"),
+            "broadcast_bytes": int(nbytes), "bucket_bytes": pdist.BROADCAST_BUCKET_BYTES}
     return (vae, unet, text, S.HashTokenizer(), sched), info
 
 
@@ -259,17 +268,56 @@ def hot_logit_row(device, dtype, B, N, D, heads):
     return kernel_row("self", us, B, N, N, D, heads, B, 2, 0, label="self (hot logits: scaled-logit std 4, synthetic q/k)")
 
 
-def measured_traffic(n_tok, d, b_rows, dtype):
-    """HBM bytes per launch of the dominant kernel from the committed PMC pass of the SHIPPED kernel and dtype
-    (profiles/r02_attn_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over the same shape through the native
-    harness, tools/pmc_traffic.sh); None if the shape or dtype differs."""
-    path = os.path.join(REPO, "profiles", "r02_attn_traffic.json")
-    if not os.path.isfile(path):
+def measured_traffic(n_tok, d, b_rows, dtype, live=False):
+    """HBM bytes per launch of the dominant kernel (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes as
+    MI355X_MICROARCH.md prescribes; correction: see the `correction` field of the profile file -- the head-sliced rows of this
+    kernel are fetched as 64-byte requests, calibrated x1.0 on the reduce kernel's known byte count). Default: the committed PMC
+    pass of the SHIPPED kernel and dtype for this shape (profiles/r03_traffic.json, else the round-2 file); `live` = run the two
+    passes now over the same launch through the native harness. None if the shape is not covered."""
+    if live:
+        return live_traffic(n_tok, d, b_rows, dtype)
+    for name in ("r03_traffic.json", "r02_attn_traffic.json"):
+        path = os.path.join(REPO, "profiles", name)
+        if not os.path.isfile(path):
+            continue
+        recs = json.load(open(path))
+        for rec in (recs if isinstance(recs, list) else [recs]):
+            if (rec.get("N"), rec.get("D"), rec.get("B"), rec.get("dtype")) == (n_tok, d, b_rows, dtype) and rec.get("kind", "self") == "self":
+                return int(rec["hbm_bytes_per_launch"])
+    return None
+
+
+HARNESS_CASES = {(4096, 40, 2, "bf16"): "sd15_self_n4096_d40_bf16_b2", (4096, 40, 2, "fp16"): "sd15_self_n4096_d40_f16_b2",
+                 (9216, 64, 4, "bf16"): "sd21_self_n9216_d64_b4"}
+
+
+def live_traffic(n_tok, d, b_rows, dtype):
+    """rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one pass each; they do not fit one pass) over tests/native/attn_check --only <case>:
+    mean per dispatch of the attention kernel, KiB -> bytes. None if rocprofv3 or a harness case for the shape is missing."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    case = HARNESS_CASES.get((n_tok, d, b_rows, dtype))
+    exe = os.path.join(REPO, "tests", "native", "attn_check")
+    if case is None or not os.path.isfile(exe) or shutil.which("rocprofv3") is None:
         return None
-    rec = json.load(open(path))
-    if (rec.get("N"), rec.get("D"), rec.get("B"), rec.get("dtype")) != (n_tok, d, b_rows, dtype):
-        return None
-    return int(rec["hbm_bytes_per_launch"])
+    total = 0.0
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="pww_pmc_")
+        env = dict(os.environ, TMPDIR="/tmp")
+        subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "pmc", "--", exe, "--only", case],
+                       cwd="/tmp", env=env, capture_output=True, timeout=600)
+        vals = []
+        for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+            for row in csv.DictReader(open(f)):
+                if "attn_fwd" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    vals.append(float(row["Counter_Value"]))
+        shutil.rmtree(out, ignore_errors=True)
+        if not vals:
+            return None
+        total += sum(vals) / len(vals) * 1024.0
+    return int(total)
 
 
 # ---- baselines ------------------------------------------------------------------------------------------------------
@@ -309,20 +357,38 @@ def reference_ops_same_gpu(cfg, tools, request, device, dtype, guidance):
 
 
 def cpu_baseline(args, cfg, request):
-    """The oracle (CPU port of the reference path, fp32) on the host cores: a bounded sample of the same
-    workload -- `--cpu-steps` denoise steps (2 UNet forwards each) of the full-size loop."""
+    """The oracle (CPU port of the reference path, fp32) on the host cores: a bounded sample of the same workload --
+    `--cpu-steps` denoise steps (2 UNet forwards each) of the full-size loop at the BEST torch thread count of a sweep
+    (one conditional UNet forward per candidate: 8 / 16 / 32 / 64 / 128 threads, capped by the box)."""
     from oracle import pww_oracle as O
     import pww_cases as cases
     log("cpu baseline: building fp32 UNet")
     vae, unet, text, tok, sch = cases.build_tools(cfg["model"], dtype=torch.float32, device="cpu", scheduler="lms", qk_gain=2.0)
     wf = weight_functions()[cfg["wf"]]
     n_denoise_steps = cfg["denoise_steps"]
+    ncpu = os.cpu_count() or 1
+    threads0 = torch.get_num_threads()
     O.install_oracle_attention(unet)
+    sweep = {}
     try:
         seeds, regions, cond, uncond = O.encode_text_color_inputs(text, tok, request["rgb"], dict(request["context"]), request["prompt"], "")
         latents = O.initial_latents(0, 4, request["rgb"].shape[0], request["rgb"].shape[1])
         sch.set_timesteps(n_denoise_steps)
         latents = latents * sch.init_noise_sigma
+        t, sigma = sch.timesteps[0], sch.sigmas[0]
+        x = sch.scale_model_input(latents, t)
+        cond.update({"SIGMA": sigma, "WEIGHT_FUNCTION": wf})
+        cands = sorted({n for n in (8, 16, 32, 64, 128) if n <= ncpu} | ({ncpu} if ncpu < 8 else set()))
+        torch.set_num_threads(cands[len(cands) // 2])
+        unet(x, t, encoder_hidden_states=cond)                       # one-time costs (primitive creation, page faults) stay out of the sweep
+        for n in cands:
+            torch.set_num_threads(n)
+            t0 = time.perf_counter()
+            unet(x, t, encoder_hidden_states=cond)
+            sweep[n] = round(time.perf_counter() - t0, 3)
+            log("cpu baseline sweep: %d threads %.2f s per conditional UNet forward" % (n, sweep[n]))
+        best = min(sweep, key=sweep.get)
+        torch.set_num_threads(best)
         times = []
         for i, t in enumerate(sch.timesteps[: args.cpu_steps]):
             t0 = time.perf_counter()
@@ -334,17 +400,20 @@ def cpu_baseline(args, cfg, request):
             eu = unet(x, t, encoder_hidden_states=uncond).sample
             latents = sch.step(O.cfg_combine(ec, eu, 7.5), t, latents).prev_sample
             times.append(time.perf_counter() - t0)
-            log("cpu baseline step", i, "%.2f s" % times[-1])
+            log("cpu baseline step", i, "%.2f s at %d threads" % (times[-1], best))
     finally:
+        torch.set_num_threads(threads0)
         from sd_standin import CrossAttention
         if "__call__" in CrossAttention.__dict__:
             del CrossAttention.__call__
     per_step = float(np.mean(times))
     unet_evals = n_denoise_steps + (1 if cfg["scheduler"] == "plms" else 0)
-    out = {"value": round(1.0 / (per_step * unet_evals), 6), "unit": "images/s", "cores": torch.get_num_threads(),
+    out = {"value": round(1.0 / (per_step * unet_evals), 6), "unit": "images/s", "cores": best,
            "kind": "port",
-           "sample": "%d of %d denoise steps (2 fp32 UNet forwards each, oracle attention) of the same %dx%d workload, %.2f s/step, "
-                     "extrapolated to %d steps" % (len(times), unet_evals, cfg["size"], cfg["size"], per_step, unet_evals)}
+           "sample": "%d of %d denoise steps (2 fp32 UNet forwards each, oracle attention) of the same %dx%d workload at the best of the swept "
+                     "torch thread counts (%d of %d logical CPUs), %.2f s/step, extrapolated to %d steps"
+                     % (len(times), unet_evals, cfg["size"], cfg["size"], best, ncpu, per_step, unet_evals),
+           "thread_sweep_s_per_unet_forward": {str(k): v for k, v in sweep.items()}, "logical_cpus": ncpu}
     ref_path = os.path.join(REPO, "tests", "golden", "ref_cpu_timing.json")
     if os.path.isfile(ref_path):     # the AST-loaded, unmodified reference timed on the BUILD box (oracle/make_golden.py reftime):
         rec = json.load(open(ref_path))   # /root/reference does not exist on the GPU box, so this figure travels as a fixture
@@ -388,7 +457,9 @@ def main():
     ap.add_argument("--scheduler", default=None, choices=["plms", "lms"])
     ap.add_argument("--denoise-steps", type=int, default=None)
     ap.add_argument("--guidance", type=float, default=7.5)
-    ap.add_argument("--cpu-steps", type=int, default=2, help="denoise steps timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=1, help="denoise steps timed for the CPU baseline after the thread sweep (0 = skip)")
+    ap.add_argument("--live-traffic", action="store_true", help="measure roofline.traffic NOW: two extra rocprofv3 --pmc passes (FETCH_SIZE, "
+                    "WRITE_SIZE) over the dominant launch through tests/native/attn_check (default: the committed PMC pass of this kernel under profiles/)")
     ap.add_argument("--no-roofline-pass", action="store_true")
     ap.add_argument("--no-reference-ops", action="store_true", help="skip the unfused-torch-ops-on-this-GPU pass")
     ap.add_argument("--memory-format", default="auto", choices=["auto", "nchw", "channels_last"],
@@ -471,7 +542,7 @@ def main():
                    "baseline_config": args.config, "mode": args.mode, "images_per_step": n_global,
                    "stock_op_settings": "MIOpen find mode%s" % (", UNet in channels_last memory format" if channels_last else ""),
                    "parallelism": "image-sharded x%d, no data-path collective" % world,
-                   "weight_broadcast": build_info, "request_broadcast_s": round(req_bcast_s, 4)},
+                   "weight_broadcast": build_info, "weight_broadcast_s": build_info.get("weight_broadcast_s"), "request_broadcast_s": round(req_bcast_s, 4)},
     }
     if args.config != 2 or cfg["denoise_steps"] != 30:     # (an overridden step count must not carry the headline's "30 steps" label)
         result["metric"] = "%dx%d images/sec (%d steps, CFG) %s+PwW" % (cfg["size"], cfg["size"], cfg["denoise_steps"],
@@ -486,10 +557,18 @@ def main():
             torch.distributed.destroy_process_group()
         return
 
+    warm_s = []
     for w in range(args.warmup):
+        t0 = time.perf_counter()
         one_step(w)
         torch.cuda.synchronize()
-        log("warmup step", w, "done")
+        warm_s.append(round(time.perf_counter() - t0, 2))
+        log("warmup step", w, "done in %.2f s" % warm_s[-1])
+    result["config"]["warmup_s"] = warm_s      # the first one holds MIOpen's solver search and the ONE hipGraph capture of the geometry
+    if args.mode == "graph":
+        smp = getattr(unet, "_pww_samplers", {}).get((id(sched), "graph"))
+        if smp is not None and smp._graphed is not None:
+            result["config"]["hipgraph_captures"] = smp._graphed.captures
     pdist.barrier(device)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -539,7 +618,9 @@ def main():
             result["kernels"].append(hot_logit_row(device, dtype, b_rows, n_dom, d, heads))
             result["roofline"] = {"bound": "mfma", "kernel": "self-attention N=%d d=%d (%s, B=%d rows folded)" % (n_dom, d, cfg["dtype"], b_rows),
                                   "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                                  "traffic": measured_traffic(n_dom, d, b_rows, cfg["dtype"]), "algorithmic_bytes": 2 * (2 * b_rows * n_dom * heads * d) * 2,
+                                  "traffic": measured_traffic(n_dom, d, b_rows, cfg["dtype"], live=args.live_traffic),
+                                  "traffic_source": "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes" if args.live_traffic else "committed PMC pass of the shipped kernel (profiles/)",
+                                  "algorithmic_bytes": 2 * (2 * b_rows * n_dom * heads * d) * 2,
                                   "avg_us": round(us, 2), "avg_us_method": "kernel-only HIP event timestamps (hipExtLaunchKernelGGL start/stop events) of every launch of this "
                                   "class in an eager pass of the same workload, on the launch stream",
                                   "avg_us_back_to_back_graph_replay": round(us_b2b, 2), "avg_us_event_bracket_eager": round(us_situ, 2),

@@ -34,10 +34,19 @@ def _worker(rank, world, port, out_dir):
     assert nbytes == sum(p.numel() * p.element_size() for p in ref.parameters())
     for a, b in zip(unet.parameters(), ref.parameters()):
         assert torch.equal(a, b)
+    # (a'') the same through many small buckets (64 KiB: several tensors per bucket, and tensors larger than a bucket on their own)
+    unet_b = build_unet(TINY_CONFIG, seed=1234 if rank == 0 else 555)
+    assert any(p.numel() * 4 > (1 << 16) for p in unet_b.parameters()) and any(p.numel() * 4 < (1 << 12) for p in unet_b.parameters())
+    assert pdist.broadcast_module(unet_b, src=0, bucket_bytes=1 << 16) == nbytes
+    for a, b in zip(unet_b.parameters(), ref.parameters()):
+        assert torch.equal(a, b)
     # (a') what bench.py does: rank 0 builds, the others allocate a meta skeleton and receive the values
     from sd_standin import UNet2DConditionModel
+    timing = {}
     m2, nb2 = pdist.build_and_broadcast(lambda: build_unet(TINY_CONFIG, seed=77), lambda: UNet2DConditionModel(**TINY_CONFIG),
-                                        dev, torch.float32, src=0)
+                                        dev, torch.float32, src=0, timing=timing)
+    assert set(timing) == {"build_s", "broadcast_s"}
+    assert os.environ.get("MIOPEN_USER_DB_PATH", "").endswith("pww_rank%d" % rank)      # one MIOpen user db per local rank
     ref2 = build_unet(TINY_CONFIG, seed=77)
     assert nb2 == nbytes and not any(p.is_meta for p in m2.parameters())
     for a, b in zip(m2.parameters(), ref2.parameters()):

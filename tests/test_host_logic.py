@@ -390,22 +390,28 @@ def test_fold_context_per_image_maps():
         _fold_context(conds[:2], unc, 3, "cpu")
 
 
-def test_bench_spawns_its_own_ranks_dry_run():
-    """`python bench.py --gpus 2 --config 3` outside a launcher re-executes itself as 2 ranks (torch.distributed.run,
-    127.0.0.1 rendezvous); on a box without GPUs `--dry-run` carries the run through rendezvous (gloo), the weight
-    broadcast of a 1/8-width model and the request broadcast, and prints the contract line with value null."""
+@pytest.mark.parametrize("gpus", [2, 8])
+def test_bench_spawns_its_own_ranks_dry_run(gpus, tmp_path):
+    """`python bench.py --gpus N --config 3` outside a launcher re-executes itself as N ranks (torch.distributed.run,
+    127.0.0.1 rendezvous); on a box without GPUs `--dry-run` carries the run through rendezvous (gloo), the bucketed weight
+    broadcast of a 1/8-width model and the request broadcast, and prints the contract line with value null -- with 2 ranks and
+    with the 8 ranks of the driver's scaling run (one MIOpen user db per local rank)."""
     import subprocess
     import sys
-    env = dict(os.environ, PWW_BENCH_VERBOSE="0")
-    env.pop("WORLD_SIZE", None), env.pop("RANK", None)
-    out = subprocess.run([sys.executable, os.path.join(cases.REPO, "bench.py"), "--gpus", "2", "--config", "3", "--dry-run"],
-                         capture_output=True, text=True, timeout=600, env=env)
+    env = dict(os.environ, PWW_BENCH_VERBOSE="0", PWW_MIOPEN_DB_BASE=str(tmp_path / "miopen"))
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("MIOPEN_USER_DB_PATH", None)
+    out = subprocess.run([sys.executable, os.path.join(cases.REPO, "bench.py"), "--gpus", str(gpus), "--config", "3", "--dry-run"],
+                         capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["value"] is None and rec["dry_run"] is True and rec["scaling"] == "weak"
-    assert rec["config"]["weight_broadcast"]["broadcast_bytes"] > 0 and rec["config"]["images_per_step"] == 16
+    assert rec["n_gpus"] == gpus and rec["value"] is None and rec["dry_run"] is True and rec["scaling"] == "weak"
+    assert rec["config"]["weight_broadcast"]["broadcast_bytes"] > 0 and rec["config"]["images_per_step"] == 8 * gpus
+    assert rec["config"]["weight_broadcast_s"] is not None and rec["config"]["request_broadcast_s"] is not None
+    assert sorted(os.listdir(tmp_path / "miopen")) == ["pww_rank%d" % r for r in range(gpus)]
+    if gpus != 2:
+        return
     assert "8 vertical stripes" in rec["config"]["workload"] and rec["config"]["baseline_config"] == 3
     # without --dry-run and without a GPU the run stops at the device check with a clear message
     out = subprocess.run([sys.executable, os.path.join(cases.REPO, "bench.py"), "--config", "4"], capture_output=True, text=True, timeout=600, env=env)
