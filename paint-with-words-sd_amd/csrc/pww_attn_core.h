@@ -238,35 +238,42 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
 
     // raw-domain logits x = s + c*bias (scale > 0, so the row max commutes with the scaling)
     // (a 4-way max tree and packed v_pk_fma_f32 for the exp arguments were measured: neutral to -3%)
+    // a 32-key block entirely past M (the second block of a ragged tail: keys 96..127 of the 77 prompt tokens) takes no part in
+    // anything below -- wave-uniform, and its P^T fragments are never multiplied (the PV loop skips the same blocks)
+    const bool live0 = !MASKED || key0 < M, live1 = !MASKED || key0 + 32 < M;
     float tmax = -INFINITY;
     if (HAS_BIAS == 2) {
         // the lane's 8 consecutive keys of each (block, half) are 32 contiguous bytes of its row in the LDS tile; a 16-key
         // group past the last non-zero column of the map (wave-uniform test) gets no loads and no multiply-adds at all
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            if (kb == 0 ? live0 : live1) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const int col0 = key0 + kb * 32 + 16 * g;
-                if (col0 < bias.lds_cols) {
-                    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bias.lds_row + (col0 + 8 * hi) * 4);
-                    const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bias.lds_row + (col0 + 8 * hi) * 4 + 16);
+                for (int g = 0; g < 2; ++g) {
+                    const int col0 = key0 + kb * 32 + 16 * g;
+                    float m4[2] = {-INFINITY, -INFINITY};        // two short max chains per group instead of one long one
+                    if (col0 < bias.lds_cols) {
+                        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bias.lds_row + (col0 + 8 * hi) * 4);
+                        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bias.lds_row + (col0 + 8 * hi) * 4 + 16);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int r = g * 8 + j;
-                        float x = fmaf(j < 4 ? b0[j] : b1[j - 4], coeff, s[kb][r]);
-                        if (MASKED) x = key0 + key_of(kb, r, hi) < M ? x : -INFINITY;
-                        s[kb][r] = x;
-                        tmax = fmaxf(tmax, x);
+                        for (int j = 0; j < 8; ++j) {
+                            const int r = g * 8 + j;
+                            float x = fmaf(j < 4 ? b0[j] : b1[j - 4], coeff, s[kb][r]);
+                            if (MASKED) x = key0 + key_of(kb, r, hi) < M ? x : -INFINITY;
+                            s[kb][r] = x;
+                            m4[j & 1] = fmaxf(m4[j & 1], x);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int r = g * 8 + j;
+                            float x = s[kb][r];
+                            if (MASKED) x = key0 + key_of(kb, r, hi) < M ? x : -INFINITY;
+                            s[kb][r] = x;
+                            m4[j & 1] = fmaxf(m4[j & 1], x);
+                        }
                     }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int r = g * 8 + j;
-                        float x = s[kb][r];
-                        if (MASKED) x = key0 + key_of(kb, r, hi) < M ? x : -INFINITY;
-                        s[kb][r] = x;
-                        tmax = fmaxf(tmax, x);
-                    }
+                    tmax = fmaxf(tmax, fmaxf(m4[0], m4[1]));
                 }
             }
         }
@@ -277,25 +284,28 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
         // buffer loads allow; the range check is per dword, so a row tail never zeroes its in-range neighbours.
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            if (kb == 0 ? live0 : live1) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const unsigned off = bias.row_off + (unsigned)(key0 + kb * 32 + 16 * g + 8 * hi) * 4u;
-                const u32x4 b0 = __builtin_amdgcn_raw_buffer_load_b128(bias.srd, off, 0, 0);
-                const u32x4 b1 = __builtin_amdgcn_raw_buffer_load_b128(bias.srd, off + 16u, 0, 0);
+                for (int g = 0; g < 2; ++g) {
+                    const unsigned off = bias.row_off + (unsigned)(key0 + kb * 32 + 16 * g + 8 * hi) * 4u;
+                    const u32x4 b0 = __builtin_amdgcn_raw_buffer_load_b128(bias.srd, off, 0, 0);
+                    const u32x4 b1 = __builtin_amdgcn_raw_buffer_load_b128(bias.srd, off + 16u, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int r = g * 8 + j;
-                    const float bv = __builtin_bit_cast(float, j < 4 ? b0[j] : b1[j - 4]);
-                    float x = fmaf(bv, coeff, s[kb][r]);
-                    if (MASKED) x = key0 + key_of(kb, r, hi) < M ? x : -INFINITY;
-                    s[kb][r] = x;
-                    tmax = fmaxf(tmax, x);
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = g * 8 + j;
+                        const float bv = __builtin_bit_cast(float, j < 4 ? b0[j] : b1[j - 4]);
+                        float x = fmaf(bv, coeff, s[kb][r]);
+                        if (MASKED) x = key0 + key_of(kb, r, hi) < M ? x : -INFINITY;
+                        s[kb][r] = x;
+                        tmax = fmaxf(tmax, x);
+                    }
                 }
             }
         }
     } else {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+        if (kb == 0 ? live0 : live1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = key0 + key_of(kb, r, hi);
@@ -308,6 +318,7 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
             if (MASKED) x = key < M ? x : -INFINITY;
             s[kb][r] = x;
             tmax = fmaxf(tmax, x);
+        }
         }
     }
     }
@@ -327,11 +338,13 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
     V8 pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+        if (kb == 0 ? live0 : live1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c1, mc));   // exp2((x - m) * scale * log2 e)
-            if (!ROWSUM_MFMA) psum += pv;
-            pf[kb][r >> 3][r & 7] = (T)pv;
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][r], c1, mc));   // exp2((x - m) * scale * log2 e)
+                if (!ROWSUM_MFMA) psum += pv;
+                pf[kb][r >> 3][r & 7] = (T)pv;
+            }
         }
     }
     if (!ROWSUM_MFMA) l_run += psum;

@@ -228,6 +228,7 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
         stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);
         // SINGLE: the (only) block's bias rows travel with K and V (one latency for all three)
         if (SINGLE && use_tile) tile_request<NT>(treg, use_compact, cbase, bias.srd, (long)chunk * NW * 32, p.N, cp.c_sn, p.b_sn, cp.R, p.bias_cols, tid);
+        tl_stamp(p, 6);
         __syncthreads();                      // the zero fill is complete
         stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
         if (SINGLE && use_tile) tile_park<NT>(treg, use_compact, tile, cp.tile_stride, cidx, bias.srd, (long)chunk * NW * 32, p.N, p.b_sn, cp.R, p.bias_cols, tid);
@@ -237,6 +238,14 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
 
     float coeff = 0.f;
     unsigned depart_prev = 0u;     // lane 0 of the workgroup: how many workgroups of the image had left before this one
+    // which of { max, min, sum, sum of squares } this launch has to know: all four when the caller wants the statistics back,
+    // else only what the selected statistic is made of -- the others are neither reduced nor polled (a quarter of the hand-off's
+    // slot traffic for qk.max())
+    const bool f_all = cp.stats_out != nullptr;
+    const bool f_max = f_all || p.stat_kind == PWW_STAT_MAX || p.stat_kind == PWW_STAT_ABSMAX;
+    const bool f_min = f_all || p.stat_kind == PWW_STAT_MIN || p.stat_kind == PWW_STAT_ABSMAX;
+    const bool f_sum = f_all || p.stat_kind == PWW_STAT_MEAN || p.stat_kind == PWW_STAT_STD;
+    const bool f_sq = f_all || p.stat_kind == PWW_STAT_STD;
     if (need_stat) {
         // ---- pass 1: per query block (max, min, sum, sum of squares) of the raw scores, as pww_qk_reduce computes them
         V8 qn[KS];
@@ -256,14 +265,25 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
                     score_tile<T, KS>(s, qf, smem + sub * SUB_BYTES, key0, p.M, l31, hi);
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb) {
+                        if (key0 + kb * 32 < p.M) {         // (a 32-key block past M holds no live key)
+                            if (f_max || f_min) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const bool live = qvalid && (key0 + key_of(kb, r, hi) < p.M);
-                            const float x = s[kb][r];
-                            vmax = fmaxf(vmax, live ? x : -INFINITY);
-                            vmin = fminf(vmin, live ? x : INFINITY);
-                            vsum += live ? x : 0.f;
-                            vsq += live ? x * x : 0.f;
+                                for (int r = 0; r < 16; ++r) {
+                                    const bool live = qvalid && (key0 + key_of(kb, r, hi) < p.M);
+                                    const float x = s[kb][r];
+                                    vmax = fmaxf(vmax, live ? x : -INFINITY);
+                                    vmin = fminf(vmin, live ? x : INFINITY);
+                                }
+                            }
+                            if (f_sum) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const bool live = qvalid && (key0 + key_of(kb, r, hi) < p.M);
+                                    const float x = s[kb][r];
+                                    vsum += live ? x : 0.f;
+                                    vsq += live ? x * x : 0.f;
+                                }
+                            }
                         }
                     }
                 }
@@ -315,13 +335,15 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
                 dmax = -INFINITY; dmin = INFINITY; dsum = 0.0; dsq = 0.0;
                 complete = true;
                 for (int i = tid; i < bpi; i += NT) {
-                    const unsigned long long x0 = slot_read(base + i * 4 + 0), x1 = slot_read(base + i * 4 + 1);
-                    const unsigned long long x2 = slot_read(base + i * 4 + 2), x3 = slot_read(base + i * 4 + 3);
+                    // (a block's four words are published together; any one of them tells that the block has arrived)
+                    const unsigned long long one = ~0ull;
+                    const unsigned long long x0 = f_max ? slot_read(base + i * 4 + 0) : one, x1 = f_min ? slot_read(base + i * 4 + 1) : one;
+                    const unsigned long long x2 = f_sum ? slot_read(base + i * 4 + 2) : one, x3 = f_sq ? slot_read(base + i * 4 + 3) : one;
                     complete = complete && x0 != 0ull && x1 != 0ull && x2 != 0ull && x3 != 0ull;
-                    dmax = fmax(dmax, slot_value(x0));
-                    dmin = fmin(dmin, slot_value(x1));
-                    dsum += slot_value(x2);
-                    dsq += slot_value(x3);
+                    if (f_max) dmax = fmax(dmax, slot_value(x0));
+                    if (f_min) dmin = fmin(dmin, slot_value(x1));
+                    if (f_sum) dsum += slot_value(x2);
+                    if (f_sq) dsq += slot_value(x3);
                 }
                 const bool expired = wall_clock64() - t0 > SPIN_LIMIT_TICKS;
                 if (__syncthreads_and(complete || expired)) break;
@@ -508,13 +530,14 @@ static int launch_cross(CrossParams cp, hipStream_t stream, bool *launched) {
     int per_cu = -1;
     for (int i = 0; i < n_seen; ++i) if (lds_seen[i] == lds) per_cu = per_cu_seen[i];
     if (per_cu < 0) {
-        if (lds > 160 * 1024) { *launched = false; return PWW_OK; }
+        // (the kernels also own a few hundred bytes of static LDS: stay clear of the 160 KiB a workgroup can have)
+        if (lds > 156 * 1024) { *launched = false; return PWW_OK; }
         if (lds > 64 * 1024 && lds > lds_attr) {
             for (auto kern : {k_single, k_multi})
-                if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)),
+                if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                               "hipFuncSetAttribute"))
                     return PWW_EHIP;
-            lds_attr = 160 * 1024;
+            lds_attr = lds;
         }
         int n1 = 0, n2 = 0;
         if (check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_single, NW * 64, lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor") ||

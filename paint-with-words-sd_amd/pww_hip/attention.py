@@ -381,9 +381,6 @@ class CoeffSlots:
 
     def __init__(self, device):
         self.dev = torch.zeros(self.MAX, dtype=torch.float32, device=device)
-        self.host = torch.zeros(self.MAX, dtype=torch.float32)
-        if torch.cuda.is_available():
-            self.host = self.host.pin_memory()
         self.sites = []            # per call site, in call order: dict(kind, w, qk_shape, dtype)
         self.cursor = 0
         self.discover = True       # eager pass: sites are (re)registered and their words written in place
@@ -419,6 +416,7 @@ class CoeffSlots:
         words (one pinned copy). Returns False if the function no longer has the captured structure (the caller re-captures)."""
         if not self.sites:
             return True
+        vals = []
         for i, rec in enumerate(self.sites):
             try:
                 res = weight_function(ScaledW(rec["w"]), sigma, _ProbeProxy(rec["qk_shape"], rec["dtype"], rec["w"].device))
@@ -427,9 +425,10 @@ class CoeffSlots:
             sym = _symbolic_scalar(res)
             if sym is None or sym[0] != rec["kind"]:
                 return False
-            self.host[i] = sym[1]
-        n = len(self.sites)
-        self.dev[:n].copy_(self.host[:n], non_blocking=True)
+            vals.append(sym[1])
+        # A FRESH pageable host tensor per step: the copy is enqueued behind the previous replay while the host runs steps ahead
+        # of the GPU -- a re-used (pinned) staging buffer would be overwritten with a later step's scalars before the copy reads it.
+        self.dev[:len(vals)].copy_(torch.tensor(vals, dtype=torch.float32))
         return True
 
 
