@@ -91,7 +91,6 @@ template <typename T, int KS, int DT, int NW, int NSUB, int KG, bool HAS_BIAS, b
 __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, HAS_BIAS>::value)) attn_fwd_kernel(const AttnParams p) {
     static_assert(!RF || (KG == 1 && !HAS_BIAS && RangeFree<T>::value), "range-free mode: bf16, no bias, no key split");
     typedef typename Vec<T>::v8 V8;
-    typedef typename Vec<T>::v4 V4;
     typedef KTile<KS> KT;
     typedef VTile<DT> VT;
     static_assert(KG == 1 || NSUB == KG, "key-split workgroups process one sub-tile per key group");
@@ -120,6 +119,7 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
     const int qrow = (qb * NW + rg) * 32 + l31;
     const bool qvalid = qrow < p.N;
     tl_stamp(p, 0);
+    const unsigned long long tl_c0 = p.timeline ? clock64() : 0ull;
 
     V8 qf[KS];
     load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qvalid, hi, p.D);
@@ -290,23 +290,9 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
     }
     // epilogue: normalise and write O[row][d]; register r of tile dt is d = dt*32 + (r&3) + 8*(r>>2) + 4*hi
     const float inv = 1.f / l_tot;
-    if (qvalid) {
-        T *orow = Op + (long)qrow * p.o_sn;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = dt * 32 + g * 8 + hi * 4;
-                if (d < p.D) {
-                    V4 out;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) out[j] = (T)(oacc[dt][g * 4 + j] * inv);
-                    *reinterpret_cast<V4 *>(orow + d) = out;
-                }
-            }
-        }
-    }
+    store_o_block<T, DT>(Op + (long)(qvalid ? qrow : 0) * p.o_sn, oacc, inv, p.D, hi, qvalid, p.o_wide != 0);
     tl_stamp(p, 3);
+    tl_cycles(p, tl_c0);
 }
 
 // ---- folded-reference variant (head dims with D % 16 == 8: SD1.x's d = 40) -----------------------------
@@ -530,7 +516,6 @@ __device__ __forceinline__ void fold_stage2(f32x16 (&oacc)[DT], float &mref, boo
 template <typename T, int KS, int DT, int NW>
 __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false>::value)) attn_fwd_fold_kernel(const AttnParams p) {
     typedef typename Vec<T>::v8 V8;
-    typedef typename Vec<T>::v4 V4;
     typedef KTile<KS> KT;
     typedef VTile<DT> VT;
     constexpr int NSUB = 2;
@@ -673,22 +658,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
         }
     }
     const float inv = 1.f / lsum;
-    if (qvalid) {
-        T *orow = Op + (long)qrow * p.o_sn;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d = dt * 32 + g * 8 + hi * 4;
-                if (d < p.D) {
-                    V4 out;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) out[j] = (T)(oacc[dt][g * 4 + j] * inv);
-                    *reinterpret_cast<V4 *>(orow + d) = out;
-                }
-            }
-        }
-    }
+    store_o_block<T, DT>(Op + (long)(qvalid ? qrow : 0) * p.o_sn, oacc, inv, p.D, hi, qvalid, p.o_wide != 0);
     tl_stamp(p, 3);
 }
 
@@ -849,6 +819,12 @@ template <typename T> static int dispatch_nw(const AttnParams &p, hipStream_t s)
     return wide ? dispatch_d<T, 4, false>(p, s) : dispatch_d<T, 2, false>(p, s);
 }
 
+static int wide_store_mode() {   // PWW_ATTN_WIDE_STORE=0: 8-byte epilogue stores as in round 2 (A/B testing)
+    static int mode = -2;
+    if (mode == -2) { const char *e = getenv("PWW_ATTN_WIDE_STORE"); mode = e ? atoi(e) : 1; }
+    return mode;
+}
+
 static bool aligned16(const void *ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
 
 // Shape / stride / alignment rules shared by every attention entry point.
@@ -912,6 +888,7 @@ void attn_fill_params(AttnParams &p, const void *q, const void *k, const void *v
     p.scale_log2e = d->scale * 1.4426950408889634f;
     p.stats = nullptr; p.stat_kind = PWW_STAT_NONE; p.stat_count = 1.0; p.coeff_scalar = 1.f;
     p.coeff_scalar_dev = nullptr; p.bias_cols = 0; p.timeline = debug_timeline();
+    p.o_wide = (d->o_stride[0] % 8 == 0 && d->o_stride[1] % 8 == 0 && d->o_stride[2] % 8 == 0 && wide_store_mode()) ? 1 : 0;
     p.timeline_wgs = (unsigned)(debug_timeline_bytes() / (TL_SLOTS * sizeof(unsigned long long)));
 }
 

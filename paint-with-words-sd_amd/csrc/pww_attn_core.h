@@ -26,6 +26,7 @@ struct AttnParams {
     const float *coeff_scalar_dev;   // optional device word that REPLACES coeff_scalar (read when the kernel runs: one captured
                                      // hipGraph serves every denoise step, the host rewrites the word before each replay)
     int bias_cols;                   // columns >= bias_cols of the bias map are zero (multiple of 16, <= M rounded up); 0 = unknown
+    int o_wide;                      // 1: rows of O are 16-byte aligned (o strides % 8 == 0): 16-byte epilogue stores
     unsigned long long *timeline;    // debug: per-workgroup phase time stamps (pww_debug_timeline), normally null
     unsigned timeline_wgs;           // workgroups the debug buffer has room for
 };
@@ -37,6 +38,11 @@ __device__ __forceinline__ float coeff_scalar_of(const AttnParams &p) {
 
 // debug time stamps (100 MHz wall clock), [workgroup][TL_SLOTS]
 constexpr int TL_SLOTS = 8;
+// slot 7: shader cycles (s_memtime) between kernel entry and exit of the workgroup's first wave: with the wall-clock stamps it
+// gives the clock the launch actually ran at
+__device__ __forceinline__ void tl_cycles(const AttnParams &p, unsigned long long c0) {
+    if (p.timeline && threadIdx.x == 0 && blockIdx.x < p.timeline_wgs) p.timeline[(long)blockIdx.x * TL_SLOTS + 7] = clock64() - c0;
+}
 __device__ __forceinline__ void tl_stamp(const AttnParams &p, int slot) {
     if (p.timeline && threadIdx.x == 0 && blockIdx.x < p.timeline_wgs) p.timeline[(long)blockIdx.x * TL_SLOTS + slot] = wall_clock64();
 }
@@ -186,6 +192,50 @@ __device__ __forceinline__ float xhalf_max(float x) {
 #else
     return fmaxf(x, __shfl_xor(x, 32));
 #endif
+}
+
+// Epilogue: normalise and write one 32-row block of O. Register r of tile dt is d = dt*32 + (r&3) + 8*(r>>2) + 4*hi of the lane's
+// row: the two half-waves hold ADJACENT 8-byte pieces of the same row. `wide`: pair the column groups (g, g+1) with
+// v_permlane32_swap -- afterwards the lower half holds 16 contiguous bytes at d = 8g, the upper half the next 16 -- and write one
+// 16-byte store per pair instead of two 8-byte ones (the store tail of a row-per-lane epilogue is issue-bound, not bandwidth-bound:
+// cdna_hip_programming.md T21). Needs 16-byte aligned rows (o strides % 8 == 0), else the 8-byte form. All 64 lanes must call
+// (cross-lane exchange); rows that are not valid only skip the store.
+template <typename T, int DT>
+__device__ __forceinline__ void store_o_block(T *orow, const f32x16 (&oacc)[DT], float inv, int D, int hi, bool qvalid, bool wide) {
+    typedef typename Vec<T>::v4 V4;
+    if (wide) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int gp = 0; gp < 4; gp += 2) {
+                if (dt * 32 + gp * 8 < D) {              // wave-uniform: the pair holds at least one stored column group
+                    V4 a, b;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { a[j] = (T)(oacc[dt][gp * 4 + j] * inv); b[j] = (T)(oacc[dt][gp * 4 + 4 + j] * inv); }
+                    const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+                    const auto x = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
+                    const auto y = __builtin_amdgcn_permlane32_swap(ua[1], ub[1], false, false);
+                    const u32x4 out = {x[0], y[0], x[1], y[1]};
+                    const int d = dt * 32 + 8 * (gp + hi);
+                    if (qvalid && d < D) *reinterpret_cast<u32x4 *>(orow + d) = out;
+                }
+            }
+        }
+    } else if (qvalid) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + g * 8 + hi * 4;
+                if (d < D) {
+                    V4 out;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) out[j] = (T)(oacc[dt][g * 4 + j] * inv);
+                    *reinterpret_cast<V4 *>(orow + d) = out;
+                }
+            }
+        }
+    }
 }
 
 // Waves per SIMD the register allocator must leave room for (2 => <= 256 VGPRs+AGPRs). The bias

@@ -135,7 +135,6 @@ __device__ __forceinline__ void tile_park(u32x4 (&reg)[4], bool compact, char *t
 template <typename T, int KS, int DT, int NW, bool SINGLE>
 __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel(const CrossParams cp) {
     typedef typename Vec<T>::v8 V8;
-    typedef typename Vec<T>::v4 V4;
     typedef KTile<KS> KT;
     typedef VTile<DT> VT;
     constexpr int NSUB = 2;
@@ -159,6 +158,7 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     const int hi = lane >> 5, l31 = lane & 31;
     const int BH = p.B * p.H;
     tl_stamp(p, 0);
+    const unsigned long long tl_c0 = p.timeline ? clock64() : 0ull;
     // Workgroup -> (image, head, query chunk). The hardware deals workgroup i to XCD i % 8, and the only bytes two workgroups of this
     // kernel share are the bias rows of a query block (the same [rows, 77] fp32 tile for all H heads of an image). With the plain
     // order (heads fastest) every XCD's L2 ends up fetching the whole map (measured: 11.9 MB fetched per launch for 6.7 MB of
@@ -174,10 +174,12 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     }
     const int b = bh / p.H, h = bh - b * p.H;
 
+    // The row gate is the first global word this workgroup touches (a cold first access costs microseconds): it is REQUESTED here
+    // and looked at after K and V are staged, so the prologue's loads -- Q, K, V, the bias rows -- do not queue up behind it.
+    // Until then everything is decided from the kernel arguments alone (`maybe`: a gated-out image stages its bias rows in vain).
     const float gate = p.bias_coeff ? p.bias_coeff[b] : 1.f;
-    const bool biased = (p.bias != nullptr || cp.compact != nullptr) && gate != 0.f;      // workgroup-uniform
-    const bool need_stat = biased && p.stat_kind != PWW_STAT_NONE;
-    const bool use_tile = biased && cp.tile_stride > 0;
+    const bool maybe_biased = p.bias != nullptr || cp.compact != nullptr;
+    const bool use_tile = maybe_biased && cp.tile_stride > 0;
     const bool use_compact = use_tile && cp.compact != nullptr;
 
     const T *Qp = reinterpret_cast<const T *>(p.q) + b * p.q_sb + h * p.q_sh;
@@ -198,7 +200,7 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     bias.lds_cols = p.bias_cols;
     const float *cbase = nullptr;
     const int *cidx = nullptr;
-    if (biased && !use_compact) {
+    if (maybe_biased && !use_compact) {
         const float *bbase = p.bias + b * p.b_sb + h * p.b_sh;
         const unsigned bytes = (unsigned)((((long)(p.N - 1) * p.b_sn + (long)(p.M - 1) * p.b_sm) + 1) * 4);
         bias.srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bbase), 0, bytes, 0x00020000);
@@ -235,6 +237,8 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     }
     __syncthreads();
     tl_stamp(p, 1);
+    const bool biased = maybe_biased && gate != 0.f;      // workgroup-uniform
+    const bool need_stat = biased && p.stat_kind != PWW_STAT_NONE;
 
     float coeff = 0.f;
     unsigned depart_prev = 0u;     // lane 0 of the workgroup: how many workgroups of the image had left before this one
@@ -399,7 +403,7 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
             const int nrow = ((qb + cp.nchunk) * NW + wave) * 32 + l31;
             load_q_frags<T, KS>(qn, Qp + (long)nrow * p.q_sn, qb + cp.nchunk < cp.nqb && nrow < p.N, hi, p.D);
             // this block's bias rows: requested now, they land under the first sub-tile's score MFMAs
-            if (use_tile) tile_request<NT>(treg, use_compact, cbase, bias.srd, (long)qb * NW * 32, p.N, cp.c_sn, p.b_sn, cp.R, p.bias_cols, tid);
+            if (biased && use_tile) tile_request<NT>(treg, use_compact, cbase, bias.srd, (long)qb * NW * 32, p.N, cp.c_sn, p.b_sn, cp.R, p.bias_cols, tid);
         }
         if (biased && !use_tile) bias.row_off = qvalid ? (unsigned)((long)qrow * p.b_sn * 4) : OOB_OFF;
         f32x16 oacc[DT];
@@ -408,7 +412,7 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;
-        if (use_tile) {
+        if (biased && use_tile) {
             f32x16 s0[2];
             score_tile<T, KS>(s0, qf, smem, 0, p.M, l31, hi);
             if constexpr (!SINGLE) {
@@ -434,22 +438,7 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
         }
         const float l_tot = l_run + __shfl_xor(l_run, 32);
         const float inv = 1.f / l_tot;
-        if (qvalid) {
-            T *orow = Op + (long)qrow * p.o_sn;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d = dt * 32 + g * 8 + hi * 4;
-                    if (d < p.D) {
-                        V4 out;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) out[j] = (T)(oacc[dt][g * 4 + j] * inv);
-                        *reinterpret_cast<V4 *>(orow + d) = out;
-                    }
-                }
-            }
-        }
+        store_o_block<T, DT>(Op + (long)(qvalid ? qrow : 0) * p.o_sn, oacc, inv, p.D, hi, qvalid, p.o_wide != 0);
         if constexpr (!SINGLE) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
@@ -479,6 +468,7 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
         }
     }
     tl_stamp(p, 5);
+    tl_cycles(p, tl_c0);
 }
 
 // ---- host side -------------------------------------------------------------------------------
@@ -643,8 +633,11 @@ int cross_attn_fused(const void *q, const void *k, const void *v, void *o, const
     cp.slots = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(state) + state_sync_bytes(d));
     cp.stats_out = stats_out;
     cp.nqb = cp.nchunk = 0;
-    // the LDS tile needs unit key stride (dense form) or the compact form; PWW_CROSS_BIAS_LDS=0 keeps the per-lane loads (dense only)
-    const bool tile_ok = compact || (d->bias_stride[3] == 1 && bias_tile_mode() == 1);
+    // The LDS tile needs unit key stride (dense form) or the compact form, and it pays when the map is NARROW: measured (MI355X,
+    // N = 4096, d = 40) 16 folded rows 73.6 us with a 32-column tile vs 81.8 us with per-lane loads, but 126 us with all 80 columns
+    // staged (82 KB of LDS: one workgroup per CU, two slabs fetched without prefetch) -- so a dense map without a column bound of
+    // at most 48 keeps the per-lane loads. PWW_CROSS_BIAS_LDS=0: per-lane loads always (A/B), =2: tile whatever the width.
+    const bool tile_ok = compact || (d->bias_stride[3] == 1 && (bias_tile_mode() == 2 || (bias_tile_mode() == 1 && bias_cols <= 48)));
     cp.tile_stride = tile_ok ? bias_cols + 4 : 0;
     cp.compact = compact ? op.bias_compact : nullptr;
     cp.col_idx = op.col_idx; cp.R = op.R;

@@ -46,7 +46,15 @@ template <typename F> static void timeline_report(const char *name, const char *
     unsigned long long t0 = ~0ull; size_t n = 0;
     for (size_t w = 0; w < wgs; ++w) if (h[w * 8]) { t0 = std::min(t0, h[w * 8]); n = w + 1; }
     printf("TIMELINE %-28s %s: %zu workgroups; us since the first workgroup's entry, per stamp [n mean min max]\n", name, what, n);
-    for (int sl = 0; sl < 8; ++sl) {
+    {   // slot 7 = shader cycles between entry and exit of the workgroup: cycles / wall time = the clock the launch ran at
+        double mhz = 0; long cnt = 0;
+        for (size_t w = 0; w < n; ++w) {
+            unsigned long long last = 0; for (int sl = 1; sl < 7; ++sl) last = std::max(last, h[w * 8 + sl]);
+            if (h[w * 8 + 7] && last > h[w * 8]) { mhz += (double)h[w * 8 + 7] / ((double)(last - h[w * 8]) * 0.01); ++cnt; }
+        }
+        if (cnt) printf("TIMELINE %-28s   shader clock over the workgroups' lifetimes: %.0f MHz\n", name, mhz / cnt);
+    }
+    for (int sl = 0; sl < 7; ++sl) {
         double sum = 0, mn = 1e30, mx = 0; long cnt = 0;
         for (size_t w = 0; w < n; ++w) if (h[w * 8 + sl]) { const double us = (double)(h[w * 8 + sl] - t0) * 0.01; sum += us; mn = std::min(mn, us); mx = std::max(mx, us); ++cnt; }
         if (cnt) printf("TIMELINE %-28s   stamp %d: n=%ld mean %.2f min %.2f max %.2f\n", name, sl, cnt, sum / cnt, mn, mx);
@@ -63,6 +71,7 @@ struct Case {
     float late_outlier = 0.f;   // != 0: key row M - 5 of every image is multiplied by this (scores far above everything seen before)
     int bias_cols = 0;          // bias_mode 1: columns >= bias_cols of the map are zero and the *_ex call says so (0 = every column may be non-zero)
     int compact_R = 0;          // bias_mode 1: only compact_R columns (< bias_cols) are non-zero; the *_ex call also gets the compact form
+    bool on_request = false;    // profiling shapes (large batches): only run with --only / --match
 };
 
 template <typename T> static T *dalloc(size_t n) { T *p; HIPCHECK(hipMalloc(&p, n * sizeof(T) + 64)); return p; }
@@ -525,6 +534,10 @@ int main(int argc, char **argv) {
         {"sd15_cross_fullbias_n4096", PWW_DTYPE_F16, 1, 8, 4096, 77, 40, 2, false, 97, 1.0f},
         {"sd21_self_n2304_d64", PWW_DTYPE_BF16, 1, 10, 2304, 2304, 64, 0, true, 61, 0.8f},
         {"sd21_self_n9216_d64_b4", PWW_DTYPE_BF16, 4, 5, 9216, 9216, 64, 0, true, 1531, 0.8f},   // BASELINE config 5: 768x768, 2 images folded
+        // the dominant launches of BASELINE configs 3 / 4 / 5 at the batch sizes bench.py runs them (profiling: tools/gpu_profile.sh)
+        {"sd15_self_n4096_d40_f16_b16", PWW_DTYPE_F16, 16, 8, 4096, 4096, 40, 0, true, 2039, 1.0f, 0.f, 0, 0, true},
+        {"sd15_self_n4096_d40_bf16_b16", PWW_DTYPE_BF16, 16, 8, 4096, 4096, 40, 0, true, 2039, 1.0f, 0.f, 0, 0, true},
+        {"sd21_self_n9216_d64_b8", PWW_DTYPE_BF16, 8, 5, 9216, 9216, 64, 0, true, 4603, 0.8f, 0.f, 0, 0, true},
         {"d96_n200_m130", PWW_DTYPE_F16, 1, 2, 200, 130, 96, 2, false, 1, 0.6f},
         {"d128_n130_m200", PWW_DTYPE_BF16, 1, 2, 130, 200, 128, 0, false, 1, 0.6f},
         {"d48_n33_m1", PWW_DTYPE_F16, 1, 1, 33, 1, 48, 0, false, 1, 1.0f},
@@ -567,6 +580,7 @@ int main(int argc, char **argv) {
     for (auto &c : cases) {
         const bool big = (long)c.N * c.M >= 1024L * 1024L || c.N >= 4096;
         if (quick && big) continue;
+        if (c.on_request && !only && !match) continue;
         if (only && strcmp(only, c.name)) continue;
         if (match && !strstr(c.name, match)) continue;
         run_case(c, big || c.bias_mode == 1);

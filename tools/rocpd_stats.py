@@ -1,5 +1,5 @@
 """Summarise a rocprofv3 rocpd sqlite database (kernel-trace) into a per-kernel stats table (markdown).
-Usage: python tools/rocpd_stats.py <results.db> [--top N] [--grid] [--split-b2b <kernel name substring>]
+Usage: python tools/rocpd_stats.py <results.db> [--top N] [--grid] [--match <substring>] [--split-b2b <kernel name substring>]
 --split-b2b: for one kernel, average duration of the launches that directly follow another launch of the SAME kernel
 (bench.py's roofline pass: 40 launches replayed back to back) and of all others (the launches inside the UNet workload)."""
 import sqlite3
@@ -19,6 +19,9 @@ def main():
     print("total kernel time: %.3f ms over %d dispatches, %d distinct kernels" % (total / 1e6, sum(r[1] for r in rows), len(rows)))
     print("| % | total ms | calls | avg us | min us | max us | vgpr | agpr | lds | grid | wg | kernel |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+    match = sys.argv[sys.argv.index("--match") + 1] if "--match" in sys.argv else None      # only kernels whose name contains this
+    if match:
+        rows = [r for r in rows if match in r[0]]
     for r in rows[:top]:
         name = r[0] if len(r[0]) < 110 else r[0][:107] + "..."
         grid = str(r[9]) if r[9] == r[10] else "%d-%d" % (r[9], r[10])
