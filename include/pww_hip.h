@@ -284,6 +284,14 @@ int pww_inpaint_prep(const uint8_t *rgb, const uint8_t *mask, int32_t H, int32_t
 int pww_cfg_combine(const void *cond, const void *uncond, float guidance, float *out,
                     int64_t n, int32_t dtype, void *stream);
 
+/*
+ * dst[i] = values[i], i < n <= 64: `values` is a HOST array that is copied into the kernel arguments at the call, so the
+ * store is an ordinary asynchronous launch on `stream` -- no pinned staging buffer to keep alive, no synchronous copy. This is
+ * how the per-step scalars c0 * g(sigma_i) of the weight function (paint_with_words.py:479-482) reach the device words that
+ * pww_cross_opts_t.coeff_scalar_dev names, between two replays of the captured UNet graph.
+ */
+int pww_store_f32(float *dst, const float *values, int32_t n, void *stream);
+
 /* Device workspace pww_qk_reduce needs from the caller for this problem (the attention entry points
    need none). */
 size_t pww_workspace_bytes(const pww_attn_desc_t *desc);

@@ -143,6 +143,7 @@ int gauss_blur(const float *in, float *out, int H, int W, const float *weights, 
 int inpaint_prep(const uint8_t *rgb, const uint8_t *mask, int H, int W, int h, int w, float *mask_out, float *masked,
                  float *mask_lat, hipStream_t stream);
 int cfg_combine(const void *cond, const void *uncond, float g, float *out, long n, int dtype, hipStream_t stream);
+int store_f32(float *dst, const float *values, int n, hipStream_t stream);
 
 }  // namespace pww
 
@@ -255,6 +256,8 @@ int pww_cfg_combine(const void *cond, const void *uncond, float guidance, float 
                     void *stream) {
     return pww::cfg_combine(cond, uncond, guidance, out, (long)n, dtype, static_cast<hipStream_t>(stream));
 }
+
+int pww_store_f32(float *dst, const float *values, int32_t n, void *stream) { return pww::store_f32(dst, values, n, static_cast<hipStream_t>(stream)); }
 
 size_t pww_workspace_bytes(const pww_attn_desc_t *desc) { return pww::qk_reduce_workspace_bytes(desc); }
 

@@ -263,4 +263,19 @@ int cfg_combine(const void *cond, const void *uncond, float g, float *out, long 
     return check_hip(hipGetLastError(), "cfg_combine_kernel launch");
 }
 
+// ---- pww_store_f32: up to 64 host floats, carried in the kernel arguments, written to device words
+struct StoreArgs { float v[64]; float *dst; int n; };
+__global__ void store_f32_kernel(const StoreArgs a) {
+    if ((int)threadIdx.x < a.n) a.dst[threadIdx.x] = a.v[threadIdx.x];
+}
+int store_f32(float *dst, const float *values, int n, hipStream_t stream) {
+    if (!dst || !values || n < 1 || n > 64) { set_error("pww_store_f32: need 1 <= n <= 64 values and a destination (n = %d)", n); return PWW_EINVAL; }
+    if (!arch_ok()) return PWW_ENOTSUP;
+    StoreArgs a;
+    for (int i = 0; i < 64; ++i) a.v[i] = i < n ? values[i] : 0.f;
+    a.dst = dst; a.n = n;
+    hipLaunchKernelGGL(store_f32_kernel, dim3(1), dim3(64), 0, stream, a);
+    return check_hip(hipGetLastError(), "store_f32_kernel launch");
+}
+
 }  // namespace pww

@@ -17,7 +17,7 @@ MAX_HEAD_DIM = 160
 EXPORTS = ("pww_version", "pww_last_error", "pww_device_arch", "pww_self_attn_fwd", "pww_cross_attn_fwd",
            "pww_cross_attn_fwd_stat", "pww_cross_attn_fwd_fused", "pww_cross_attn_fwd_stat_ex", "pww_cross_attn_fwd_fused_ex",
            "pww_cross_fused_workspace_bytes", "pww_cross_fused_state_bytes",
-           "pww_qk_reduce", "pww_mask_build", "pww_mask_build_rgb", "pww_mask_build_f32", "pww_resize_tokens", "pww_gauss_blur", "pww_inpaint_prep", "pww_cfg_combine",
+           "pww_qk_reduce", "pww_mask_build", "pww_mask_build_rgb", "pww_mask_build_f32", "pww_resize_tokens", "pww_gauss_blur", "pww_inpaint_prep", "pww_cfg_combine", "pww_store_f32",
            "pww_workspace_bytes", "pww_profile_arm", "pww_profile_elapsed_us", "pww_profile_reset", "pww_debug_timeline")
 
 
@@ -87,6 +87,8 @@ def load():
     lib.pww_gauss_blur.argtypes = [vp, vp, i32, i32, vp, i32, vp, vp]
     lib.pww_inpaint_prep.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     lib.pww_cfg_combine.argtypes = [vp, vp, f32, vp, i64, i32, vp]
+    lib.pww_store_f32.argtypes = [vp, ctypes.POINTER(ctypes.c_float), i32, vp]
+    lib.pww_store_f32.restype = ctypes.c_int
     lib.pww_workspace_bytes.argtypes = [ctypes.POINTER(AttnDesc)]
     lib.pww_workspace_bytes.restype = ctypes.c_size_t
     lib.pww_profile_arm.argtypes = []

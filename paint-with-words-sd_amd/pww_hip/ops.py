@@ -379,6 +379,18 @@ def inpaint_prep(rgb, mask, lat_h, lat_w):
     return m, masked, ml
 
 
+def store_f32(dst, values):
+    """dst[:len(values)] = values (Python floats, at most 64) as ONE asynchronous launch on the current stream: the values ride
+    in the kernel arguments -- no host staging buffer that a later call could overwrite, no synchronous copy."""
+    _require_gpu(dst)
+    n = len(values)
+    if dst.dtype != torch.float32 or not dst.is_contiguous() or dst.numel() < n:
+        raise PwwHipError("store_f32 needs a contiguous float32 device tensor with room for %d values" % n)
+    arr = (ctypes.c_float * n)(*[float(v) for v in values])
+    with torch.cuda.device(dst.device):
+        _lib.check(_lib.load().pww_store_f32(_ptr(dst), arr, n, _stream()), "pww_store_f32")
+
+
 def cfg_combine(cond, uncond, guidance_scale):
     """uncond + g * (cond - uncond) in fp32 (returns fp32)."""
     _require_gpu(cond, uncond)
