@@ -281,7 +281,8 @@ def measured_traffic(n_tok, d, b_rows, dtype, live=False):
         if not os.path.isfile(path):
             continue
         recs = json.load(open(path))
-        for rec in (recs if isinstance(recs, list) else [recs]):
+        recs = recs.get("records", [recs]) if isinstance(recs, dict) else recs
+        for rec in recs:
             if (rec.get("N"), rec.get("D"), rec.get("B"), rec.get("dtype")) == (n_tok, d, b_rows, dtype) and rec.get("kind", "self") == "self":
                 return int(rec["hbm_bytes_per_launch"])
     return None
@@ -577,6 +578,8 @@ def main():
     pdist.barrier(device)
     torch.cuda.synchronize()
     elapsed = pdist.max_over_ranks(time.perf_counter() - t0, device)
+    for smp in getattr(unet, "_pww_samplers", {}).values():
+        smp.check_errors()            # fused hand-off time-outs of any timed request (raises; the requests are complete: synchronised above)
     assert torch.isfinite(lat).all(), "non-finite latents"
     log("timed region done: %.3f s for %d steps" % (elapsed, args.steps))
     images = args.steps * n_global

@@ -107,8 +107,8 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
     const int lane = tid & 63, wave = tid >> 6;
     const int rg = KG > 1 ? wave % NW : wave, kg = KG > 1 ? wave / NW : 0;
     const int hi = lane >> 5, l31 = lane & 31;
-    const int BH = p.B * p.H;
-    const int bh = blockIdx.x % BH, qb = blockIdx.x / BH;
+    int bh, qb;
+    wg_to_pair_block(p, (p.N + NW * 32 - 1) / (NW * 32), bh, qb);
     const int b = bh / p.H, h = bh - b * p.H;
 
     const T *Qp = reinterpret_cast<const T *>(p.q) + b * p.q_sb + h * p.q_sh;
@@ -531,8 +531,8 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
-    const int BH = p.B * p.H;
-    const int bh = blockIdx.x % BH, qb = blockIdx.x / BH;
+    int bh, qb;
+    wg_to_pair_block(p, (p.N + NW * 32 - 1) / (NW * 32), bh, qb);
     const int b = bh / p.H, h = bh - b * p.H;
 
     const T *Qp = reinterpret_cast<const T *>(p.q) + b * p.q_sb + h * p.q_sh;
@@ -819,6 +819,12 @@ template <typename T> static int dispatch_nw(const AttnParams &p, hipStream_t s)
     return wide ? dispatch_d<T, 4, false>(p, s) : dispatch_d<T, 2, false>(p, s);
 }
 
+static int pair_major_min() {   // PWW_ATTN_PAIR_MAJOR=n: pair-major workgroup order for launches with at least n (image, head) pairs (0 = never)
+    static int n = -2;
+    if (n == -2) { const char *e = getenv("PWW_ATTN_PAIR_MAJOR"); n = e ? atoi(e) : 0; if (n <= 0) n = 0x7fffffff; }
+    return n;
+}
+
 static int wide_store_mode() {   // PWW_ATTN_WIDE_STORE=0: 8-byte epilogue stores as in round 2 (A/B testing)
     static int mode = -2;
     if (mode == -2) { const char *e = getenv("PWW_ATTN_WIDE_STORE"); mode = e ? atoi(e) : 1; }
@@ -888,6 +894,7 @@ void attn_fill_params(AttnParams &p, const void *q, const void *k, const void *v
     p.scale_log2e = d->scale * 1.4426950408889634f;
     p.stats = nullptr; p.stat_kind = PWW_STAT_NONE; p.stat_count = 1.0; p.coeff_scalar = 1.f;
     p.coeff_scalar_dev = nullptr; p.bias_cols = 0; p.timeline = debug_timeline();
+    p.pair_major = ((d->B * d->H) % 8 == 0 && d->B * d->H >= pair_major_min() && !bias) ? 1 : 0;
     p.o_wide = (d->o_stride[0] % 8 == 0 && d->o_stride[1] % 8 == 0 && d->o_stride[2] % 8 == 0 && wide_store_mode()) ? 1 : 0;
     p.timeline_wgs = (unsigned)(debug_timeline_bytes() / (TL_SLOTS * sizeof(unsigned long long)));
 }

@@ -27,6 +27,7 @@ struct AttnParams {
                                      // hipGraph serves every denoise step, the host rewrites the word before each replay)
     int bias_cols;                   // columns >= bias_cols of the bias map are zero (multiple of 16, <= M rounded up); 0 = unknown
     int o_wide;                      // 1: rows of O are 16-byte aligned (o strides % 8 == 0): 16-byte epilogue stores
+    int pair_major;                  // 1: workgroups of one (image, head) pair run on ONE XCD, pairs dealt round-robin to the XCDs
     unsigned long long *timeline;    // debug: per-workgroup phase time stamps (pww_debug_timeline), normally null
     unsigned timeline_wgs;           // workgroups the debug buffer has room for
 };
@@ -34,6 +35,24 @@ struct AttnParams {
 // the Python scalar c0 * g(sigma) of the weight function: baked into the launch, or read from a device word
 __device__ __forceinline__ float coeff_scalar_of(const AttnParams &p) {
     return p.coeff_scalar_dev ? *p.coeff_scalar_dev : p.coeff_scalar;
+}
+
+// Workgroup -> ((image, head) pair, query block). Default: pairs fastest -- consecutive workgroups (= consecutive XCDs) work on
+// different pairs, every pair's query blocks are spread over all XCDs and each XCD's L2 streams the K/V of every pair it meets.
+// That is fine while all pairs' K/V fit the L2s together (B = 2: 10.5 MB, traffic 1.2x algorithmic); with 128 pairs (16 folded
+// rows) each XCD runs 32 workgroups of 16 different pairs at a time and re-fetches 655 KB of K/V per pair and query block from the
+// Infinity Cache (5.4x algorithmic, profiles/r03_traffic.json). pair_major: XCD x (= blockIdx & 7) takes the pairs x, x + 8, ...
+// one after the other, all query blocks of a pair together -- a pair's K/V is fetched into one L2 once.
+__device__ __forceinline__ void wg_to_pair_block(const AttnParams &p, int nqb, int &bh, int &qb) {
+    const int BH = p.B * p.H;
+    if (p.pair_major) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        qb = j % nqb;
+        bh = (j / nqb) * 8 + xcd;
+    } else {
+        bh = blockIdx.x % BH;
+        qb = blockIdx.x / BH;
+    }
 }
 
 // debug time stamps (100 MHz wall clock), [workgroup][TL_SLOTS]

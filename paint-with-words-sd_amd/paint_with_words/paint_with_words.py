@@ -176,7 +176,9 @@ def paint_with_words(
                         init_images=None if init_image is None else [init_image], strength=strength, shared=True)
     if return_latents:
         return latents
-    return _pil_from_latents(tools[0], latents)[0]
+    image = _pil_from_latents(tools[0], latents)[0]
+    _sampler_for(tools[1], tools[4], DEFAULT_MODE).check_errors()     # (the decode above synchronised already)
+    return image
 
 
 @torch.no_grad()
@@ -231,7 +233,9 @@ def paint_with_words_batch(
             _extract_seed_and_sigma_from_context(c)
     if return_latents:
         return latents
-    return _pil_from_latents(tools[0], latents)
+    images = _pil_from_latents(tools[0], latents)
+    _sampler_for(tools[1], tools[4], DEFAULT_MODE).check_errors()
+    return images
 
 
 def __getattr__(name):

@@ -189,7 +189,9 @@ def paint_with_words_inpaint(
                                 strength, shared=True)
     if return_latents:
         return latents
-    return _pil_from_latents(tools[0], latents)[0]
+    image = _pil_from_latents(tools[0], latents)[0]
+    _sampler_for(tools[1], tools[4], _mode()).check_errors()
+    return image
 
 
 @torch.no_grad()
@@ -235,7 +237,9 @@ def paint_with_words_inpaint_batch(
                                 weight_function, unconditional_input_prompt, strength, shared=s1 and s2 and s3)
     if return_latents:
         return latents
-    return _pil_from_latents(tools[0], latents)
+    images = _pil_from_latents(tools[0], latents)
+    _sampler_for(tools[1], tools[4], _mode()).check_errors()
+    return images
 
 
 def __getattr__(name):

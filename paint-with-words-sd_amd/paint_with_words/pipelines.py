@@ -24,7 +24,9 @@ import torch
 from PIL import Image
 
 import pww_hip
-from .paint_with_words import (pww_load_tools, LMSDiscreteScheduler, _generate, _pil_from_latents)
+import importlib
+_pw = importlib.import_module(__name__.rsplit(".", 1)[0] + ".paint_with_words")
+from .paint_with_words import (pww_load_tools, LMSDiscreteScheduler, _generate, _pil_from_latents, _sampler_for)
 from . import paint_with_words_inpaint as _inp
 
 _warned = set()
@@ -142,6 +144,7 @@ class PaintWithWord_StableDiffusionPipeline:
                         strength=eta, latent_hw=(height, width), use_region_sigma=False, shared=True,
                         on_step=self._callback_adapter(callback, callback_steps))
         images = _decode(self.vae, lat, output_type)
+        _sampler_for(self.unet, self.scheduler, _pw.DEFAULT_MODE).check_errors()
         if not return_dict:
             return (images, False)
         return SimpleNamespace(images=images, nsfw_content_detected=False)
@@ -194,6 +197,7 @@ class PaintWithWord_StableDiffusionInpaintPipeline(PaintWithWord_StableDiffusion
                                      on_step=self._callback_adapter(callback, callback_steps), mask_hw=(height, width), resize_inputs=False,
                                      use_region_sigma=False)
         images = _decode(self.vae, lat, output_type)
+        _sampler_for(self.unet, self.scheduler, _pw.DEFAULT_MODE).check_errors()
         if not return_dict:
             return (images, False)
         return SimpleNamespace(images=images, nsfw_content_detected=False)

@@ -117,6 +117,50 @@ class FusedScratch:
                 t.zero_()
 
 
+class FusedErrorWatch:
+    """check_fused_errors without stopping the host: after a request's last launch the error words of all layers are reduced on the
+    device and copied to a pinned host flag behind an event (`post`); `poll` looks at the flags whose event has completed -- or
+    waits for all of them -- and raises like check_fused_errors. The sampler posts at the end of every request and polls at the
+    start of the next one, the PIL-returning entry points poll with wait=True after the decode they synchronise on anyway: the
+    host keeps running ahead of the GPU between requests (a synchronous check after every image costs ~3 % images/s at batch 1:
+    the next request's conditioning would start only when the GPU is idle)."""
+
+    def __init__(self):
+        self.pending = []
+
+    def post(self, modules):
+        scratches = [m.__dict__["_pww_fused_scratch"] for m in modules if "_pww_fused_scratch" in getattr(m, "__dict__", {})]
+        words = [w for w in (s.error_word() for s in scratches) if w is not None]
+        if not words:
+            return
+        flag = torch.stack(words).ne(0).any().to(torch.int32)
+        host = torch.empty((), dtype=torch.int32).pin_memory()
+        host.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending.append((ev, host, scratches))
+
+    def poll(self, wait=False):
+        while self.pending:
+            ev, host, scratches = self.pending[0]
+            if wait:
+                ev.synchronize()
+            elif not ev.query():
+                return
+            self.pending.pop(0)
+            if int(host.item()) != 0:
+                torch.cuda.synchronize()
+                for s in scratches:
+                    s.reset()
+                self.pending.clear()
+                raise PwwHipError(_TIMEOUT_MESSAGE)
+
+
+_TIMEOUT_MESSAGE = ("a fused cross-attention launch timed out waiting for its own workgroups (the GPU is shared with another process or "
+                    "stream?); its outputs are NaN and were discarded. State re-zeroed. Set PWW_FUSED_CROSS=0 to use the two-launch "
+                    "path on a shared device.")
+
+
 def check_fused_errors(modules):
     """One device -> host read for a whole request: raise PwwHipError if any fused cross-attention launch of the given
     modules' scratch buffers timed out in its hand-off (the launch needs every workgroup resident at once: another process or
@@ -130,9 +174,7 @@ def check_fused_errors(modules):
         torch.cuda.synchronize()
         for s in scratches:
             s.reset()
-        raise PwwHipError("a fused cross-attention launch timed out waiting for its own workgroups (the GPU is shared with another "
-                          "process or stream?); its outputs are NaN and were discarded. State re-zeroed. Set PWW_FUSED_CROSS=0 to "
-                          "use the two-launch path on a shared device.")
+        raise PwwHipError(_TIMEOUT_MESSAGE)
 
 
 def _cross_opts(B, N, coeff_dev, bias_cols, compact, keep):

@@ -225,6 +225,7 @@ class PwWSampler:
         self._fallback_sig = None
         self._static_folded = None
         self._scratch_modules = None
+        self._errors = ops.FusedErrorWatch()
 
     def _static_context(self, folded, weight_function, latents, timesteps):
         """Captured graphs read the context tensors by ADDRESS: keep one set of static tensors alive and copy each new
@@ -270,6 +271,7 @@ class PwWSampler:
         latents: [n_images, C, h, w] already scaled by init_noise_sigma (or noised for img2img).
         extra_channels: inpaint's cat([mask, masked_image_latents]) ([n or 1, 5, h, w]) or None."""
         sch, unet, dev = self.scheduler, self.unet, latents.device
+        self._errors.poll(wait=False)      # a hand-off time-out of an earlier request surfaces here (or in check_errors())
         install(unet)      # the plug is a class-level patch (:193-195): put it back if somebody removed it since __init__
         n = latents.shape[0]
         udt = unet.dtype if hasattr(unet, "dtype") else next(unet.parameters()).dtype
@@ -317,8 +319,15 @@ class PwWSampler:
             latents = sch.step(noise_pred, t, latents).prev_sample
             if on_step is not None:
                 on_step(i, t, latents)
-        # one 4-byte device -> host read per request: did any fused cross-attention launch time out in its hand-off?
+        # did any fused cross-attention launch of this request time out in its hand-off? One 4-byte device -> host copy behind an
+        # event (ops.FusedErrorWatch): looked at when the next request starts and by check_errors() -- never a host stall here
         if self._scratch_modules is None:
             self._scratch_modules = [m for m in unet.modules() if m.__class__.__name__ in ("CrossAttention", "Attention")]
-        ops.check_fused_errors(self._scratch_modules)
+        self._errors.post(self._scratch_modules)
         return latents
+
+    def check_errors(self):
+        """Wait for the requests issued so far and raise PwwHipError if a fused cross-attention hand-off of any of them timed out
+        (their outputs are NaN). The PIL-returning entry points call this after decoding; callers that take latents
+        (`return_latents=True`) call it when they synchronise."""
+        self._errors.poll(wait=True)

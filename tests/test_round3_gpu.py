@@ -267,22 +267,31 @@ print("state clean:", not m.__dict__["_pww_fused_scratch"].error())
 
 
 def test_sampler_raises_on_a_set_error_word(gpu_device):
-    """PwWSampler.sample checks the error words of every attention layer after the loop (one device -> host read)."""
+    """PwWSampler posts the error words of every attention layer after the loop (one device -> host copy behind an event) and
+    raises when they are looked at: in the PIL-returning entry points right after the decode, for `return_latents=True` callers at
+    the start of the next request or in sampler.check_errors() -- never by stalling the host between requests."""
     import paint_with_words as pw
     from pww_hip._lib import PwwHipError
     tools = cases.build_tools("tiny", dtype=torch.float16, device=gpu_device)
     kw = dict(color_map_image=Image.fromarray(cases.load_example_rgb()), input_prompt=cases.RUNNER_PROMPT, num_inference_steps=2,
-              guidance_scale=7.5, seed=0, device=str(gpu_device), weight_function=cases.weight_fn_runner, preloaded_utils=tools, return_latents=True)
+              guidance_scale=7.5, seed=0, device=str(gpu_device), weight_function=cases.weight_fn_runner, preloaded_utils=tools)
     try:
         with _mode("folded"):
-            pw.paint_with_words(color_context=dict(cases.RUNNER_CONTEXT), **kw)
+            pw.paint_with_words(color_context=dict(cases.RUNNER_CONTEXT), return_latents=True, **kw)
+            sampler = tools[1]._pww_samplers[(id(tools[4]), "folded")]
+            sampler.check_errors()
             scr = [m.__dict__["_pww_fused_scratch"] for m in tools[1].modules() if "_pww_fused_scratch" in m.__dict__]
             assert len(scr) >= 3
             scr[1].state.view(torch.int32)[scr[1]._err_index] = 1
+            pw.paint_with_words(color_context=dict(cases.RUNNER_CONTEXT), return_latents=True, **kw)      # latents: nobody waited yet
             with pytest.raises(PwwHipError):
+                sampler.check_errors()
+            assert not any(s.error() for s in scr)
+            scr[2].state.view(torch.int32)[scr[2]._err_index] = 1
+            with pytest.raises(PwwHipError):                                                                # PIL result: checked after the decode
                 pw.paint_with_words(color_context=dict(cases.RUNNER_CONTEXT), **kw)
             assert not any(s.error() for s in scr)
-            pw.paint_with_words(color_context=dict(cases.RUNNER_CONTEXT), **kw)       # clean again
+            assert isinstance(pw.paint_with_words(color_context=dict(cases.RUNNER_CONTEXT), **kw), Image.Image)     # clean again
     finally:
         uninstall_all()
 
