@@ -819,9 +819,9 @@ template <typename T> static int dispatch_nw(const AttnParams &p, hipStream_t s)
     return wide ? dispatch_d<T, 4, false>(p, s) : dispatch_d<T, 2, false>(p, s);
 }
 
-static int pair_major_min() {   // PWW_ATTN_PAIR_MAJOR=n: pair-major workgroup order for launches with at least n (image, head) pairs (0 = never)
+static int pair_major_min() {   // PWW_ATTN_PAIR_MAJOR=n: pair-major workgroup order for launches with at least n (image, head) pairs (0 = never; default 16)
     static int n = -2;
-    if (n == -2) { const char *e = getenv("PWW_ATTN_PAIR_MAJOR"); n = e ? atoi(e) : 0; if (n <= 0) n = 0x7fffffff; }
+    if (n == -2) { const char *e = getenv("PWW_ATTN_PAIR_MAJOR"); n = e ? atoi(e) : 16; if (n <= 0) n = 0x7fffffff; }
     return n;
 }
 
