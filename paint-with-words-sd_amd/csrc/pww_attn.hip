@@ -29,6 +29,7 @@ namespace pww {
 // the K tile contribute nothing.
 template <typename T> struct RangeFree { static constexpr bool value = false; };
 template <> struct RangeFree<bf16> { static constexpr bool value = true; };
+template <> struct RangeFree<f16> { static constexpr bool value = true; };     // round 3: without headroom (RfHeadroom<f16>), diagonal stage first
 
 template <typename T, int KS, int DT, int NSUB, bool ROWSUM_MFMA, int KPT, int VPT, typename SRD>
 __device__ __forceinline__ void exact_rows(f32x16 (&oacc)[DT], float &l_run, const AttnParams &p, const T *qrow_ptr, bool qvalid, char *smem,
@@ -89,7 +90,7 @@ __device__ __forceinline__ void exact_rows(f32x16 (&oacc)[DT], float &l_run, con
 // one range check at the end, exact_rows as the fallback.
 template <typename T, int KS, int DT, int NW, int NSUB, int KG, bool HAS_BIAS, bool ROWSUM_MFMA, bool RF = false>
 __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, HAS_BIAS>::value)) attn_fwd_kernel(const AttnParams p) {
-    static_assert(!RF || (KG == 1 && !HAS_BIAS && RangeFree<T>::value), "range-free mode: bf16, no bias, no key split");
+    static_assert(!RF || (KG == 1 && !HAS_BIAS && RangeFree<T>::value), "range-free mode: no bias, no key split");
     typedef typename Vec<T>::v8 V8;
     typedef KTile<KS> KT;
     typedef VTile<DT> VT;
@@ -165,11 +166,13 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
     u32x4 vreg[VPT];
     const int nstage = (p.M + STAGE_KEYS - 1) / STAGE_KEYS;
     const int nfull = p.M / STAGE_KEYS;                 // stages without any key >= M
+    // self-attention: the diagonal stage first (stage_at); step i of the loop works on key stage stage_at(i, st0, nfull)
+    const int st0 = (KG == 1 && !HAS_BIAS && p.M == p.N && nfull > 1) ? min((qb * NW * 32) / STAGE_KEYS, nfull - 1) : 0;   // (a bias is addressed by key position: natural order)
 
-    // prologue: stage 0 -> buffer 0, stage 1 -> registers
-    stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);
+    // prologue: first stage -> buffer 0, second stage -> registers
+    stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(0, st0, nfull) * k_step, (unsigned)stage_at(0, st0, nfull) * v_step);
     stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
-    if (nstage > 1) stage_load(kreg, vreg, plan, srd_k, srd_v, k_step, v_step);
+    if (nstage > 1) stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(1, st0, nfull) * k_step, (unsigned)stage_at(1, st0, nfull) * v_step);
     __syncthreads();
     tl_stamp(p, 1);
 
@@ -180,7 +183,7 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
         // registers hold stage st+1: park it in the other buffer (its readers finished before the last
         // barrier), then re-use the registers for stage st+2, whose loads fly during this stage's compute
         if (st + 1 < nstage) stage_store<DT, KPT, VPT>(kreg, vreg, plan, nxt);
-        if (st + 2 < nstage) stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
+        if (st + 2 < nstage) stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(st + 2, st0, nfull) * k_step, (unsigned)stage_at(st + 2, st0, nfull) * v_step);
         if constexpr (KG > 1) {
             attn_tile<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + kg * SUB_BYTES,
                                                                cur + kg * SUB_BYTES + KT::BYTES, st * STAGE_KEYS + kg * KVBLK,
@@ -316,7 +319,6 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
 //     checked at the end and a workgroup that sees a non-finite (or zero) sum recomputes its rows with the exact online
 //     softmax (exact_rows above): always correct, fast for every input whose logits span less than e^83.
 constexpr float FOLD_TAU = 6.f;
-constexpr float FOLD_HEADROOM = 8.f;
 
 // MAGNITUDE GUARD. The one approximation of this variant is the extra rounding of Q * scale * log2(e) to T: a relative error of
 // 2^-9 (bf16) / 2^-12 (f16) on every term of a score, i.e. an absolute logit error that grows LINEARLY with the magnitude of the
@@ -417,7 +419,7 @@ __device__ __forceinline__ void fold_tile(f32x16 (&oacc)[DT], float &mref, bool 
             for (int r = 0; r < 16; ++r) s[0][kb][r] = key0 + key_of(kb, r, hi) < M ? s[0][kb][r] : -INFINITY;
     }
     if constexpr (RangeFree<T>::value) {
-        if (first) fold_rereference<T, KS, DT, 1>(s, oacc, mref, qf, xhalf_max(max32(s[0], -INFINITY)) + FOLD_HEADROOM, true, hi, D);
+        if (first) fold_rereference<T, KS, DT, 1>(s, oacc, mref, qf, xhalf_max(max32(s[0], -INFINITY)) + RfHeadroom<T>::value, true, hi, D);
     } else {
         const float tmax = xhalf_max(max32(s[0], -INFINITY));   // finite: key0 < M
         if (first || !__all(tmax <= FOLD_TAU)) fold_rereference<T, KS, DT, 1>(s, oacc, mref, qf, tmax, first, hi, D);
@@ -501,7 +503,7 @@ __device__ __forceinline__ void fold_stage2(f32x16 (&oacc)[DT], float &mref, boo
     load_vfrags<T, DT>(v1, cur + SUB_BYTES + KT::BYTES, l31, hi);   // lands during the max / check below
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (RangeFree<T>::value) {    // reference set once, from the first stage (see the header comment)
-        if (first) fold_rereference<T, KS, DT, 2>(s, oacc, mref, qf, xhalf_max(max32(s[1], max32(s[0], -INFINITY))) + FOLD_HEADROOM, true, hi, D);
+        if (first) fold_rereference<T, KS, DT, 2>(s, oacc, mref, qf, xhalf_max(max32(s[1], max32(s[0], -INFINITY))) + RfHeadroom<T>::value, true, hi, D);
     } else {
         const float tmax = xhalf_max(max32(s[1], max32(s[0], -INFINITY)));
         if (first || !__all(tmax <= FOLD_TAU)) fold_rereference<T, KS, DT, 2>(s, oacc, mref, qf, tmax, first, hi, D);
@@ -584,10 +586,12 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
     u32x4 vreg[VPT];
     const int nstage = (p.M + STAGE_KEYS - 1) / STAGE_KEYS;
     const int nfull = p.M / STAGE_KEYS;
+    // self-attention: the diagonal stage first (stage_at, pww_attn_core.h): the range-free reference comes from the queries' own neighbourhood
+    const int st0 = (p.M == p.N && nfull > 1) ? min((qb * NW * 32) / STAGE_KEYS, nfull - 1) : 0;
 
-    stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);
+    stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(0, st0, nfull) * k_step, (unsigned)stage_at(0, st0, nfull) * v_step);
     stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
-    stage_load(kreg, vreg, plan, srd_k, srd_v, k_step, v_step);     // past the last key: zeros (out of range)
+    stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(1, st0, nfull) * k_step, (unsigned)stage_at(1, st0, nfull) * v_step);     // past the last key: zeros (out of range)
     __syncthreads();
 
     int st = 0;
@@ -595,11 +599,11 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
         char *cur = smem + (st & 1) * STAGE_BYTES;                  // end read zeros and land in a buffer nobody reads),
         char *nxt = smem + ((st & 1) ^ 1) * STAGE_BYTES;            // so the whole body up to the reference check is one block
         stage_store<DT, KPT, VPT>(kreg, vreg, plan, nxt);
-        stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
+        stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(st + 2, st0, nfull) * k_step, (unsigned)stage_at(st + 2, st0, nfull) * v_step);
         fold_stage2<T, KS, DT, SUB_BYTES>(oacc, mref, first, qf, cur, st * STAGE_KEYS, l31, hi, p.D);
         first = false;
         if (st == 0) {       // magnitude guard, early form: the first stage's row maximum (m_ref minus the range-free headroom)
-            const float m0 = mref - (RangeFree<T>::value ? FOLD_HEADROOM : 0.f);
+            const float m0 = mref - (RangeFree<T>::value ? RfHeadroom<T>::value : 0.f);
             if (__syncthreads_or(qvalid && !(fabsf(m0) <= FoldLimit<T>::value))) { early = true; break; }
         } else {
             __syncthreads();

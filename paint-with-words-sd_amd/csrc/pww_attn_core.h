@@ -440,7 +440,23 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
 // 2^RF_HEADROOM), and every later tile is  P = exp2(s * c1 + mc)  with no maximum, no compare and no O^T rescale. A
 // later score more than ~120 binary orders above that first maximum would overflow exp2: the kernels check the row
 // sums / accumulators once at the end and recompute the workgroup's rows with the exact online softmax in that case.
-constexpr float RF_HEADROOM = 8.f;
+// Headroom of the range-free reference above the first tile's maximum, in binary orders. bf16 (8 exponent bits): 2^8 -- P never
+// leaves the range whatever follows within ~120 orders. f16 (5 exponent bits, finite to 2^16): NONE -- P = 1 at the first tile's
+// maximum, later scores may rise 16 orders (11 natural units) above it before P overflows to inf (caught by the final check: the
+// workgroup then takes the exact path), and everything more than 2^-24 below the reference is flushed: at most 4096 * 2^-24 = 2.4e-4
+// of a row sum that is >= 1 (O^T and the sum accumulate in fp32).
+template <typename T> struct RfHeadroom { static constexpr float value = 8.f; };
+template <> struct RfHeadroom<f16> { static constexpr float value = 0.f; };
+
+// Order in which a self-attention workgroup visits its full key stages: starting with the stage that holds its own first query row
+// (the diagonal), then wrapping around; a ragged last stage stays last. Any order is valid for the online softmax; this one makes the
+// FIRST stage -- the one the range-free reference is taken from -- the neighbourhood of the queries themselves, where trained
+// self-attention keeps its largest logits, so that the reference is (nearly) the row maximum and the overflow fall-back stays rare.
+__device__ __forceinline__ int stage_at(int i, int st0, int nfull) {
+    if (i >= nfull) return i;
+    const int s = i + st0;
+    return s < nfull ? s : s - nfull;
+}
 
 template <typename T, int KS, int DT, bool MASKED, bool ROWSUM_MFMA>
 __device__ __forceinline__ void attn_tile_rf(f32x16 (&oacc)[DT], float &mc, float &l_run, bool first,
@@ -463,7 +479,7 @@ __device__ __forceinline__ void attn_tile_rf(f32x16 (&oacc)[DT], float &mc, floa
 #pragma unroll
             for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb][r]);
         tmax = xhalf_max(tmax);                      // finite: key0 < M, at least one live key
-        mc = -(tmax * c1) - RF_HEADROOM;
+        mc = -(tmax * c1) - RfHeadroom<T>::value;
     }
     const char *vl = Vs + vfrag_lane_off<DT>(hi * 32 + l31);
     float psum = 0.f;

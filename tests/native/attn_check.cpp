@@ -565,6 +565,15 @@ int main(int argc, char **argv) {
         {"d64_late_outlier_bf16", PWW_DTYPE_BF16, 2, 5, 1100, 1100, 64, 0, true, 3, 1.0f, 90.f},        // range-free general kernel (SD2.x head dim): fallback taken
         {"d80_late_outlier_bf16", PWW_DTYPE_BF16, 4, 8, 1024, 1024, 80, 0, true, 7, 0.7f, 90.f},
         {"d160_late_outlier_bf16", PWW_DTYPE_BF16, 2, 8, 300, 300, 160, 0, true, 3, 0.5f, 90.f},
+        // f16 range-free mode (round 3: no headroom, 16 binary orders of room above the first stage's maximum): a late key far above it
+        // overflows P to inf -> the workgroup must notice and take the exact path; a mild one (+8 natural units) must stay on the fast path
+        {"d40_late_outlier_f16", PWW_DTYPE_F16, 2, 4, 700, 700, 40, 0, true, 1, 1.0f, 30.f},
+        {"d40_late_outlier_n4096_f16", PWW_DTYPE_F16, 1, 8, 4096, 4096, 40, 0, true, 31, 1.0f, 30.f},
+        {"d64_late_outlier_f16", PWW_DTYPE_F16, 2, 5, 1100, 1100, 64, 0, true, 3, 1.0f, 40.f},
+        {"d80_late_outlier_f16", PWW_DTYPE_F16, 4, 8, 1024, 1024, 80, 0, true, 7, 0.7f, 40.f},
+        {"d160_late_outlier_f16", PWW_DTYPE_F16, 2, 8, 300, 300, 160, 0, true, 3, 0.5f, 40.f},
+        {"d40_mild_outlier_f16", PWW_DTYPE_F16, 2, 4, 700, 700, 40, 0, true, 1, 1.0f, 3.f},
+        {"d64_self_n2304_f16_b8", PWW_DTYPE_F16, 8, 10, 2304, 2304, 64, 0, true, 193, 0.8f},
         {"d64_self_n2304_bf16_b8", PWW_DTYPE_BF16, 8, 10, 2304, 2304, 64, 0, true, 193, 0.8f},
         {"d40_mild_outlier_bf16", PWW_DTYPE_BF16, 2, 4, 700, 700, 40, 0, true, 1, 1.0f, 10.f},      // scaled logits to +-40: inside the range, fast path only
         // magnitude guard of the folded-reference kernel: row maxima of ~80 and ~120 natural units (gain g gives scaled logits ~ N(0, g^2)):
