@@ -515,7 +515,46 @@ __device__ __forceinline__ void fold_stage2(f32x16 (&oacc)[DT], float &mref, boo
     pv_frags<T, DT>(pf, oacc, v1);
 }
 
-template <typename T, int KS, int DT, int NW>
+// fold_stage2 with the K fragments of the stage ALREADY in registers (read before the barrier that opened the stage) and the next
+// stage's K fragments requested as soon as this stage's score MFMAs are issued: after a barrier all 8 waves used to ask for their 12
+// K fragment reads at once and the first score MFMA waited for them (~200 - 600 cycles of every ~3700-cycle stage). Needs the next
+// stage's rows to be in LDS one barrier earlier: three stage buffers, global loads three stages ahead (PRE mode of the kernel below).
+template <typename T, int KS, int DT, int SUB_BYTES>
+__device__ __forceinline__ void fold_stage2_pre(f32x16 (&oacc)[DT], float &mref, bool first, typename Vec<T>::v8 (&qf)[KS],
+                                                typename Vec<T>::v8 (&k0)[2][KS], typename Vec<T>::v8 (&k1)[2][KS],
+                                                const char *cur, const char *nxt, bool have_next, int l31, int hi, int D) {
+    typedef typename Vec<T>::v8 V8;
+    typedef KTile<KS> KT;
+    V8 v0[2][2][DT], v1[2][2][DT];
+    load_vfrags<T, DT>(v0, cur + KT::BYTES, l31, hi);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 s[2][2];
+    score_frags<T, KS>(s[0], k0, qf);
+    score_frags<T, KS>(s[1], k1, qf);
+    load_vfrags<T, DT>(v1, cur + SUB_BYTES + KT::BYTES, l31, hi);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (RangeFree<T>::value) {
+        if (first) fold_rereference<T, KS, DT, 2>(s, oacc, mref, qf, xhalf_max(max32(s[1], max32(s[0], -INFINITY))) + RfHeadroom<T>::value, true, hi, D);
+    } else {
+        const float tmax = xhalf_max(max32(s[1], max32(s[0], -INFINITY)));
+        if (first || !__all(tmax <= FOLD_TAU)) fold_rereference<T, KS, DT, 2>(s, oacc, mref, qf, tmax, first, hi, D);
+    }
+    V8 pf[2][2];
+    exp_tile<T>(pf, s[0]);
+    pv_frags<T, DT>(pf, oacc, v0);
+    __builtin_amdgcn_sched_barrier(0);
+    // the first sub-tile's scores and V fragments are dead now: their registers take the NEXT stage's K fragments (its rows were parked
+    // in LDS one iteration ago: visible since the last barrier); they land under the second sub-tile's exp / PV work
+    if (have_next) {
+        load_kfrags<T, KS>(k0, nxt, l31, hi);
+        load_kfrags<T, KS>(k1, nxt + SUB_BYTES, l31, hi);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    exp_tile<T>(pf, s[1]);
+    pv_frags<T, DT>(pf, oacc, v1);
+}
+
+template <typename T, int KS, int DT, int NW, bool PRE = false>
 __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false>::value)) attn_fwd_fold_kernel(const AttnParams p) {
     typedef typename Vec<T>::v8 V8;
     typedef KTile<KS> KT;
@@ -565,13 +604,14 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
     bool early = false;    // magnitude guard tripped after the first stage: skip the fast path
     tl_stamp(p, 0);
 
-    // padding is never staged: zero both buffers once, then column D of every V row = one (softmax denominator
+    // padding is never staged: zero the stage buffers once, then column D of every V row = one (softmax denominator
     // from the PV MFMA) and column D of every K row = one (the folded -m_ref term of the score MFMA)
-    for (int i = tid * 16; i < 2 * STAGE_BYTES; i += NT * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0u, 0u, 0u, 0u};
+    constexpr int NBUF = PRE ? 3 : 2;
+    for (int i = tid * 16; i < NBUF * STAGE_BYTES; i += NT * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
     {
         const T one = (T)1.0f;
-        for (int i = tid; i < 2 * NSUB * KVBLK; i += NT) {
+        for (int i = tid; i < NBUF * NSUB * KVBLK; i += NT) {
             *reinterpret_cast<T *>(smem + (i >> 6) * SUB_BYTES + KT::BYTES + (i & 63) * VT::STRIDE + p.D * 2) = one;
             *reinterpret_cast<T *>(smem + (i >> 6) * SUB_BYTES + (i & 63) * KT::STRIDE + p.D * 2) = one;
         }
@@ -589,12 +629,45 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
     // self-attention: the diagonal stage first (stage_at, pww_attn_core.h): the range-free reference comes from the queries' own neighbourhood
     const int st0 = (p.M == p.N && nfull > 1) ? min((qb * NW * 32) / STAGE_KEYS, nfull - 1) : 0;
 
+    int st = 0;
+    char *tail_buf;
+    if constexpr (PRE) {
+        // three stage buffers; rows of stage i + 2 are parked while stage i is computed, so stage i + 1 is readable BEFORE the barrier
+        // that ends stage i and its K fragments can be requested right behind stage i's score MFMAs
+        V8 kc0[2][KS], kc1[2][KS];
+        {
+            u32x4 kreg2[KPT];
+            u32x4 vreg2[VPT];
+            stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(0, st0, nfull) * k_step, (unsigned)stage_at(0, st0, nfull) * v_step);
+            stage_load(kreg2, vreg2, plan, srd_k, srd_v, (unsigned)stage_at(1, st0, nfull) * k_step, (unsigned)stage_at(1, st0, nfull) * v_step);
+            stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
+            stage_store<DT, KPT, VPT>(kreg2, vreg2, plan, smem + STAGE_BYTES);
+        }
+        stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(2, st0, nfull) * k_step, (unsigned)stage_at(2, st0, nfull) * v_step);
+        __syncthreads();
+        char *cur = smem, *nxt = smem + STAGE_BYTES, *nx2 = smem + 2 * STAGE_BYTES;
+        load_kfrags<T, KS>(kc0, cur, l31, hi);
+        load_kfrags<T, KS>(kc1, cur + SUB_BYTES, l31, hi);
+        for (; st < nfull; ++st) {
+            stage_store<DT, KPT, VPT>(kreg, vreg, plan, nx2);                      // rows of stage st + 2
+            stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(st + 3, st0, nfull) * k_step, (unsigned)stage_at(st + 3, st0, nfull) * v_step);
+            fold_stage2_pre<T, KS, DT, SUB_BYTES>(oacc, mref, first, qf, kc0, kc1, cur, nxt, st + 1 < nfull, l31, hi, p.D);
+            first = false;
+            char *t = cur; cur = nxt; nxt = nx2; nx2 = t;
+            if (st == 0) {
+                const float m0 = mref - RfHeadroom<T>::value * (RangeFree<T>::value ? 1.f : 0.f);
+                if (__syncthreads_or(qvalid && !(fabsf(m0) <= FoldLimit<T>::value))) { early = true; break; }
+            } else {
+                __syncthreads();
+            }
+        }
+        tail_buf = cur;                    // the buffer of loop step `st` (the ragged stage, if any)
+    } else {
     stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(0, st0, nfull) * k_step, (unsigned)stage_at(0, st0, nfull) * v_step);
     stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
     stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(1, st0, nfull) * k_step, (unsigned)stage_at(1, st0, nfull) * v_step);     // past the last key: zeros (out of range)
     __syncthreads();
 
-    int st = 0;
     for (; st < nfull; ++st) {   // full stages; ONE barrier per stage. Store / load are unconditional (stages past the
         char *cur = smem + (st & 1) * STAGE_BYTES;                  // end read zeros and land in a buffer nobody reads),
         char *nxt = smem + ((st & 1) ^ 1) * STAGE_BYTES;            // so the whole body up to the reference check is one block
@@ -609,8 +682,10 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
             __syncthreads();
         }
     }
+    tail_buf = smem + (st & 1) * STAGE_BYTES;
+    }
     if (st < nstage && !early) {           // ragged tail stage (already in LDS)
-        char *cur = smem + (st & 1) * STAGE_BYTES;
+        char *cur = tail_buf;
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
             const int key0 = st * STAGE_KEYS + sub * KVBLK;
@@ -732,19 +807,26 @@ static int fold_mode() {   // PWW_ATTN_FOLD (A/B testing only -- accuracy is gua
     return mode;
 }
 
+static int fold_pre_mode() {   // PWW_ATTN_FOLD3=1: three stage buffers + K fragments requested before the barrier (A/B testing; wide workgroups only)
+    static int mode = -2;
+    if (mode == -2) { const char *e = getenv("PWW_ATTN_FOLD3"); mode = e ? atoi(e) : 0; }
+    return mode;
+}
+
 template <typename T, int KS, int DT, int NW>
 static int launch_attn_fold(const AttnParams &p, hipStream_t stream) {
-
-    constexpr size_t lds = 2 * 2 * (KTile<KS>::BYTES + VTile<DT>::BYTES);
+    constexpr size_t stage = 2 * (KTile<KS>::BYTES + VTile<DT>::BYTES);
+    const bool pre = NW >= 4 && fold_pre_mode() == 1;
+    const size_t lds = (pre ? 3 : 2) * stage;
     const int qblocks = (p.N + NW * 32 - 1) / (NW * 32);
-    auto kern = attn_fwd_fold_kernel<T, KS, DT, NW>;
+    auto kern = pre ? attn_fwd_fold_kernel<T, KS, DT, NW, (NW >= 4)> : attn_fwd_fold_kernel<T, KS, DT, NW, false>;
     if (lds > 64 * 1024) {
-        static thread_local bool done = false;
-        if (!done) {
+        static thread_local size_t done[2] = {0, 0};
+        if (done[pre] < lds) {
             if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                           "hipFuncSetAttribute"))
                 return PWW_EHIP;
-            done = true;
+            done[pre] = lds;
         }
     }
     launch_attn_kernel(kern, dim3((unsigned)(qblocks * p.B * p.H)), dim3(NW * 64), lds, stream, p);
