@@ -166,13 +166,16 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
     u32x4 vreg[VPT];
     const int nstage = (p.M + STAGE_KEYS - 1) / STAGE_KEYS;
     const int nfull = p.M / STAGE_KEYS;                 // stages without any key >= M
-    // self-attention: the diagonal stage first (stage_at); step i of the loop works on key stage stage_at(i, st0, nfull)
-    const int st0 = (KG == 1 && !HAS_BIAS && p.M == p.N && nfull > 1) ? min((qb * NW * 32) / STAGE_KEYS, nfull - 1) : 0;   // (a bias is addressed by key position: natural order)
+    // f16 range-free mode: the reference is floored by the row's self-logit (self_logit, pww_attn_core.h); raw-score domain here
+    float ref_floor = -INFINITY;
+    if constexpr (RF && RfHeadroom<T>::value == 0.f) {
+        if (p.M == p.N) { const float sl = self_logit<T, KS>(qf, Kp + (long)qrow * p.k_sm, qvalid, hi, p.D); ref_floor = qvalid ? sl : -INFINITY; }
+    }
 
     // prologue: first stage -> buffer 0, second stage -> registers
-    stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(0, st0, nfull) * k_step, (unsigned)stage_at(0, st0, nfull) * v_step);
+    stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(0) * k_step, (unsigned)(0) * v_step);
     stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
-    if (nstage > 1) stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(1, st0, nfull) * k_step, (unsigned)stage_at(1, st0, nfull) * v_step);
+    if (nstage > 1) stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(1) * k_step, (unsigned)(1) * v_step);
     __syncthreads();
     tl_stamp(p, 1);
 
@@ -183,7 +186,7 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
         // registers hold stage st+1: park it in the other buffer (its readers finished before the last
         // barrier), then re-use the registers for stage st+2, whose loads fly during this stage's compute
         if (st + 1 < nstage) stage_store<DT, KPT, VPT>(kreg, vreg, plan, nxt);
-        if (st + 2 < nstage) stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(st + 2, st0, nfull) * k_step, (unsigned)stage_at(st + 2, st0, nfull) * v_step);
+        if (st + 2 < nstage) stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
         if constexpr (KG > 1) {
             attn_tile<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + kg * SUB_BYTES,
                                                                cur + kg * SUB_BYTES + KT::BYTES, st * STAGE_KEYS + kg * KVBLK,
@@ -192,7 +195,7 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub)
                 attn_tile_rf<T, KS, DT, false, ROWSUM_MFMA>(oacc, mc, l_run, st == 0 && sub == 0, qf, cur + sub * SUB_BYTES,
-                                                            cur + sub * SUB_BYTES + KT::BYTES, st * STAGE_KEYS + sub * KVBLK, p.M, l31, hi, c1);
+                                                            cur + sub * SUB_BYTES + KT::BYTES, st * STAGE_KEYS + sub * KVBLK, p.M, l31, hi, c1, ref_floor);
         } else {
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub)
@@ -216,7 +219,7 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
                 if (key0 < p.M) {
                     if constexpr (RF)
                         attn_tile_rf<T, KS, DT, true, ROWSUM_MFMA>(oacc, mc, l_run, key0 == 0, qf, cur + sub * SUB_BYTES,
-                                                                   cur + sub * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, c1);
+                                                                   cur + sub * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, c1, ref_floor);
                     else
                         attn_tile<T, KS, DT, HAS_BIAS, true, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES,
                                                                           cur + sub * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
@@ -409,7 +412,7 @@ __device__ __forceinline__ float max32(const f32x16 (&s)[2], float m) {
 // one (possibly ragged) 64-key sub-tile
 template <typename T, int KS, int DT, bool MASKED>
 __device__ __forceinline__ void fold_tile(f32x16 (&oacc)[DT], float &mref, bool first, typename Vec<T>::v8 (&qf)[KS],
-                                          const char *Ks, const char *Vs, int key0, int M, int l31, int hi, int D) {
+                                          const char *Ks, const char *Vs, int key0, int M, int l31, int hi, int D, float ref_floor) {
     f32x16 s[1][2];
     score_tile<T, KS>(s[0], qf, Ks, key0, MASKED ? M : 0x7fffffff, l31, hi);
     if (MASKED) {
@@ -419,7 +422,7 @@ __device__ __forceinline__ void fold_tile(f32x16 (&oacc)[DT], float &mref, bool 
             for (int r = 0; r < 16; ++r) s[0][kb][r] = key0 + key_of(kb, r, hi) < M ? s[0][kb][r] : -INFINITY;
     }
     if constexpr (RangeFree<T>::value) {
-        if (first) fold_rereference<T, KS, DT, 1>(s, oacc, mref, qf, xhalf_max(max32(s[0], -INFINITY)) + RfHeadroom<T>::value, true, hi, D);
+        if (first) fold_rereference<T, KS, DT, 1>(s, oacc, mref, qf, fmaxf(xhalf_max(max32(s[0], -INFINITY)), ref_floor) + RfHeadroom<T>::value, true, hi, D);
     } else {
         const float tmax = xhalf_max(max32(s[0], -INFINITY));   // finite: key0 < M
         if (first || !__all(tmax <= FOLD_TAU)) fold_rereference<T, KS, DT, 1>(s, oacc, mref, qf, tmax, first, hi, D);
@@ -489,7 +492,7 @@ __device__ __forceinline__ void exp_tile(typename Vec<T>::v8 (&pf)[2][2], const 
 // sub-tiles are scored, one joint reference check, then exp / PV per sub-tile
 template <typename T, int KS, int DT, int SUB_BYTES>
 __device__ __forceinline__ void fold_stage2(f32x16 (&oacc)[DT], float &mref, bool first, typename Vec<T>::v8 (&qf)[KS],
-                                            const char *cur, int key0, int l31, int hi, int D) {
+                                            const char *cur, int key0, int l31, int hi, int D, float ref_floor) {
     typedef typename Vec<T>::v8 V8;
     typedef KTile<KS> KT;
     V8 k0[2][KS], k1[2][KS], v0[2][2][DT], v1[2][2][DT];
@@ -503,7 +506,7 @@ __device__ __forceinline__ void fold_stage2(f32x16 (&oacc)[DT], float &mref, boo
     load_vfrags<T, DT>(v1, cur + SUB_BYTES + KT::BYTES, l31, hi);   // lands during the max / check below
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (RangeFree<T>::value) {    // reference set once, from the first stage (see the header comment)
-        if (first) fold_rereference<T, KS, DT, 2>(s, oacc, mref, qf, xhalf_max(max32(s[1], max32(s[0], -INFINITY))) + RfHeadroom<T>::value, true, hi, D);
+        if (first) fold_rereference<T, KS, DT, 2>(s, oacc, mref, qf, fmaxf(xhalf_max(max32(s[1], max32(s[0], -INFINITY))), ref_floor) + RfHeadroom<T>::value, true, hi, D);
     } else {
         const float tmax = xhalf_max(max32(s[1], max32(s[0], -INFINITY)));
         if (first || !__all(tmax <= FOLD_TAU)) fold_rereference<T, KS, DT, 2>(s, oacc, mref, qf, tmax, first, hi, D);
@@ -515,46 +518,7 @@ __device__ __forceinline__ void fold_stage2(f32x16 (&oacc)[DT], float &mref, boo
     pv_frags<T, DT>(pf, oacc, v1);
 }
 
-// fold_stage2 with the K fragments of the stage ALREADY in registers (read before the barrier that opened the stage) and the next
-// stage's K fragments requested as soon as this stage's score MFMAs are issued: after a barrier all 8 waves used to ask for their 12
-// K fragment reads at once and the first score MFMA waited for them (~200 - 600 cycles of every ~3700-cycle stage). Needs the next
-// stage's rows to be in LDS one barrier earlier: three stage buffers, global loads three stages ahead (PRE mode of the kernel below).
-template <typename T, int KS, int DT, int SUB_BYTES>
-__device__ __forceinline__ void fold_stage2_pre(f32x16 (&oacc)[DT], float &mref, bool first, typename Vec<T>::v8 (&qf)[KS],
-                                                typename Vec<T>::v8 (&k0)[2][KS], typename Vec<T>::v8 (&k1)[2][KS],
-                                                const char *cur, const char *nxt, bool have_next, int l31, int hi, int D) {
-    typedef typename Vec<T>::v8 V8;
-    typedef KTile<KS> KT;
-    V8 v0[2][2][DT], v1[2][2][DT];
-    load_vfrags<T, DT>(v0, cur + KT::BYTES, l31, hi);
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 s[2][2];
-    score_frags<T, KS>(s[0], k0, qf);
-    score_frags<T, KS>(s[1], k1, qf);
-    load_vfrags<T, DT>(v1, cur + SUB_BYTES + KT::BYTES, l31, hi);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (RangeFree<T>::value) {
-        if (first) fold_rereference<T, KS, DT, 2>(s, oacc, mref, qf, xhalf_max(max32(s[1], max32(s[0], -INFINITY))) + RfHeadroom<T>::value, true, hi, D);
-    } else {
-        const float tmax = xhalf_max(max32(s[1], max32(s[0], -INFINITY)));
-        if (first || !__all(tmax <= FOLD_TAU)) fold_rereference<T, KS, DT, 2>(s, oacc, mref, qf, tmax, first, hi, D);
-    }
-    V8 pf[2][2];
-    exp_tile<T>(pf, s[0]);
-    pv_frags<T, DT>(pf, oacc, v0);
-    __builtin_amdgcn_sched_barrier(0);
-    // the first sub-tile's scores and V fragments are dead now: their registers take the NEXT stage's K fragments (its rows were parked
-    // in LDS one iteration ago: visible since the last barrier); they land under the second sub-tile's exp / PV work
-    if (have_next) {
-        load_kfrags<T, KS>(k0, nxt, l31, hi);
-        load_kfrags<T, KS>(k1, nxt + SUB_BYTES, l31, hi);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    exp_tile<T>(pf, s[1]);
-    pv_frags<T, DT>(pf, oacc, v1);
-}
-
-template <typename T, int KS, int DT, int NW, bool PRE = false>
+template <typename T, int KS, int DT, int NW>
 __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false>::value)) attn_fwd_fold_kernel(const AttnParams p) {
     typedef typename Vec<T>::v8 V8;
     typedef KTile<KS> KT;
@@ -606,7 +570,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
 
     // padding is never staged: zero the stage buffers once, then column D of every V row = one (softmax denominator
     // from the PV MFMA) and column D of every K row = one (the folded -m_ref term of the score MFMA)
-    constexpr int NBUF = PRE ? 3 : 2;
+    constexpr int NBUF = 2;
     for (int i = tid * 16; i < NBUF * STAGE_BYTES; i += NT * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();
     {
@@ -626,54 +590,26 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
     u32x4 vreg[VPT];
     const int nstage = (p.M + STAGE_KEYS - 1) / STAGE_KEYS;
     const int nfull = p.M / STAGE_KEYS;
-    // self-attention: the diagonal stage first (stage_at, pww_attn_core.h): the range-free reference comes from the queries' own neighbourhood
-    const int st0 = (p.M == p.N && nfull > 1) ? min((qb * NW * 32) / STAGE_KEYS, nfull - 1) : 0;
+    // f16 range-free mode: the reference is floored by the row's self-logit (self_logit, pww_attn_core.h; qf is pre-scaled: exp2 domain)
+    float ref_floor = -INFINITY;
+    if constexpr (RangeFree<T>::value && RfHeadroom<T>::value == 0.f) {
+        if (p.M == p.N) { const float sl = self_logit<T, KS>(qf, Kp + (long)qrow * p.k_sm, qvalid, hi, p.D); ref_floor = qvalid ? sl : -INFINITY; }
+    }
 
     int st = 0;
     char *tail_buf;
-    if constexpr (PRE) {
-        // three stage buffers; rows of stage i + 2 are parked while stage i is computed, so stage i + 1 is readable BEFORE the barrier
-        // that ends stage i and its K fragments can be requested right behind stage i's score MFMAs
-        V8 kc0[2][KS], kc1[2][KS];
-        {
-            u32x4 kreg2[KPT];
-            u32x4 vreg2[VPT];
-            stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(0, st0, nfull) * k_step, (unsigned)stage_at(0, st0, nfull) * v_step);
-            stage_load(kreg2, vreg2, plan, srd_k, srd_v, (unsigned)stage_at(1, st0, nfull) * k_step, (unsigned)stage_at(1, st0, nfull) * v_step);
-            stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
-            stage_store<DT, KPT, VPT>(kreg2, vreg2, plan, smem + STAGE_BYTES);
-        }
-        stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(2, st0, nfull) * k_step, (unsigned)stage_at(2, st0, nfull) * v_step);
-        __syncthreads();
-        char *cur = smem, *nxt = smem + STAGE_BYTES, *nx2 = smem + 2 * STAGE_BYTES;
-        load_kfrags<T, KS>(kc0, cur, l31, hi);
-        load_kfrags<T, KS>(kc1, cur + SUB_BYTES, l31, hi);
-        for (; st < nfull; ++st) {
-            stage_store<DT, KPT, VPT>(kreg, vreg, plan, nx2);                      // rows of stage st + 2
-            stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(st + 3, st0, nfull) * k_step, (unsigned)stage_at(st + 3, st0, nfull) * v_step);
-            fold_stage2_pre<T, KS, DT, SUB_BYTES>(oacc, mref, first, qf, kc0, kc1, cur, nxt, st + 1 < nfull, l31, hi, p.D);
-            first = false;
-            char *t = cur; cur = nxt; nxt = nx2; nx2 = t;
-            if (st == 0) {
-                const float m0 = mref - RfHeadroom<T>::value * (RangeFree<T>::value ? 1.f : 0.f);
-                if (__syncthreads_or(qvalid && !(fabsf(m0) <= FoldLimit<T>::value))) { early = true; break; }
-            } else {
-                __syncthreads();
-            }
-        }
-        tail_buf = cur;                    // the buffer of loop step `st` (the ragged stage, if any)
-    } else {
-    stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(0, st0, nfull) * k_step, (unsigned)stage_at(0, st0, nfull) * v_step);
+    {
+    stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(0) * k_step, (unsigned)(0) * v_step);
     stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
-    stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(1, st0, nfull) * k_step, (unsigned)stage_at(1, st0, nfull) * v_step);     // past the last key: zeros (out of range)
+    stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(1) * k_step, (unsigned)(1) * v_step);     // past the last key: zeros (out of range)
     __syncthreads();
 
     for (; st < nfull; ++st) {   // full stages; ONE barrier per stage. Store / load are unconditional (stages past the
         char *cur = smem + (st & 1) * STAGE_BYTES;                  // end read zeros and land in a buffer nobody reads),
         char *nxt = smem + ((st & 1) ^ 1) * STAGE_BYTES;            // so the whole body up to the reference check is one block
         stage_store<DT, KPT, VPT>(kreg, vreg, plan, nxt);
-        stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)stage_at(st + 2, st0, nfull) * k_step, (unsigned)stage_at(st + 2, st0, nfull) * v_step);
-        fold_stage2<T, KS, DT, SUB_BYTES>(oacc, mref, first, qf, cur, st * STAGE_KEYS, l31, hi, p.D);
+        stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
+        fold_stage2<T, KS, DT, SUB_BYTES>(oacc, mref, first, qf, cur, st * STAGE_KEYS, l31, hi, p.D, ref_floor);
         first = false;
         if (st == 0) {       // magnitude guard, early form: the first stage's row maximum (m_ref minus the range-free headroom)
             const float m0 = mref - (RangeFree<T>::value ? RfHeadroom<T>::value : 0.f);
@@ -691,7 +627,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
             const int key0 = st * STAGE_KEYS + sub * KVBLK;
             if (key0 < p.M) {
                 fold_tile<T, KS, DT, true>(oacc, mref, first, qf, cur + sub * SUB_BYTES, cur + sub * SUB_BYTES + KT::BYTES,
-                                           key0, p.M, l31, hi, p.D);
+                                           key0, p.M, l31, hi, p.D, ref_floor);
                 first = false;
             }
         }
@@ -807,26 +743,18 @@ static int fold_mode() {   // PWW_ATTN_FOLD (A/B testing only -- accuracy is gua
     return mode;
 }
 
-static int fold_pre_mode() {   // PWW_ATTN_FOLD3=1: three stage buffers + K fragments requested before the barrier (A/B testing; wide workgroups only)
-    static int mode = -2;
-    if (mode == -2) { const char *e = getenv("PWW_ATTN_FOLD3"); mode = e ? atoi(e) : 0; }
-    return mode;
-}
-
 template <typename T, int KS, int DT, int NW>
 static int launch_attn_fold(const AttnParams &p, hipStream_t stream) {
-    constexpr size_t stage = 2 * (KTile<KS>::BYTES + VTile<DT>::BYTES);
-    const bool pre = NW >= 4 && fold_pre_mode() == 1;
-    const size_t lds = (pre ? 3 : 2) * stage;
+    constexpr size_t lds = 2 * 2 * (KTile<KS>::BYTES + VTile<DT>::BYTES);
     const int qblocks = (p.N + NW * 32 - 1) / (NW * 32);
-    auto kern = pre ? attn_fwd_fold_kernel<T, KS, DT, NW, (NW >= 4)> : attn_fwd_fold_kernel<T, KS, DT, NW, false>;
+    auto kern = attn_fwd_fold_kernel<T, KS, DT, NW>;
     if (lds > 64 * 1024) {
-        static thread_local size_t done[2] = {0, 0};
-        if (done[pre] < lds) {
+        static thread_local bool done = false;
+        if (!done) {
             if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                           "hipFuncSetAttribute"))
                 return PWW_EHIP;
-            done[pre] = lds;
+            done = true;
         }
     }
     launch_attn_kernel(kern, dim3((unsigned)(qblocks * p.B * p.H)), dim3(NW * 64), lds, stream, p);

@@ -448,20 +448,28 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
 template <typename T> struct RfHeadroom { static constexpr float value = 8.f; };
 template <> struct RfHeadroom<f16> { static constexpr float value = 0.f; };
 
-// Order in which a self-attention workgroup visits its full key stages: starting with the stage that holds its own first query row
-// (the diagonal), then wrapping around; a ragged last stage stays last. Any order is valid for the online softmax; this one makes the
-// FIRST stage -- the one the range-free reference is taken from -- the neighbourhood of the queries themselves, where trained
-// self-attention keeps its largest logits, so that the reference is (nearly) the row maximum and the overflow fall-back stays rare.
-__device__ __forceinline__ int stage_at(int i, int st0, int nfull) {
-    if (i >= nfull) return i;
-    const int s = i + st0;
-    return s < nfull ? s : s - nfull;
+// The f16 range-free reference has only 16 binary orders of room above it, and the first key stage (in self-attention: the first
+// 128 tokens = the top two rows of the image) says little about where a query's largest logits are. Trained self-attention keeps them
+// around the query's OWN token, so for M == N the reference is floored by the row's self-logit q_row . k_row -- one 3-fragment load and
+// a 24-term dot product per lane, once per kernel; the key stages stay in natural order (all query blocks of a head walk the keys in
+// lockstep: that is what lets one L2 fill serve 16 workgroups -- visiting the diagonal stage first instead was measured: 2.6x the
+// fabric traffic, profiles/r03_traffic.json). Returns the raw dot product over the lane's fragment halves, summed over both halves.
+template <typename T, int KS>
+__device__ __forceinline__ float self_logit(const typename Vec<T>::v8 (&qf)[KS], const T *krow_ptr, bool valid, int hi, int D) {
+    typename Vec<T>::v8 kd[KS];
+    load_q_frags<T, KS>(kd, krow_ptr, valid, hi, D);
+    float acc = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = fmaf((float)qf[ks][j], (float)kd[ks][j], acc);
+    return acc + __shfl_xor(acc, 32);
 }
 
 template <typename T, int KS, int DT, bool MASKED, bool ROWSUM_MFMA>
 __device__ __forceinline__ void attn_tile_rf(f32x16 (&oacc)[DT], float &mc, float &l_run, bool first,
                                              const typename Vec<T>::v8 (&qf)[KS], const char *Ks, const char *Vs,
-                                             int key0, int M, int l31, int hi, float c1) {
+                                             int key0, int M, int l31, int hi, float c1, float ref_floor = -INFINITY) {
     typedef typename Vec<T>::v8 V8;
     f32x16 s[2];
     score_tile<T, KS>(s, qf, Ks, key0, MASKED ? M : 0x7fffffff, l31, hi);
@@ -478,7 +486,7 @@ __device__ __forceinline__ void attn_tile_rf(f32x16 (&oacc)[DT], float &mc, floa
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[kb][r]);
-        tmax = xhalf_max(tmax);                      // finite: key0 < M, at least one live key
+        tmax = fmaxf(xhalf_max(tmax), ref_floor);    // finite: key0 < M, at least one live key (ref_floor: the row's self-logit, f16)
         mc = -(tmax * c1) - RfHeadroom<T>::value;
     }
     const char *vl = Vs + vfrag_lane_off<DT>(hi * 32 + l31);
