@@ -289,7 +289,8 @@ def measured_traffic(n_tok, d, b_rows, dtype, live=False):
 
 
 HARNESS_CASES = {(4096, 40, 2, "bf16"): "sd15_self_n4096_d40_bf16_b2", (4096, 40, 2, "fp16"): "sd15_self_n4096_d40_f16_b2",
-                 (9216, 64, 4, "bf16"): "sd21_self_n9216_d64_b4"}
+                 (4096, 40, 16, "fp16"): "sd15_self_n4096_d40_f16_b16", (4096, 40, 16, "bf16"): "sd15_self_n4096_d40_bf16_b16",
+                 (9216, 64, 4, "bf16"): "sd21_self_n9216_d64_b4", (9216, 64, 8, "bf16"): "sd21_self_n9216_d64_b8"}
 
 
 def live_traffic(n_tok, d, b_rows, dtype):

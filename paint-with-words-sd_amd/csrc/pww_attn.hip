@@ -173,9 +173,9 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
     }
 
     // prologue: first stage -> buffer 0, second stage -> registers
-    stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(0) * k_step, (unsigned)(0) * v_step);
+    stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);
     stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
-    if (nstage > 1) stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(1) * k_step, (unsigned)(1) * v_step);
+    if (nstage > 1) stage_load(kreg, vreg, plan, srd_k, srd_v, k_step, v_step);
     __syncthreads();
     tl_stamp(p, 1);
 
@@ -596,14 +596,12 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
         if (p.M == p.N) { const float sl = self_logit<T, KS>(qf, Kp + (long)qrow * p.k_sm, qvalid, hi, p.D); ref_floor = qvalid ? sl : -INFINITY; }
     }
 
-    int st = 0;
-    char *tail_buf;
-    {
-    stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(0) * k_step, (unsigned)(0) * v_step);
+    stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);
     stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
-    stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(1) * k_step, (unsigned)(1) * v_step);     // past the last key: zeros (out of range)
+    stage_load(kreg, vreg, plan, srd_k, srd_v, k_step, v_step);     // past the last key: zeros (out of range)
     __syncthreads();
 
+    int st = 0;
     for (; st < nfull; ++st) {   // full stages; ONE barrier per stage. Store / load are unconditional (stages past the
         char *cur = smem + (st & 1) * STAGE_BYTES;                  // end read zeros and land in a buffer nobody reads),
         char *nxt = smem + ((st & 1) ^ 1) * STAGE_BYTES;            // so the whole body up to the reference check is one block
@@ -618,10 +616,8 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
             __syncthreads();
         }
     }
-    tail_buf = smem + (st & 1) * STAGE_BYTES;
-    }
     if (st < nstage && !early) {           // ragged tail stage (already in LDS)
-        char *cur = tail_buf;
+        char *cur = smem + (st & 1) * STAGE_BYTES;
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
             const int key0 = st * STAGE_KEYS + sub * KVBLK;

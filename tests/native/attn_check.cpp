@@ -300,6 +300,24 @@ static void run_case(const Case &c, bool timing) {
                 HIPCHECK(hipEventRecord(e1, nullptr)); HIPCHECK(hipEventSynchronize(e1));
                 HIPCHECK(hipEventElapsedTime(&ms_e, e0, e1));
                 printf("TIME %-28s fused_ex with bias_cols=%d: %.2f us/call\n", c.name, c.bias_cols, ms_e * 1e3 / iters);
+                if (!ccols.empty()) {      // the compact form of the same map
+                    const int R = (int)ccols.size();
+                    std::vector<float> comp((size_t)N * R);
+                    for (int n = 0; n < N; ++n) for (int r = 0; r < R; ++r) comp[(size_t)n * R + r] = bias[(size_t)n * M + ccols[r]];
+                    std::vector<int32_t> ci(ccols.begin(), ccols.end());
+                    float *dcompact = dalloc<float>(comp.size()); int32_t *dcidx = dalloc<int32_t>(R);
+                    HIPCHECK(hipMemcpy(dcompact, comp.data(), comp.size() * 4, hipMemcpyHostToDevice));
+                    HIPCHECK(hipMemcpy(dcidx, ci.data(), R * 4, hipMemcpyHostToDevice));
+                    op.bias_compact = dcompact; op.col_idx = dcidx; op.R = R; op.compact_stride[1] = R;
+                    for (int i = 0; i < 5 + iters; ++i) {
+                        if (i == 5) HIPCHECK(hipEventRecord(e0, nullptr));
+                        pww_cross_attn_fwd_fused_ex(dq, dk, dv, o2, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, nullptr, dsync, sync_bytes, fws, fws_bytes, &op, nullptr);
+                    }
+                    HIPCHECK(hipEventRecord(e1, nullptr)); HIPCHECK(hipEventSynchronize(e1));
+                    HIPCHECK(hipEventElapsedTime(&ms_e, e0, e1));
+                    printf("TIME %-28s fused_ex with the compact form (R=%d, bias_cols=%d): %.2f us/call\n", c.name, R, c.bias_cols, ms_e * 1e3 / iters);
+                    (void)hipFree(dcompact); (void)hipFree(dcidx);
+                }
             }
         }
         for (void *ptr : {(void *)fws, (void *)dsync, (void *)fstats, (void *)o1, (void *)o2, (void *)dgate}) (void)hipFree(ptr);
