@@ -10,7 +10,11 @@ import numpy as np
 import torch
 import torch.nn.functional as F  # noqa: F401  (region-seed masks: _get_binary_mask)
 
+import os
+
 from . import ops
+
+COMPACT_BIAS = os.environ.get("PWW_COMPACT_BIAS", "0") == "1"   # see prepare_conditioning: private compact weight maps, opt-in
 
 
 def always_round(x):
@@ -174,7 +178,10 @@ def _encode_text_color_inputs(text_encoder, tokenizer, device, color_map_image, 
         # (both are kernel-launch geometry, i.e. part of a captured hipGraph's identity: rounded up -- the bound to 16 columns,
         # the compact width to 8 slots with unused ones marked -1 -- so that similar prompts replay the same graph)
         encoder_hidden_states[BIAS_COLS] = ((max(nz_cols) + 16) // 16 * 16) if nz_cols else 16
-        if 1 <= len(nz_cols) <= ops.COMPACT_MAX_R:
+        # The compact form is OPT-IN (PWW_COMPACT_BIAS=1 / conditioning.COMPACT_BIAS): measured on MI355X it is 0.5 - 6 us SLOWER per
+        # launch than the dense LDS tile bounded by BIAS_COLS in every UNet shape (profiles/r03_cross_timeline.md: the launch is bound
+        # by the statistic hand-off and the score passes, not by the bias bytes), and building it costs 5 extra kernels per request.
+        if COMPACT_BIAS and 1 <= len(nz_cols) <= ops.COMPACT_MAX_R:
             R = (len(nz_cols) + 7) // 8 * 8
             idx = torch.tensor(nz_cols, dtype=torch.int64, device=device)
             pad = torch.full((R - len(nz_cols),), -1, dtype=torch.int32, device=device)

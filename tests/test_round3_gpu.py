@@ -365,6 +365,32 @@ def test_bias_hints_do_not_change_a_bit(gpu_device, shape, dtype, B):
     assert torch.equal(two, base)
 
 
+def test_opt_in_compact_maps_through_the_product(gpu_device, monkeypatch):
+    """conditioning.COMPACT_BIAS (env PWW_COMPACT_BIAS=1) adds the compact [N, R] + col_idx form of every weight map to the
+    conditional context; the folded batch stacks them and pww_attention hands them to the fused kernel. Off by default (slower
+    than the dense LDS tile in every measured shape); on, the latents must be bit-identical to the default route."""
+    import paint_with_words as pw
+    from pww_hip import conditioning
+    from pww_hip.attention import COMPACT_IDX
+    tools = cases.build_tools("tiny", dtype=torch.float16, device=gpu_device)
+    kw = dict(color_map_image=Image.fromarray(cases.load_example_rgb()), color_context=dict(cases.RUNNER_CONTEXT), input_prompt=cases.RUNNER_PROMPT,
+              num_inference_steps=3, guidance_scale=7.5, seed=5, device=str(gpu_device), weight_function=cases.weight_fn_runner,
+              preloaded_utils=tools, return_latents=True)
+    try:
+        with _mode("graph"):
+            assert conditioning.COMPACT_BIAS is (os.environ.get("PWW_COMPACT_BIAS", "0") == "1")
+            monkeypatch.setattr(conditioning, "COMPACT_BIAS", False)
+            base = pw.paint_with_words(**kw)
+            sampler = tools[1]._pww_samplers[(id(tools[4]), "graph")]
+            assert COMPACT_IDX not in sampler._static_folded
+            monkeypatch.setattr(conditioning, "COMPACT_BIAS", True)
+            on = pw.paint_with_words(**kw)
+            assert COMPACT_IDX in sampler._static_folded and sampler._graphed.captures == 2     # new context tensors: re-captured once
+    finally:
+        uninstall_all()
+    assert torch.equal(on, base)
+
+
 # ---- 8: the inpaint pipeline class, called --------------------------------------------------------------------------------------
 
 def test_inpaint_pipeline_call(gpu_device):
