@@ -276,10 +276,31 @@ struct BiasRef {
     unsigned key_stride;   // bytes
     bool unit;             // key_stride == 4
     // BIAS == 2: the query block's bias rows sit in LDS (pww_cross.hip stages the contiguous [rows, cols] span with coalesced
-    // 16-byte loads): the lane's row starts at lds_row, columns >= lds_cols (a multiple of 16) are known to be zero
-    const char *lds_row;
+    // 16-byte loads): columns >= lds_cols (a multiple of 16) are known to be zero. The tile is UNPADDED (row stride = a power of two
+    // >= lds_cols floats: what an LDS-direct load writes, lane-linear) and XOR-swizzled in 16-byte chunks -- physical chunk = chunk ^
+    // tile_swz(row) -- so that the lanes of a wave, each reading the same chunk of its own row, hit different banks. For the
+    // reading lane the swizzle is a constant: lds_p0 / lds_p1 = row start + ((2 hi) ^ (swz & 3)) * 16 and its ^1 neighbour (the
+    // lane's two chunks of a 16-key group), lds_hi16 = (swz & ~3) * 16 is XORed onto the group's chunk base.
+    const char *lds_p0, *lds_p1;
+    unsigned lds_hi16;
     int lds_cols;
 };
+
+// swizzle of the bias tile: cpr = 16-byte chunks per tile row (a multiple of 4). Rows whose starts fall on the same banks
+// (row stride 64 / 192 bytes mod 256: every 4th row; 128: every 2nd; 0: every row) get different chunk permutations: any 16
+// consecutive rows reading the same logical chunk touch 16 different 4-bank groups.
+__device__ __forceinline__ int tile_swz(int row, int cpr) {
+    const int t = (cpr & 4) ? 2 : (cpr & 8) ? 3 : 4;
+    return (row >> (4 - t)) & ((1 << t) - 1);
+}
+__device__ __forceinline__ void bias_ref_tile(BiasRef &b, const char *tile, int row, int stride, int cols, int hi) {
+    const int swz = tile_swz(row, stride >> 2);
+    const char *rowp = tile + (long)row * stride * 4;
+    b.lds_p0 = rowp + (((2 * hi) ^ (swz & 3)) << 4);
+    b.lds_p1 = rowp + (((2 * hi + 1) ^ (swz & 3)) << 4);
+    b.lds_hi16 = (unsigned)(swz & ~3) << 4;
+    b.lds_cols = cols;
+}
 
 template <typename T, int KS, int DT, int HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
 __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[DT], float &m_run, float &l_run, const char *Vs,
@@ -322,8 +343,9 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
                     const int col0 = key0 + kb * 32 + 16 * g;
                     float m4[2] = {-INFINITY, -INFINITY};        // two short max chains per group instead of one long one
                     if (col0 < bias.lds_cols) {
-                        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bias.lds_row + (col0 + 8 * hi) * 4);
-                        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bias.lds_row + (col0 + 8 * hi) * 4 + 16);
+                        const unsigned grp = ((unsigned)col0 * 4u) ^ bias.lds_hi16;      // (col0 / 4) chunks * 16 bytes, swizzled
+                        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bias.lds_p0 + grp);
+                        const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bias.lds_p1 + grp);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const int r = g * 8 + j;

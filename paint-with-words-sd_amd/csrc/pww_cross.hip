@@ -41,7 +41,9 @@ struct CrossParams {
     int nchunk;          // workgroups per (image, head)
     // bias rows of a query block staged in LDS (tile_stride > 0): [NW * 32 rows][tile_stride floats], filled either from the
     // dense map (columns < a.bias_cols; the rows of a block are one contiguous span of the [N, M] map) or from the compact form
-    int tile_stride;             // floats per tile row = bias_cols + 4 (row -> bank map odd: conflict-free 16-byte reads); 0 = per-lane global loads
+    int tile_stride;             // floats per tile row: bias_cols rounded up to a power of two (16 / 32 / 64 / 128; XOR-swizzled chunks: tile_swz); 0 = per-lane global loads
+    int tile_nbuf;               // dense form, several query blocks per workgroup: 2 = the next block's rows are loaded (LDS-direct) while
+                                 // this block is computed, 1 = one buffer (the second would cost a resident workgroup per CU)
     const float *compact;        // compact bias [B?][N][R] (or null): bias[b][n][col_idx[b?][r]] = compact[b][n][r], every other column zero
     const int *col_idx;          // [B?][R], -1 = unused slot
     int R;
@@ -60,6 +62,22 @@ __device__ __forceinline__ unsigned long long slot_read(const unsigned long long
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ double slot_value(unsigned long long x) { return __longlong_as_double((long long)~x); }
+
+// Q fragments through a buffer descriptor: UNCONDITIONAL loads (validity goes into the offset: an out-of-range offset returns zeros).
+// A load under an `if` -- rows past N, fragment halves past D -- sits in its own basic block and hipcc then waits for everything in
+// flight at the join: a prefetch issued that way is no prefetch (the query-block loops of this kernel ran one exposed global-load
+// latency per block until round 3). row_off = byte offset of the lane's row within the (image, head) slice, or OOB_OFF.
+template <typename T, int KS, typename SRD>
+__device__ __forceinline__ void load_q_frags_buf(typename Vec<T>::v8 (&qf)[KS], SRD srd, unsigned row_off, int hi, int D) {
+    typedef typename Vec<T>::v8 V8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int d0 = ks * 16 + hi * 8;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srd, d0 < D ? row_off + (unsigned)d0 * 2u : OOB_OFF, 0, 0);
+        qf[ks] = __builtin_bit_cast(V8, v);
+    }
+}
+constexpr int WAIT_VMCNT0 = 0x0F70;     // s_waitcnt vmcnt(0) only (gfx9 encoding: expcnt 7, lgkmcnt 15 = "do not wait")
 
 // ---- bias tile staging -------------------------------------------------------------------------------------------------
 // A query block's bias rows are ONE contiguous span of the [N, M] fp32 map (rows x 308 bytes for the 77 prompt tokens). Loading
@@ -80,9 +98,47 @@ template <int NT>
 __device__ __forceinline__ void tile_slab_store(const u32x4 (&reg)[4], char *tile, int tile_stride, int slab, int bias_cols, int tid) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int g = tid + i * NT, row = g >> 3, col = slab * 32 + (g & 7) * 4;
-        if (col < bias_cols) *reinterpret_cast<u32x4 *>(tile + ((long)row * tile_stride + col) * 4) = reg[i];
+        const int g = tid + i * NT, row = g >> 3, chunk = slab * 8 + (g & 7);
+        if (chunk * 4 < bias_cols)
+            *reinterpret_cast<u32x4 *>(tile + (long)row * tile_stride * 4 + ((chunk ^ tile_swz(row, tile_stride >> 2)) << 4)) = reg[i];
     }
+}
+// LDS-direct form of the same copy (several query blocks per workgroup): `buffer_load_dwordx4 ... lds` writes lane-linear
+// (wave-uniform base + lane * 16), so thread t fills the physical chunks t + i * NT of the tile and the swizzle goes onto the
+// SOURCE address. No staging registers, and the copy of block i + 1 is in flight while block i is computed. The tile's physical row
+// is a power of two wide (4 / 8 / 16 chunks for 16 / 32 / 48 columns), so step i of a thread is the same chunk NT / cpr rows further
+// down -- which leaves the swizzle alone: ONE register (rel0 = the thread's source offset within a block, or OOB_OFF for the padding
+// chunks of a 48-column tile) describes all of a thread's copies. Rows past N lie beyond the descriptor's range and arrive as zeros.
+template <int NT>
+__device__ __forceinline__ unsigned tile_glds_plan(int cpr, int cols, long b_sn, int tid) {
+    const int row = tid / cpr, pc = tid - row * cpr, c = pc ^ tile_swz(row, cpr);
+    return c * 4 < cols ? (unsigned)((row * b_sn + c * 4) * 4) : OOB_OFF;
+}
+// The copies are issued as inline assembly ON PURPOSE: hipcc orders every later LDS read behind an LDS-direct load it knows about
+// (it cannot tell the K / V fragment reads and the other tile buffer from the copy's destination) and would wait for the copy at
+// the first `ds_read` of the block -- the latency this scheme exists to hide. Untracked, the copies only ever make hipcc's own counted
+// waits conservative (vmcnt retires in order); their completion is waited for explicitly (s_waitcnt vmcnt(0) + barrier) before
+// the tile is read. M0 (the LDS destination) is saved and restored inside the statement.
+__device__ __forceinline__ void glds16(const u32x4 srd, unsigned lds_dst, unsigned voff) {
+    unsigned keep;
+    __asm__ volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(srd) : "memory");
+}
+template <int NT, int CNT>
+__device__ __forceinline__ void tile_glds_n(unsigned rel0, unsigned step, const u32x4 srd, unsigned lds_dst) {
+#pragma unroll
+    for (int i = 0; i < CNT; ++i) glds16(srd, lds_dst + (unsigned)(i * NT * 16), rel0 + (unsigned)i * step);
+}
+// (one straight-line sequence per width: 2 / 4 / 8 copies per thread)
+template <int NT>
+__device__ __forceinline__ void tile_glds(unsigned rel0, const u32x4 srd, const char *tile, long row0, long b_sn, int cpr, int wave) {
+    typedef __attribute__((address_space(3))) const char *lds_cp;
+    const unsigned base = rel0 + (unsigned)(row0 * b_sn * 4);            // (OOB_OFF + anything below 2^31 stays out of range)
+    const unsigned step = (unsigned)((NT / cpr) * b_sn * 4);
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_cp)tile + (unsigned)(wave * 64 * 16));   // wave-uniform (an SGPR): each lane lands 16 bytes further
+    if (cpr == 4) tile_glds_n<NT, 2>(base, step, srd, lds_dst);
+    else if (cpr == 8) tile_glds_n<NT, 4>(base, step, srd, lds_dst);
+    else tile_glds_n<NT, 8>(base, step, srd, lds_dst);
 }
 // compact form: rows x R contiguous floats of the block, scattered to their columns (the tile was zeroed once: columns outside
 // col_idx stay zero for the whole launch)
@@ -101,14 +157,16 @@ __device__ __forceinline__ void compact_load(u32x4 (&reg)[4], const float *cbase
     }
 }
 template <int NT>
-__device__ __forceinline__ void compact_store(const u32x4 (&reg)[4], float *tile, int tile_stride, const int *cidx_lds, int R, int tid) {
-    float *trow = tile + (long)(tid >> 1) * tile_stride;
+__device__ __forceinline__ void compact_store(const u32x4 (&reg)[4], char *tile, int tile_stride, const int *cidx_lds, int R, int tid) {
+    const int row = tid >> 1;
+    char *trow = tile + (long)row * tile_stride * 4;
+    const int swz = tile_swz(row, tile_stride >> 2);
     const int *ci = cidx_lds + (tid & 1);
 #pragma unroll
     for (int i = 0; i < COMPACT_MAX_R / 2; ++i) {
         if ((tid & 1) + 2 * i < R) {
             const int col = ci[2 * i];
-            if (col >= 0) trow[col] = __uint_as_float(reg[i >> 2][i & 3]);
+            if (col >= 0) *reinterpret_cast<float *>(trow + (((col >> 2) ^ swz) << 4) + (col & 3) * 4) = __uint_as_float(reg[i >> 2][i & 3]);
         }
     }
 }
@@ -123,7 +181,7 @@ __device__ __forceinline__ void tile_request(u32x4 (&reg)[4], bool compact, cons
 template <int NT, typename SRD>
 __device__ __forceinline__ void tile_park(u32x4 (&reg)[4], bool compact, char *tile, int tile_stride, const int *cidx, SRD srd, long row0, int N,
                                           long b_sn, int R, int bias_cols, int tid) {
-    if (compact) { compact_store<NT>(reg, reinterpret_cast<float *>(tile), tile_stride, cidx, R, tid); return; }
+    if (compact) { compact_store<NT>(reg, tile, tile_stride, cidx, R, tid); return; }
     tile_slab_store<NT>(reg, tile, tile_stride, 0, bias_cols, tid);
     const int nslab = (bias_cols + 31) >> 5;
     for (int slab = 1; slab < nslab; ++slab) {     // maps wider than 32 columns: the further slabs are not prefetched
@@ -132,7 +190,7 @@ __device__ __forceinline__ void tile_park(u32x4 (&reg)[4], bool compact, char *t
     }
 }
 
-template <typename T, int KS, int DT, int NW, bool SINGLE>
+template <typename T, int KS, int DT, int NW, bool SINGLE, bool COMPACT>
 __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel(const CrossParams cp) {
     typedef typename Vec<T>::v8 V8;
     typedef KTile<KS> KT;
@@ -145,13 +203,14 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     constexpr int VPT = (NSUB * VT::NCHUNK + NT - 1) / NT;
     const AttnParams &p = cp.a;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [K|V stage][fin: NW x 4 f64][final: 4 f64][red: NW x 4 f32][flag][col_idx][bias tile]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [K|V stage][fin: NW x 4 f64][final: 4 f64][red: 2 x NW x 4 f32][flag][col_idx][bias tile(s)]
     double *fin = reinterpret_cast<double *>(smem + STAGE_BYTES);
     double *final_st = fin + NW * 4;
-    float *red = reinterpret_cast<float *>(final_st + 4);
-    volatile int *ok_flag = reinterpret_cast<volatile int *>(red + NW * 4);
-    int *cidx_lds = reinterpret_cast<int *>(red + NW * 4) + 4;                 // COMPACT_MAX_R ints
+    float *red = reinterpret_cast<float *>(final_st + 4);          // two buffers, alternating by block: one barrier per block
+    volatile int *ok_flag = reinterpret_cast<volatile int *>(red + 2 * NW * 4);
+    int *cidx_lds = reinterpret_cast<int *>(red + 2 * NW * 4) + 4;             // COMPACT_MAX_R ints
     char *tile = reinterpret_cast<char *>(cidx_lds + COMPACT_MAX_R);
+    const int tile_bytes = NW * 32 * cp.tile_stride * 4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -178,9 +237,10 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     // and looked at after K and V are staged, so the prologue's loads -- Q, K, V, the bias rows -- do not queue up behind it.
     // Until then everything is decided from the kernel arguments alone (`maybe`: a gated-out image stages its bias rows in vain).
     const float gate = p.bias_coeff ? p.bias_coeff[b] : 1.f;
-    const bool maybe_biased = p.bias != nullptr || cp.compact != nullptr;
+    const bool maybe_biased = COMPACT || p.bias != nullptr;
     const bool use_tile = maybe_biased && cp.tile_stride > 0;
-    const bool use_compact = use_tile && cp.compact != nullptr;
+    const bool use_compact = COMPACT && use_tile;     // (the host instantiates COMPACT exactly when cp.compact is set: the compact
+                                                      // form's staging registers stay out of the dense kernels)
 
     const T *Qp = reinterpret_cast<const T *>(p.q) + b * p.q_sb + h * p.q_sh;
     const T *Kp = reinterpret_cast<const T *>(p.k) + b * p.k_sb + h * p.k_sh;
@@ -190,20 +250,28 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     // first query block of this workgroup: its Q fragments are requested before anything else (SINGLE: they stay in
     // registers for both passes; otherwise every iteration requests the NEXT block's fragments before it computes)
     V8 qf[KS];
-    {
-        const int qrow = (chunk * NW + wave) * 32 + l31;
-        load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qrow < p.N, hi, p.D);
-    }
+    const auto srd_q = head_srd(Qp, p.N, p.q_sn, p.D);
+    auto request_q = [&](V8 (&dst)[KS], int blk) {       // the fragments of query block `blk` (zeros past the last block / row)
+        const int nrow = (blk * NW + wave) * 32 + l31;
+        load_q_frags_buf<T, KS>(dst, srd_q, blk < cp.nqb && nrow < p.N ? (unsigned)((long)nrow * p.q_sn * 2) : OOB_OFF, hi, p.D);
+    };
+    request_q(qf, chunk);
 
     BiasRef bias;
-    bias.lds_row = tile + (long)(wave * 32 + l31) * cp.tile_stride * 4;
-    bias.lds_cols = p.bias_cols;
+    u32x4 bias_srd4 = {0u, 0u, 0u, 0u};
+    if (use_tile) bias_ref_tile(bias, tile, wave * 32 + l31, cp.tile_stride, p.bias_cols, hi);
+    // dense form, several blocks per workgroup: LDS-direct copies (no staging registers), double-buffered when cp.tile_nbuf == 2
+    const bool use_glds = !SINGLE && use_tile && !use_compact;
+    const int tcpr = cp.tile_stride >> 2;      // physical 16-byte chunks per tile row (4 / 8 / 16 / 32)
+    const unsigned trel0 = use_glds ? tile_glds_plan<NT>(tcpr, p.bias_cols, p.b_sn, tid) : 0u;
     const float *cbase = nullptr;
     const int *cidx = nullptr;
     if (maybe_biased && !use_compact) {
         const float *bbase = p.bias + b * p.b_sb + h * p.b_sh;
         const unsigned bytes = (unsigned)((((long)(p.N - 1) * p.b_sn + (long)(p.M - 1) * p.b_sm) + 1) * 4);
         bias.srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bbase), 0, bytes, 0x00020000);
+        const unsigned long long ba = (unsigned long long)bbase;       // the same descriptor as four words, for the LDS-direct copies
+        bias_srd4 = u32x4{(unsigned)ba, (unsigned)(ba >> 32) & 0xffffu, bytes, 0x00020000u};
         bias.key_stride = (unsigned)(p.b_sm * 4);
         bias.unit = p.b_sm == 1;
     }
@@ -216,10 +284,8 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
 
     // K and V of this head -> LDS (rows past M and the head-dim padding are zeros)
     for (int i = tid * 16; i < STAGE_BYTES; i += NT * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0u, 0u, 0u, 0u};
-    if (use_compact) {
-        const int tbytes = NW * 32 * cp.tile_stride * 4;
-        for (int i = tid * 16; i < tbytes; i += NT * 16) *reinterpret_cast<u32x4 *>(tile + i) = u32x4{0u, 0u, 0u, 0u};
-    }
+    if (use_compact)
+        for (int i = tid * 16; i < tile_bytes; i += NT * 16) *reinterpret_cast<u32x4 *>(tile + i) = u32x4{0u, 0u, 0u, 0u};
     {
         StagePlan<KPT, VPT> plan;
         make_plan<T, KS, DT, NT, NSUB, KPT, VPT>(plan, tid, p.D, p.k_sm, p.v_sm);
@@ -251,15 +317,20 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     const bool f_sum = f_all || p.stat_kind == PWW_STAT_MEAN || p.stat_kind == PWW_STAT_STD;
     const bool f_sq = f_all || p.stat_kind == PWW_STAT_STD;
     if (need_stat) {
-        // ---- pass 1: per query block (max, min, sum, sum of squares) of the raw scores, as pww_qk_reduce computes them
-        V8 qn[KS];
-        for (int qb = chunk; qb < cp.nqb; qb += cp.nchunk) {
+        // ---- pass 1: per query block (max, min, sum, sum of squares) of the raw scores, as pww_qk_reduce computes them.
+        // Several blocks per workgroup: a block's work here is short (9 MFMAs and a reduction), far shorter than a global load's
+        // latency, so the Q fragments run THREE blocks ahead (a ring of named register sets: q1, q2, q3); pass 1 holds no
+        // accumulators, the registers are there.
+        V8 q1[KS], q2[KS], q3[KS];
+        if constexpr (!SINGLE) {
+            request_q(q1, chunk + cp.nchunk);
+            request_q(q2, chunk + 2 * cp.nchunk);
+            request_q(q3, chunk + 3 * cp.nchunk);
+        }
+        int it = 0;
+        for (int qb = chunk; qb < cp.nqb; qb += cp.nchunk, ++it) {
             const int qrow = (qb * NW + wave) * 32 + l31;
             const bool qvalid = qrow < p.N;
-            if constexpr (!SINGLE) {       // next block's fragments fly while this block is scored
-                const int nrow = ((qb + cp.nchunk) * NW + wave) * 32 + l31;
-                load_q_frags<T, KS>(qn, Qp + (long)nrow * p.q_sn, qb + cp.nchunk < cp.nqb && nrow < p.N, hi, p.D);
-            }
             float vmax = -INFINITY, vmin = INFINITY, vsum = 0.f, vsq = 0.f;
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) {
@@ -299,19 +370,20 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
                 vsum += __shfl_xor(vsum, off);
                 vsq += __shfl_xor(vsq, off);
             }
-            __syncthreads();
+            // (two alternating buffers: thread 0 reads block i's partials while the waves write block i + 1's -- one barrier per block)
+            float *redp = red + (it & 1) * NW * 4;
             if (lane == 0) {
-                red[wave * 4 + 0] = vmax; red[wave * 4 + 1] = vmin;
-                red[wave * 4 + 2] = vsum; red[wave * 4 + 3] = vsq;
+                redp[wave * 4 + 0] = vmax; redp[wave * 4 + 1] = vmin;
+                redp[wave * 4 + 2] = vsum; redp[wave * 4 + 3] = vsq;
             }
             __syncthreads();
             if (tid == 0) {
                 double dmax = -INFINITY, dmin = INFINITY, dsum = 0.0, dsq = 0.0;
                 for (int w = 0; w < NW; ++w) {
-                    dmax = fmax(dmax, (double)red[w * 4 + 0]);
-                    dmin = fmin(dmin, (double)red[w * 4 + 1]);
-                    dsum += (double)red[w * 4 + 2];
-                    dsq += (double)red[w * 4 + 3];
+                    dmax = fmax(dmax, (double)redp[w * 4 + 0]);
+                    dmin = fmin(dmin, (double)redp[w * 4 + 1]);
+                    dsum += (double)redp[w * 4 + 2];
+                    dsq += (double)redp[w * 4 + 3];
                 }
                 unsigned long long *slot = cp.slots + ((long)b * cp.nqb * p.H + (long)qb * p.H + h) * 4;
                 slot_publish(slot + 0, dmax); slot_publish(slot + 1, dmin);
@@ -319,13 +391,15 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
             }
             if constexpr (!SINGLE) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
+                for (int ks = 0; ks < KS; ++ks) { qf[ks] = q1[ks]; q1[ks] = q2[ks]; q2[ks] = q3[ks]; }
+                request_q(q3, qb + 4 * cp.nchunk);
             }
         }
         tl_stamp(p, 2);
-        if constexpr (!SINGLE) {   // pass 2 starts over at the first block: request its fragments before the hand-off
-            const int qrow = (chunk * NW + wave) * 32 + l31;
-            load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qrow < p.N, hi, p.D);
+        if constexpr (!SINGLE) {   // pass 2 starts over at the first block: its fragments and its bias rows are requested before the hand-off
+            __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);     // (nothing is in flight any more -- the ring's last requests lie past the last block -- and hipcc should know)
+            request_q(qf, chunk);
+            if (use_glds) tile_glds<NT>(trel0, bias_srd4, tile, (long)chunk * NW * 32, p.b_sn, tcpr, wave);
         }
         // ---- hand-off + fold: every workgroup folds the image's partials itself (the order of pww_qk_reduce's
         // last-arriver fold), re-reading them until none is empty
@@ -391,19 +465,40 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     } else if (biased) {
         coeff = coeff_scalar_of(p);
         if (p.bias_coeff) coeff = coeff * gate;
+        if constexpr (!SINGLE)
+            if (use_glds) tile_glds<NT>(trel0, bias_srd4, tile, (long)chunk * NW * 32, p.b_sn, tcpr, wave);
     }
 
     // ---- pass 2: bias -> softmax -> PV per query block
+    // Dense bias rows with several blocks per workgroup (use_glds): block i's rows were copied into LDS (LDS-direct) while block
+    // i - 1 was computed -- every wave waits for its own copies (vmcnt) at the end of a block, before it issues the block's output
+    // stores, and ONE barrier at the top of the next block makes them visible and tells that the other buffer is free again. With a
+    // single buffer (tile_nbuf == 1) the copy can only start once every wave is done with the previous block: its latency shows.
     const float c1 = p.scale_log2e;
+    const bool glds_on = !SINGLE && use_glds && biased;          // workgroup-uniform
+    const bool two_buf = glds_on && cp.tile_nbuf == 2;
+    if constexpr (!SINGLE) {
+        if (glds_on) {
+            __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);     // the first block's rows (requested before the hand-off) have landed ...
+            __syncthreads();                                         // ... in every wave's part of the tile
+        }
+    }
     V8 qn[KS];
-    for (int qb = chunk; qb < cp.nqb; qb += cp.nchunk) {
+    int it2 = 0;
+    for (int qb = chunk; qb < cp.nqb; qb += cp.nchunk, ++it2) {
         const int qrow = (qb * NW + wave) * 32 + l31;
         const bool qvalid = qrow < p.N;
+        const char *cur_tile = tile + (two_buf && (it2 & 1) ? tile_bytes : 0);
         if constexpr (!SINGLE) {
-            const int nrow = ((qb + cp.nchunk) * NW + wave) * 32 + l31;
-            load_q_frags<T, KS>(qn, Qp + (long)nrow * p.q_sn, qb + cp.nchunk < cp.nqb && nrow < p.N, hi, p.D);
-            // this block's bias rows: requested now, they land under the first sub-tile's score MFMAs
-            if (biased && use_tile) tile_request<NT>(treg, use_compact, cbase, bias.srd, (long)qb * NW * 32, p.N, cp.c_sn, p.b_sn, cp.R, p.bias_cols, tid);
+            if (glds_on && it2 > 0) {
+                __syncthreads();              // every wave is done with block it2 - 1 (and has waited for its copies of this block's rows)
+                if (!two_buf) tile_glds<NT>(trel0, bias_srd4, tile, (long)qb * NW * 32, p.b_sn, tcpr, wave);
+            }
+            if (two_buf && qb + cp.nchunk < cp.nqb)
+                tile_glds<NT>(trel0, bias_srd4, tile + ((it2 & 1) ? 0 : tile_bytes), (long)(qb + cp.nchunk) * NW * 32, p.b_sn, tcpr, wave);
+            request_q(qn, qb + cp.nchunk);
+            // compact form: this block's values are requested now, they land under the first sub-tile's score MFMAs
+            if (biased && use_compact) tile_request<NT>(treg, true, cbase, bias.srd, (long)qb * NW * 32, p.N, cp.c_sn, p.b_sn, cp.R, p.bias_cols, tid);
         }
         if (biased && !use_tile) bias.row_off = qvalid ? (unsigned)((long)qrow * p.b_sn * 4) : OOB_OFF;
         f32x16 oacc[DT];
@@ -416,9 +511,15 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
             f32x16 s0[2];
             score_tile<T, KS>(s0, qf, smem, 0, p.M, l31, hi);
             if constexpr (!SINGLE) {
-                __syncthreads();            // every wave is done reading the previous block's rows
-                tile_park<NT>(treg, use_compact, tile, cp.tile_stride, cidx, bias.srd, (long)qb * NW * 32, p.N, p.b_sn, cp.R, p.bias_cols, tid);
-                __syncthreads();
+                if (use_compact) {
+                    __syncthreads();            // every wave is done reading the previous block's rows
+                    tile_park<NT>(treg, true, tile, cp.tile_stride, cidx, bias.srd, (long)qb * NW * 32, p.N, p.b_sn, cp.R, p.bias_cols, tid);
+                    __syncthreads();
+                } else if (!two_buf && it2 > 0) {
+                    __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
+                    __syncthreads();
+                }
+                if (use_glds) bias_ref_tile(bias, cur_tile, wave * 32 + l31, cp.tile_stride, p.bias_cols, hi);
             }
             attn_tile_sm_pv<T, KS, DT, 2, true, false>(s0, oacc, m_run, l_run, smem + KT::BYTES, 0, p.M, l31, hi, bias, coeff, c1);
             if (KVBLK < p.M)
@@ -436,13 +537,16 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
                 }
             }
         }
-        const float l_tot = l_run + __shfl_xor(l_run, 32);
-        const float inv = 1.f / l_tot;
-        store_o_block<T, DT>(Op + (long)(qvalid ? qrow : 0) * p.o_sn, oacc, inv, p.D, hi, qvalid, p.o_wide != 0);
         if constexpr (!SINGLE) {
+            // the next block's fragments and bias rows have had this block's compute to arrive: wait for them HERE, before the output
+            // stores are issued (a wait at the next barrier would also wait for the stores)
+            if (two_buf) __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
         }
+        const float l_tot = l_run + __shfl_xor(l_run, 32);
+        const float inv = 1.f / l_tot;
+        store_o_block<T, DT>(Op + (long)(qvalid ? qrow : 0) * p.o_sn, oacc, inv, p.D, hi, qvalid, p.o_wide != 0);
     }
     tl_stamp(p, 4);
 
@@ -506,22 +610,28 @@ static int fused_assume_resident() {   // PWW_CROSS_ASSUME_RESIDENT=n: TEST HOOK
     return n;
 }
 
-template <typename T, int KS, int DT, int NW>
+static int bias_tile_mode();
+static int tile_nbuf_mode() {   // PWW_CROSS_TILE_NBUF=1: never double-buffer the bias tile (A/B testing); default 2: when it costs no residency
+    static int mode = -1;
+    if (mode < 0) { const char *e = getenv("PWW_CROSS_TILE_NBUF"); mode = e ? atoi(e) : 2; if (mode != 1) mode = 2; }
+    return mode;
+}
+
+template <typename T, int KS, int DT, int NW, bool COMPACT>
 static int launch_cross(CrossParams cp, hipStream_t stream, bool *launched) {
-    constexpr size_t lds_fixed = 2 * (KTile<KS>::BYTES + VTile<DT>::BYTES) + NW * 4 * 8 + 4 * 8 + NW * 4 * 4 + 16 + COMPACT_MAX_R * 4;
-    const size_t lds = lds_fixed + (size_t)NW * 32 * cp.tile_stride * 4;
-    auto k_single = cross_fused_kernel<T, KS, DT, NW, true>;
-    auto k_multi = cross_fused_kernel<T, KS, DT, NW, false>;
-    // resident workgroups per CU for this LDS size (the tile width is a run-time value): asked once per size
-    static thread_local size_t lds_seen[8];
-    static thread_local int per_cu_seen[8];
+    constexpr size_t lds_fixed = 2 * (KTile<KS>::BYTES + VTile<DT>::BYTES) + NW * 4 * 8 + 4 * 8 + 2 * NW * 4 * 4 + 16 + COMPACT_MAX_R * 4;
+    const size_t tile_bytes = (size_t)NW * 32 * cp.tile_stride * 4;
+    auto k_single = cross_fused_kernel<T, KS, DT, NW, true, COMPACT>;
+    auto k_multi = cross_fused_kernel<T, KS, DT, NW, false, COMPACT>;
+    // resident workgroups per CU for an LDS size (the tile width is a run-time value): asked once per size
+    static thread_local size_t lds_seen[16];
+    static thread_local int per_cu_seen[16];
     static thread_local int n_seen = 0;
     static thread_local size_t lds_attr = 0;
-    int per_cu = -1;
-    for (int i = 0; i < n_seen; ++i) if (lds_seen[i] == lds) per_cu = per_cu_seen[i];
-    if (per_cu < 0) {
+    auto resident = [&](size_t lds, int *per_cu_out) -> int {
+        for (int i = 0; i < n_seen; ++i) if (lds_seen[i] == lds) { *per_cu_out = per_cu_seen[i]; return PWW_OK; }
         // (the kernels also own a few hundred bytes of static LDS: stay clear of the 160 KiB a workgroup can have)
-        if (lds > 156 * 1024) { *launched = false; return PWW_OK; }
+        if (lds > 156 * 1024) { *per_cu_out = 0; return PWW_OK; }
         if (lds > 64 * 1024 && lds > lds_attr) {
             for (auto kern : {k_single, k_multi})
                 if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
@@ -536,20 +646,39 @@ static int launch_cross(CrossParams cp, hipStream_t stream, bool *launched) {
         // every workgroup of the launch must be resident at once (the hand-off spins on partials of workgroups that have to be
         // running). The occupancy answer can be one high near an SGPR edge when it says 7 or 8 (MI355X_MICROARCH.md); this
         // kernel's answers are LDS / VGPR bound (<= 4) and taken as they are, up to 4.
-        per_cu = n1 < n2 ? n1 : n2;
+        int per_cu = n1 < n2 ? n1 : n2;
         if (per_cu >= 7) per_cu -= 1;
         if (per_cu > fused_wg_cap()) per_cu = fused_wg_cap();
         if (fused_assume_resident()) per_cu = fused_assume_resident();
-        if (n_seen < 8) { lds_seen[n_seen] = lds; per_cu_seen[n_seen] = per_cu; ++n_seen; }
-    }
+        if (n_seen < 16) { lds_seen[n_seen] = lds; per_cu_seen[n_seen] = per_cu; ++n_seen; }
+        *per_cu_out = per_cu;
+        return PWW_OK;
+    };
+    size_t lds = lds_fixed + tile_bytes;
+    int per_cu = 0;
+    if (int rc = resident(lds, &per_cu)) return rc;
     const AttnParams &p = cp.a;
-    const long cap = (long)per_cu * device_cus();
     const long BH = (long)p.B * p.H;
     cp.nqb = (p.N + NW * 32 - 1) / (NW * 32);
+    const long cap = (long)per_cu * device_cus();
     if (cap < BH) { *launched = false; return PWW_OK; }      // cannot be made resident: the caller takes the two-launch path
     long nchunk = cap / BH;
     if (nchunk > cp.nqb) nchunk = cp.nqb;
     cp.nchunk = (int)nchunk;
+    cp.tile_nbuf = 1;
+    if (!COMPACT && cp.nchunk < cp.nqb && cp.tile_stride > 0 && ((NW == 2 && cp.tile_stride > 32) || bias_tile_mode() == 1)) {
+        // (the LDS-direct plan needs NT / chunks-per-row to be a multiple of the swizzle period: 128 threads x 16 chunks is not --
+        // the narrow workgroups keep per-lane loads there; smaller LDS, so the residency answer above still holds)
+        lds -= tile_bytes;
+        cp.tile_stride = 0;
+    }
+    if (cp.nchunk < cp.nqb && cp.tile_stride > 0 && !cp.compact && tile_nbuf_mode() == 2) {
+        // several blocks per workgroup, dense tile: a second buffer lets the next block's rows load under this block's compute --
+        // taken when it does not cost a resident workgroup per CU
+        int per_cu2 = 0;
+        if (int rc = resident(lds + tile_bytes, &per_cu2)) return rc;
+        if (per_cu2 >= per_cu) { cp.tile_nbuf = 2; lds += tile_bytes; }
+    }
     const dim3 grid((unsigned)(BH * nchunk));
     if (cp.nchunk == cp.nqb) launch_attn_kernel(k_single, grid, dim3(NW * 64), lds, stream, cp);
     else launch_attn_kernel(k_multi, grid, dim3(NW * 64), lds, stream, cp);
@@ -557,16 +686,19 @@ static int launch_cross(CrossParams cp, hipStream_t stream, bool *launched) {
     return check_hip(hipGetLastError(), "cross_fused_kernel launch");
 }
 
-template <typename T, int NW> static int dispatch_cross_d(const CrossParams &cp, hipStream_t s, bool *launched) {
+template <typename T, int NW, bool COMPACT> static int dispatch_cross_d(const CrossParams &cp, hipStream_t s, bool *launched) {
     const int D = cp.a.D;
-    if (D <= 48) return launch_cross<T, 3, 2, NW>(cp, s, launched);
-    if (D <= 64) return launch_cross<T, 4, 2, NW>(cp, s, launched);
-    if (D <= 80) return launch_cross<T, 5, 3, NW>(cp, s, launched);
-    if (D <= 96) return launch_cross<T, 6, 3, NW>(cp, s, launched);
+    if (D <= 48) return launch_cross<T, 3, 2, NW, COMPACT>(cp, s, launched);
+    if (D <= 64) return launch_cross<T, 4, 2, NW, COMPACT>(cp, s, launched);
+    if (D <= 80) return launch_cross<T, 5, 3, NW, COMPACT>(cp, s, launched);
+    if (D <= 96) return launch_cross<T, 6, 3, NW, COMPACT>(cp, s, launched);
     if constexpr (NW == 2) { set_error("cross_attn_fused: internal dispatch error"); return PWW_EINVAL; } else {
-        if (D <= 128) return launch_cross<T, 8, 4, NW>(cp, s, launched);
-        return launch_cross<T, 10, 5, NW>(cp, s, launched);
+        if (D <= 128) return launch_cross<T, 8, 4, NW, COMPACT>(cp, s, launched);
+        return launch_cross<T, 10, 5, NW, COMPACT>(cp, s, launched);
     }
+}
+template <typename T, int NW> static int dispatch_cross_form(const CrossParams &cp, hipStream_t s, bool *launched) {
+    return cp.compact ? dispatch_cross_d<T, NW, true>(cp, s, launched) : dispatch_cross_d<T, NW, false>(cp, s, launched);
 }
 
 // scratch of the two-launch path (pww_qk_reduce's workspace followed by its [B][4] statistics): only touched when the
@@ -584,9 +716,12 @@ size_t cross_fused_state_bytes(const pww_attn_desc_t *d) {
     return state_sync_bytes(d) + (size_t)d->B * ((d->N + 63) / 64) * d->H * 4 * sizeof(unsigned long long);
 }
 
-static int bias_tile_mode() {   // PWW_CROSS_BIAS_LDS=0: per-lane global bias loads as in round 2 (A/B testing); default: LDS tile
+// PWW_CROSS_BIAS_LDS (A/B testing): 0 = per-lane global bias loads as in round 2; 1 = LDS tile only in launches with one query block per
+// workgroup (register-staged), several blocks per workgroup keep the per-lane loads; 2 (default) = LDS tile everywhere (several blocks
+// per workgroup: LDS-direct copies)
+static int bias_tile_mode() {
     static int mode = -2;
-    if (mode == -2) { const char *e = getenv("PWW_CROSS_BIAS_LDS"); mode = e ? atoi(e) : 1; }
+    if (mode == -2) { const char *e = getenv("PWW_CROSS_BIAS_LDS"); mode = e ? atoi(e) : 2; }
     return mode;
 }
 
@@ -636,17 +771,20 @@ int cross_attn_fused(const void *q, const void *k, const void *v, void *o, const
     // The LDS tile needs unit key stride (dense form) or the compact form, and it pays when the map is NARROW: measured (MI355X,
     // N = 4096, d = 40) 16 folded rows 73.6 us with a 32-column tile vs 81.8 us with per-lane loads, but 126 us with all 80 columns
     // staged (82 KB of LDS: one workgroup per CU, two slabs fetched without prefetch) -- so a dense map without a column bound of
-    // at most 48 keeps the per-lane loads. PWW_CROSS_BIAS_LDS=0: per-lane loads always (A/B), =2: tile whatever the width.
-    const bool tile_ok = compact || (d->bias_stride[3] == 1 && (bias_tile_mode() == 2 || (bias_tile_mode() == 1 && bias_cols <= 48)));
-    cp.tile_stride = tile_ok ? bias_cols + 4 : 0;
+    // at most 48 keeps the per-lane loads (wider tiles would cost a resident workgroup per CU). PWW_CROSS_BIAS_LDS=0: per-lane loads (A/B).
+    const bool tile_ok = compact || (d->bias_stride[3] == 1 && bias_tile_mode() != 0 && bias_cols <= 48);
+    int tile_stride = 16;
+    while (tile_stride < bias_cols) tile_stride *= 2;
+    cp.tile_stride = tile_ok ? tile_stride : 0;
+    cp.tile_nbuf = 1;
     cp.compact = compact ? op.bias_compact : nullptr;
     cp.col_idx = op.col_idx; cp.R = op.R;
     cp.c_sb = op.compact_stride[0]; cp.c_sn = op.compact_stride[1]; cp.ci_sb = op.col_idx_stride;
     bool launched = false;
     const bool wide = attn_wide_groups(d);
     int rc;
-    if (d->dtype == PWW_DTYPE_F16) rc = wide ? dispatch_cross_d<f16, 4>(cp, stream, &launched) : dispatch_cross_d<f16, 2>(cp, stream, &launched);
-    else rc = wide ? dispatch_cross_d<bf16, 4>(cp, stream, &launched) : dispatch_cross_d<bf16, 2>(cp, stream, &launched);
+    if (d->dtype == PWW_DTYPE_F16) rc = wide ? dispatch_cross_form<f16, 4>(cp, stream, &launched) : dispatch_cross_form<f16, 2>(cp, stream, &launched);
+    else rc = wide ? dispatch_cross_form<bf16, 4>(cp, stream, &launched) : dispatch_cross_form<bf16, 2>(cp, stream, &launched);
     if (rc || launched) return rc;
     // more (image, head) pairs than resident workgroups: statistic and attention as two launches, same arithmetic
     if (!bias) { set_error("cross_attn_fused: this launch cannot be made resident (B*H = %d) and the two-launch path needs the dense bias map", d->B * d->H); return PWW_ENOTSUP; }

@@ -537,6 +537,9 @@ int main(int argc, char **argv) {
         {"sd15_cross_n4096_d40_cols32", PWW_DTYPE_BF16, 2, 8, 4096, 77, 40, 1, false, 97, 1.0f, 0.f, 32, 9},
         {"sd15_cross_n4096_d40_b16_cols32", PWW_DTYPE_BF16, 16, 8, 4096, 77, 40, 1, false, 397, 1.0f, 0.f, 32, 9},
         {"sd15_cross_n4096_f16_b16_cols48", PWW_DTYPE_F16, 16, 8, 4096, 77, 40, 1, false, 397, 1.0f, 0.f, 48, 17},
+        {"sd15_cross_n4096_d40_b16_cols16", PWW_DTYPE_BF16, 16, 8, 4096, 77, 40, 1, false, 397, 1.0f, 0.f, 16, 4},     // narrowest tile: 2 LDS-direct copies per thread
+        {"cross_n3990_d40_b16_cols32_ragged", PWW_DTYPE_F16, 16, 8, 3990, 77, 40, 1, false, 397, 1.0f, 0.f, 32, 9},      // several blocks per workgroup, last block ragged (rows past N arrive as zeros)
+        {"cross_n2000_d64_b20_cols48_ragged", PWW_DTYPE_BF16, 20, 5, 2000, 77, 64, 1, false, 211, 0.8f, 0.f, 48, 17},    // odd block count per workgroup, 64-float tile rows, padding chunks
         {"sd15_cross_n1024_d80_cols32", PWW_DTYPE_BF16, 2, 8, 1024, 77, 80, 1, false, 17, 0.7f, 0.f, 32, 5},
         {"sd15_cross_n1024_d80_b16_cols48", PWW_DTYPE_F16, 16, 8, 1024, 77, 80, 1, false, 67, 0.7f, 0.f, 48, 17},
         {"sd15_cross_n256_d160_cols32", PWW_DTYPE_F16, 2, 8, 256, 77, 160, 1, false, 3, 0.5f, 0.f, 32, 9},
