@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define PWW_VERSION 120 /* 0.1.20: + pww_cross_attn_fwd_fused_ex / pww_cross_attn_fwd_stat_ex (pww_cross_opts_t: device-side coefficient word, bias column bound,
+#define PWW_VERSION 121 /* 0.1.21: pww_cross_opts_t.gated_images (was padding); 0.1.20: + pww_cross_attn_fwd_fused_ex / pww_cross_attn_fwd_stat_ex (pww_cross_opts_t: device-side coefficient word, bias column bound,
                            compact bias), pww_debug_timeline (0.1.11: pww_profile_*; 0.1.10: fused cross-attention, blur, resize, inpaint prep) */
 
 #define PWW_OK 0
@@ -178,6 +178,11 @@ size_t pww_cross_fused_workspace_bytes(const pww_attn_desc_t *desc);
  *                     (a launch that cannot be made resident then fails with PWW_ENOTSUP).
  *   col_idx           int32 [B?][R] (image stride col_idx_stride, 0 = shared): the column of compact slot r, or -1 = unused.
  *                     bias_cols must cover max(col_idx) + 1 (0 = M).
+ *   gated_images      (version >= 121; the field was padding before) the caller's hint that gate[b] != 0 exactly for b < gated_images
+ *                     -- a CFG-folded batch [conditional rows; unconditional rows] (paint_with_words.py:479-489 as one call). The
+ *                     gated-in images carry the statistic, the hand-off and the bias work; the launch gives them more, shorter
+ *                     workgroups so that all workgroups finish together. 0 = unknown. A wrong hint costs time, never correctness:
+ *                     the kernel still reads gate[].
  */
 typedef struct pww_cross_opts {
     uint32_t size;
@@ -186,7 +191,7 @@ typedef struct pww_cross_opts {
     const float *bias_compact;
     const int32_t *col_idx;
     int32_t R;
-    int32_t _pad;
+    int32_t gated_images;
     int64_t compact_stride[2];   /* image, row (elements) */
     int64_t col_idx_stride;      /* image (elements) */
 } pww_cross_opts_t;

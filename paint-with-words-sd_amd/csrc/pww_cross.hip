@@ -38,7 +38,10 @@ struct CrossParams {
                                  // heads_left[B], then the error word
     double *stats_out;   // optional [B][4]: the folded statistics of the gated-in images
     int nqb;             // query blocks per (image, head)
-    int nchunk;          // workgroups per (image, head)
+    int nchunk;          // workgroups per (image, head) -- of the first n_gated images when the caller gave that hint
+    int nchunk_u;        // workgroups per (image, head) of the images from n_gated on (== nchunk without the hint)
+    int n_gated;         // hint: gate[b] != 0 exactly for b < n_gated (0 = unknown): those images carry pass 1, the hand-off and the
+                         // bias work -- about three times the time per query block -- and get more, shorter workgroups
     // bias rows of a query block staged in LDS (tile_stride > 0): [NW * 32 rows][tile_stride floats], filled either from the
     // dense map (columns < a.bias_cols; the rows of a block are one contiguous span of the [N, M] map) or from the compact form
     int tile_stride;             // floats per tile row: bias_cols rounded up to a power of two (16 / 32 / 64 / 128; XOR-swizzled chunks: tile_swz); 0 = per-lane global loads
@@ -52,6 +55,7 @@ struct CrossParams {
 
 constexpr unsigned long long SPIN_LIMIT_TICKS = 100000000ull;   // wall_clock64 runs at 100 MHz: 1 s (the grid is sized to be resident:
                                                                 // the limit only bounds the impossible case, e.g. state words left dirty by an aborted launch)
+constexpr int RED_BLKS = 8;         // pass 1 folds the per-wave partials of up to 8 query blocks behind one barrier
 constexpr int COMPACT_MAX_R = 32;    // compact bias: at most 32 non-zero columns (16 staged values per thread)
 
 // a slot holds ~bits(value): zero = empty (no finite or infinite double has an all-ones bit pattern)
@@ -203,12 +207,12 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     constexpr int VPT = (NSUB * VT::NCHUNK + NT - 1) / NT;
     const AttnParams &p = cp.a;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [K|V stage][fin: NW x 4 f64][final: 4 f64][red: 2 x NW x 4 f32][flag][col_idx][bias tile(s)]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [K|V stage][fin: NW x 4 f64][final: 4 f64][red: 2 x RED_BLKS x NW x 4 f32][flag][col_idx][bias tile(s)]
     double *fin = reinterpret_cast<double *>(smem + STAGE_BYTES);
     double *final_st = fin + NW * 4;
-    float *red = reinterpret_cast<float *>(final_st + 4);          // two buffers, alternating by block: one barrier per block
-    volatile int *ok_flag = reinterpret_cast<volatile int *>(red + 2 * NW * 4);
-    int *cidx_lds = reinterpret_cast<int *>(red + 2 * NW * 4) + 4;             // COMPACT_MAX_R ints
+    float *red = reinterpret_cast<float *>(final_st + 4);          // pass 1: [2 groups][RED_BLKS blocks][NW waves][4] per-wave partials
+    volatile int *ok_flag = reinterpret_cast<volatile int *>(red + 2 * RED_BLKS * NW * 4);
+    int *cidx_lds = reinterpret_cast<int *>(red + 2 * RED_BLKS * NW * 4) + 4;             // COMPACT_MAX_R ints
     char *tile = reinterpret_cast<char *>(cidx_lds + COMPACT_MAX_R);
     const int tile_bytes = NW * 32 * cp.tile_stride * 4;
 
@@ -222,8 +226,13 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     // kernel share are the bias rows of a query block (the same [rows, 77] fp32 tile for all H heads of an image). With the plain
     // order (heads fastest) every XCD's L2 ends up fetching the whole map (measured: 11.9 MB fetched per launch for 6.7 MB of
     // distinct bytes); dealing query chunk c to XCD c % 8 for every head fetches each bias tile once.
-    int bh, chunk;
-    if ((cp.nchunk & 7) == 0) {
+    int bh, chunk, nchunk = cp.nchunk;
+    if (cp.n_gated > 0) {
+        // two classes of images (see CrossParams::n_gated): the workgroups of the hinted-in images come first
+        const int gh = cp.n_gated * p.H, first = gh * cp.nchunk;
+        if ((int)blockIdx.x < first) { bh = blockIdx.x % gh; chunk = blockIdx.x / gh; }
+        else { const int i = blockIdx.x - first, uh = BH - gh; bh = gh + i % uh; chunk = i / uh; nchunk = cp.nchunk_u; }
+    } else if ((cp.nchunk & 7) == 0) {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         bh = j % BH;
         chunk = (j / BH) * 8 + xcd;
@@ -318,19 +327,38 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     const bool f_sq = f_all || p.stat_kind == PWW_STAT_STD;
     if (need_stat) {
         // ---- pass 1: per query block (max, min, sum, sum of squares) of the raw scores, as pww_qk_reduce computes them.
-        // Several blocks per workgroup: a block's work here is short (9 MFMAs and a reduction), far shorter than a global load's
-        // latency, so the Q fragments run THREE blocks ahead (a ring of named register sets: q1, q2, q3); pass 1 holds no
-        // accumulators, the registers are there.
+        // Several blocks per workgroup: the Q fragments run THREE blocks ahead (a ring of named register sets: q1, q2, q3 -- pass 1
+        // holds no accumulators, the registers are there), and the per-block partials are folded in GROUPS of up to RED_BLKS blocks:
+        // every wave parks its four values per block in LDS, one barrier per group, then thread t folds the group's t-th block over
+        // the waves in fp64 (the order of pww_qk_reduce) and publishes it -- no barrier and no serial one-thread stretch per block.
         V8 q1[KS], q2[KS], q3[KS];
         if constexpr (!SINGLE) {
-            request_q(q1, chunk + cp.nchunk);
-            request_q(q2, chunk + 2 * cp.nchunk);
-            request_q(q3, chunk + 3 * cp.nchunk);
+            request_q(q1, chunk + nchunk);
+            request_q(q2, chunk + 2 * nchunk);
+            request_q(q3, chunk + 3 * nchunk);
         }
+        auto fold_group = [&](int grp, int nblk) {       // blocks grp * RED_BLKS ... + nblk - 1 of this workgroup (counted from its first)
+            __syncthreads();
+            if (tid < nblk) {
+                const float *rp = red + ((grp & 1) * RED_BLKS + tid) * NW * 4;
+                double dmax = -INFINITY, dmin = INFINITY, dsum = 0.0, dsq = 0.0;
+                for (int w = 0; w < NW; ++w) {
+                    dmax = fmax(dmax, (double)rp[w * 4 + 0]);
+                    dmin = fmin(dmin, (double)rp[w * 4 + 1]);
+                    dsum += (double)rp[w * 4 + 2];
+                    dsq += (double)rp[w * 4 + 3];
+                }
+                const int qb = chunk + (grp * RED_BLKS + tid) * nchunk;
+                unsigned long long *slot = cp.slots + ((long)b * cp.nqb * p.H + (long)qb * p.H + h) * 4;
+                slot_publish(slot + 0, dmax); slot_publish(slot + 1, dmin);
+                slot_publish(slot + 2, dsum); slot_publish(slot + 3, dsq);
+            }
+        };
         int it = 0;
-        for (int qb = chunk; qb < cp.nqb; qb += cp.nchunk, ++it) {
+        for (int qb = chunk; qb < cp.nqb; qb += nchunk, ++it) {
             const int qrow = (qb * NW + wave) * 32 + l31;
             const bool qvalid = qrow < p.N;
+            const bool rows_full = (qb * NW + wave) * 32 + 32 <= p.N;      // wave-uniform: every row of the wave is a real row
             float vmax = -INFINITY, vmin = INFINITY, vsum = 0.f, vsq = 0.f;
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) {
@@ -341,60 +369,69 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb) {
                         if (key0 + kb * 32 < p.M) {         // (a 32-key block past M holds no live key)
-                            if (f_max || f_min) {
+                            if (rows_full && key0 + kb * 32 + 32 <= p.M) {
+                                // every score of the block is live (all but the last key block of all but the last query block): no selects
+                                if (f_max) {
 #pragma unroll
-                                for (int r = 0; r < 16; ++r) {
-                                    const bool live = qvalid && (key0 + key_of(kb, r, hi) < p.M);
-                                    const float x = s[kb][r];
-                                    vmax = fmaxf(vmax, live ? x : -INFINITY);
-                                    vmin = fminf(vmin, live ? x : INFINITY);
+                                    for (int r = 0; r < 16; ++r) vmax = fmaxf(vmax, s[kb][r]);
                                 }
-                            }
-                            if (f_sum) {
+                                if (f_min) {
 #pragma unroll
-                                for (int r = 0; r < 16; ++r) {
-                                    const bool live = qvalid && (key0 + key_of(kb, r, hi) < p.M);
-                                    const float x = s[kb][r];
-                                    vsum += live ? x : 0.f;
-                                    vsq += live ? x * x : 0.f;
+                                    for (int r = 0; r < 16; ++r) vmin = fminf(vmin, s[kb][r]);
+                                }
+                                if (f_sum) {
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) { const float x = s[kb][r]; vsum += x; vsq += x * x; }
+                                }
+                            } else {
+                                if (f_max || f_min) {
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) {
+                                        const bool live = qvalid && (key0 + key_of(kb, r, hi) < p.M);
+                                        const float x = s[kb][r];
+                                        vmax = fmaxf(vmax, live ? x : -INFINITY);
+                                        vmin = fminf(vmin, live ? x : INFINITY);
+                                    }
+                                }
+                                if (f_sum) {
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) {
+                                        const bool live = qvalid && (key0 + key_of(kb, r, hi) < p.M);
+                                        const float x = s[kb][r];
+                                        vsum += live ? x : 0.f;
+                                        vsq += live ? x * x : 0.f;
+                                    }
                                 }
                             }
                         }
                     }
                 }
             }
+            if (f_max) {
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                vmax = fmaxf(vmax, __shfl_xor(vmax, off));
-                vmin = fminf(vmin, __shfl_xor(vmin, off));
-                vsum += __shfl_xor(vsum, off);
-                vsq += __shfl_xor(vsq, off);
+                for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
             }
-            // (two alternating buffers: thread 0 reads block i's partials while the waves write block i + 1's -- one barrier per block)
-            float *redp = red + (it & 1) * NW * 4;
+            if (f_min) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) vmin = fminf(vmin, __shfl_xor(vmin, off));
+            }
+            if (f_sum) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) { vsum += __shfl_xor(vsum, off); vsq += __shfl_xor(vsq, off); }
+            }
+            // (the groups alternate between two buffers: thread t still reads group g while the waves already park group g + 1)
             if (lane == 0) {
-                redp[wave * 4 + 0] = vmax; redp[wave * 4 + 1] = vmin;
-                redp[wave * 4 + 2] = vsum; redp[wave * 4 + 3] = vsq;
+                float *rp = red + ((((it / RED_BLKS) & 1) * RED_BLKS + it % RED_BLKS) * NW + wave) * 4;
+                rp[0] = vmax; rp[1] = vmin; rp[2] = vsum; rp[3] = vsq;
             }
-            __syncthreads();
-            if (tid == 0) {
-                double dmax = -INFINITY, dmin = INFINITY, dsum = 0.0, dsq = 0.0;
-                for (int w = 0; w < NW; ++w) {
-                    dmax = fmax(dmax, (double)redp[w * 4 + 0]);
-                    dmin = fmin(dmin, (double)redp[w * 4 + 1]);
-                    dsum += (double)redp[w * 4 + 2];
-                    dsq += (double)redp[w * 4 + 3];
-                }
-                unsigned long long *slot = cp.slots + ((long)b * cp.nqb * p.H + (long)qb * p.H + h) * 4;
-                slot_publish(slot + 0, dmax); slot_publish(slot + 1, dmin);
-                slot_publish(slot + 2, dsum); slot_publish(slot + 3, dsq);
-            }
+            if (it % RED_BLKS == RED_BLKS - 1) fold_group(it / RED_BLKS, RED_BLKS);
             if constexpr (!SINGLE) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) { qf[ks] = q1[ks]; q1[ks] = q2[ks]; q2[ks] = q3[ks]; }
-                request_q(q3, qb + 4 * cp.nchunk);
+                request_q(q3, qb + 4 * nchunk);
             }
         }
+        if (it % RED_BLKS) fold_group(it / RED_BLKS, it % RED_BLKS);
         tl_stamp(p, 2);
         if constexpr (!SINGLE) {   // pass 2 starts over at the first block: its fragments and its bias rows are requested before the hand-off
             __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);     // (nothing is in flight any more -- the ring's last requests lie past the last block -- and hipcc should know)
@@ -485,7 +522,7 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     }
     V8 qn[KS];
     int it2 = 0;
-    for (int qb = chunk; qb < cp.nqb; qb += cp.nchunk, ++it2) {
+    for (int qb = chunk; qb < cp.nqb; qb += nchunk, ++it2) {
         const int qrow = (qb * NW + wave) * 32 + l31;
         const bool qvalid = qrow < p.N;
         const char *cur_tile = tile + (two_buf && (it2 & 1) ? tile_bytes : 0);
@@ -494,9 +531,9 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
                 __syncthreads();              // every wave is done with block it2 - 1 (and has waited for its copies of this block's rows)
                 if (!two_buf) tile_glds<NT>(trel0, bias_srd4, tile, (long)qb * NW * 32, p.b_sn, tcpr, wave);
             }
-            if (two_buf && qb + cp.nchunk < cp.nqb)
-                tile_glds<NT>(trel0, bias_srd4, tile + ((it2 & 1) ? 0 : tile_bytes), (long)(qb + cp.nchunk) * NW * 32, p.b_sn, tcpr, wave);
-            request_q(qn, qb + cp.nchunk);
+            if (two_buf && qb + nchunk < cp.nqb)
+                tile_glds<NT>(trel0, bias_srd4, tile + ((it2 & 1) ? 0 : tile_bytes), (long)(qb + nchunk) * NW * 32, p.b_sn, tcpr, wave);
+            request_q(qn, qb + nchunk);
             // compact form: this block's values are requested now, they land under the first sub-tile's score MFMAs
             if (biased && use_compact) tile_request<NT>(treg, true, cbase, bias.srd, (long)qb * NW * 32, p.N, cp.c_sn, p.b_sn, cp.R, p.bias_cols, tid);
         }
@@ -556,7 +593,7 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     if (need_stat) {
         if (tid == 0) {
             int last = 0;
-            if (*ok_flag && depart_prev == (unsigned)cp.nchunk - 1u) {
+            if (*ok_flag && depart_prev == (unsigned)nchunk - 1u) {
                 const unsigned prev = __hip_atomic_fetch_add(cp.sync + p.B * p.H + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 last = prev == (unsigned)p.H - 1u;
             }
@@ -611,6 +648,11 @@ static int fused_assume_resident() {   // PWW_CROSS_ASSUME_RESIDENT=n: TEST HOOK
 }
 
 static int bias_tile_mode();
+static int gate_balance_weight() {   // PWW_CROSS_GATE_WEIGHT: cost of a gated-in image's query block in units of a gated-out one's (default 3; 1 = ignore the hint)
+    static int w = -1;
+    if (w < 0) { const char *e = getenv("PWW_CROSS_GATE_WEIGHT"); w = e ? atoi(e) : 3; if (w < 1) w = 1; }
+    return w;
+}
 static int tile_nbuf_mode() {   // PWW_CROSS_TILE_NBUF=1: never double-buffer the bias tile (A/B testing); default 2: when it costs no residency
     static int mode = -1;
     if (mode < 0) { const char *e = getenv("PWW_CROSS_TILE_NBUF"); mode = e ? atoi(e) : 2; if (mode != 1) mode = 2; }
@@ -619,7 +661,7 @@ static int tile_nbuf_mode() {   // PWW_CROSS_TILE_NBUF=1: never double-buffer th
 
 template <typename T, int KS, int DT, int NW, bool COMPACT>
 static int launch_cross(CrossParams cp, hipStream_t stream, bool *launched) {
-    constexpr size_t lds_fixed = 2 * (KTile<KS>::BYTES + VTile<DT>::BYTES) + NW * 4 * 8 + 4 * 8 + 2 * NW * 4 * 4 + 16 + COMPACT_MAX_R * 4;
+    constexpr size_t lds_fixed = 2 * (KTile<KS>::BYTES + VTile<DT>::BYTES) + NW * 4 * 8 + 4 * 8 + 2 * RED_BLKS * NW * 4 * 4 + 16 + COMPACT_MAX_R * 4;
     const size_t tile_bytes = (size_t)NW * 32 * cp.tile_stride * 4;
     auto k_single = cross_fused_kernel<T, KS, DT, NW, true, COMPACT>;
     auto k_multi = cross_fused_kernel<T, KS, DT, NW, false, COMPACT>;
@@ -664,23 +706,45 @@ static int launch_cross(CrossParams cp, hipStream_t stream, bool *launched) {
     if (cap < BH) { *launched = false; return PWW_OK; }      // cannot be made resident: the caller takes the two-launch path
     long nchunk = cap / BH;
     if (nchunk > cp.nqb) nchunk = cp.nqb;
-    cp.nchunk = (int)nchunk;
+    cp.nchunk = cp.nchunk_u = (int)nchunk;
+    const int hint = cp.n_gated;
+    cp.n_gated = 0;
+    if (hint > 0 && hint < p.B && nchunk < cp.nqb && gate_balance_weight() > 1) {
+        // The caller told which images carry the statistic and the bias (the conditional rows of a CFG-folded batch). A query block
+        // of theirs costs about three times one of the others (pass 1 + pass 2 with bias, vs pass 2 alone -- measured 7.2 vs 2.6 us),
+        // and a workgroup's lifetime is what the launch lasts: give those images c workgroups per head and the others u so that both
+        // kinds finish together, within the resident capacity (g * c + (B - g) * u <= cap / H).
+        const long per_head = cap / p.H, g = hint, rest = p.B - hint;
+        const int w = gate_balance_weight();
+        long best_c = nchunk, best_u = nchunk, best_cost = -1;
+        for (long c = 1; c <= cp.nqb; ++c) {
+            long u = (per_head - g * c) / rest;
+            if (u < 1) break;
+            if (u > cp.nqb) u = cp.nqb;
+            const long bc = (cp.nqb + c - 1) / c, bu = (cp.nqb + u - 1) / u;
+            const long cost = bc * w + 2 > bu ? bc * w + 2 : bu;        // (+2: the hand-off, in units of an unbiased block)
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_c = c; best_u = u; }
+        }
+        if (best_c != best_u) { cp.n_gated = hint; cp.nchunk = (int)best_c; cp.nchunk_u = (int)best_u; }
+    }
+    const long n_wgs = cp.n_gated ? (long)p.H * (cp.n_gated * (long)cp.nchunk + (p.B - cp.n_gated) * (long)cp.nchunk_u) : BH * nchunk;
+    const bool single = cp.nchunk == cp.nqb && cp.nchunk_u == cp.nqb;
     cp.tile_nbuf = 1;
-    if (!COMPACT && cp.nchunk < cp.nqb && cp.tile_stride > 0 && ((NW == 2 && cp.tile_stride > 32) || bias_tile_mode() == 1)) {
+    if (!COMPACT && !single && cp.tile_stride > 0 && ((NW == 2 && cp.tile_stride > 32) || bias_tile_mode() == 1)) {
         // (the LDS-direct plan needs NT / chunks-per-row to be a multiple of the swizzle period: 128 threads x 16 chunks is not --
         // the narrow workgroups keep per-lane loads there; smaller LDS, so the residency answer above still holds)
         lds -= tile_bytes;
         cp.tile_stride = 0;
     }
-    if (cp.nchunk < cp.nqb && cp.tile_stride > 0 && !cp.compact && tile_nbuf_mode() == 2) {
+    if (!single && cp.tile_stride > 0 && !cp.compact && tile_nbuf_mode() == 2) {
         // several blocks per workgroup, dense tile: a second buffer lets the next block's rows load under this block's compute --
         // taken when it does not cost a resident workgroup per CU
         int per_cu2 = 0;
         if (int rc = resident(lds + tile_bytes, &per_cu2)) return rc;
         if (per_cu2 >= per_cu) { cp.tile_nbuf = 2; lds += tile_bytes; }
     }
-    const dim3 grid((unsigned)(BH * nchunk));
-    if (cp.nchunk == cp.nqb) launch_attn_kernel(k_single, grid, dim3(NW * 64), lds, stream, cp);
+    const dim3 grid((unsigned)n_wgs);
+    if (single) launch_attn_kernel(k_single, grid, dim3(NW * 64), lds, stream, cp);
     else launch_attn_kernel(k_multi, grid, dim3(NW * 64), lds, stream, cp);
     *launched = true;
     return check_hip(hipGetLastError(), "cross_fused_kernel launch");
@@ -767,7 +831,8 @@ int cross_attn_fused(const void *q, const void *k, const void *v, void *o, const
     cp.sync = reinterpret_cast<unsigned *>(state);
     cp.slots = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(state) + state_sync_bytes(d));
     cp.stats_out = stats_out;
-    cp.nqb = cp.nchunk = 0;
+    cp.nqb = cp.nchunk = cp.nchunk_u = 0;
+    cp.n_gated = op.gated_images > 0 && op.gated_images < d->B ? op.gated_images : 0;
     // The LDS tile needs unit key stride (dense form) or the compact form, and it pays when the map is NARROW: measured (MI355X,
     // N = 4096, d = 40) 16 folded rows 73.6 us with a 32-column tile vs 81.8 us with per-lane loads, but 126 us with all 80 columns
     // staged (82 KB of LDS: one workgroup per CU, two slabs fetched without prefetch) -- so a dense map without a column bound of

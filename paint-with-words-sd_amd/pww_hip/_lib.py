@@ -33,7 +33,7 @@ class AttnDesc(ctypes.Structure):
 class CrossOpts(ctypes.Structure):
     """struct pww_cross_opts (optional arguments of the *_ex cross-attention entry points)."""
     _fields_ = [("size", ctypes.c_uint32), ("bias_cols", ctypes.c_int32), ("coeff_scalar_dev", ctypes.c_void_p),
-                ("bias_compact", ctypes.c_void_p), ("col_idx", ctypes.c_void_p), ("R", ctypes.c_int32), ("_pad", ctypes.c_int32),
+                ("bias_compact", ctypes.c_void_p), ("col_idx", ctypes.c_void_p), ("R", ctypes.c_int32), ("gated_images", ctypes.c_int32),
                 ("compact_stride", ctypes.c_int64 * 2), ("col_idx_stride", ctypes.c_int64)]
 
 
@@ -101,8 +101,8 @@ def load():
                  "pww_cross_attn_fwd_stat_ex", "pww_cross_attn_fwd_fused_ex", "pww_qk_reduce", "pww_mask_build",
                  "pww_mask_build_rgb", "pww_mask_build_f32", "pww_resize_tokens", "pww_gauss_blur", "pww_inpaint_prep", "pww_cfg_combine"):
         getattr(lib, name).restype = ctypes.c_int
-    if lib.pww_version() // 100 != 1 or lib.pww_version() < 120:
-        raise PwwHipError("libpww_hip ABI version %d is not 1.x >= 1.20 (rebuild: python paint-with-words-sd_amd/build.py)" % lib.pww_version())
+    if lib.pww_version() // 100 != 1 or lib.pww_version() < 121:
+        raise PwwHipError("libpww_hip ABI version %d is not 1.x >= 1.21 (rebuild: python paint-with-words-sd_amd/build.py)" % lib.pww_version())
     _lib = lib
     return lib
 

@@ -28,6 +28,7 @@ COEFF_SLOTS = "_PWW_COEFF_SLOTS"   # private context key: CoeffSlots (hipGraph m
 BIAS_COLS = "_PWW_BIAS_COLS"       # private context key: int, columns >= this of every weight map of the context are zero
 COMPACT_W = "_PWW_COMPACT_W_"      # private context key prefix: compact form [N, R] (or [B, N, R]) of CROSS_ATTENTION_WEIGHT_<N>
 COMPACT_IDX = "_PWW_COMPACT_IDX"   # private context key: int32 [R] (or [B, R]) columns of the compact slots, -1 = unused
+GATED_ROWS = "_PWW_GATED_ROWS"     # private context key: int, _PWW_ROW_GATE is 1 for exactly the first so many rows, 0 after (a CFG-folded batch)
 # statistic + attention in one launch (pww_cross_attn_fwd_fused); 0 = two launches (A/B). The fused launch needs all its workgroups
 # resident at once: two ranks sharing one device (PWW_DIST_ONE_DEVICE, a test mode) take the two-launch path.
 FUSED_CROSS = os.environ.get("PWW_FUSED_CROSS", "1") != "0" and os.environ.get("PWW_DIST_ONE_DEVICE", "0") != "1"
@@ -572,6 +573,7 @@ def pww_attention(attn, hidden_states, context=None):
     coeff_dev = None
     bias_cols = 0
     compact = None
+    gated = 0
     slots = context.get(COEFF_SLOTS) if (context is not None and is_dict) else None
     if isinstance(bias, LazyStat):     # a bare statistic: a per-image constant on every logit of a row cancels in softmax
         bias = None
@@ -583,6 +585,7 @@ def pww_attention(attn, hidden_states, context=None):
         kind, scalar = sym
         n_img, w_map = query.shape[1], bias.w
         bias_cols = int(context.get(BIAS_COLS, 0) or 0)
+        gated = int(context.get(GATED_ROWS, 0) or 0) if gate is not None else 0
         wc, ci = context.get(COMPACT_W + str(n_img)), context.get(COMPACT_IDX)
         if torch.is_tensor(wc) and torch.is_tensor(ci) and context.get(f"CROSS_ATTENTION_WEIGHT_{n_img}") is w_map:
             compact = (wc, ci)
@@ -624,7 +627,7 @@ def pww_attention(attn, hidden_states, context=None):
     if bias is None:
         return ops.attention(query, key, value, attn.heads, attn.scale)
     return ops.attention(query, key, value, attn.heads, attn.scale, bias=bias, bias_coeff=gate, stat=stat, scratch=scratch,
-                         coeff_dev=coeff_dev, bias_cols=bias_cols, compact=compact)
+                         coeff_dev=coeff_dev, bias_cols=bias_cols, compact=compact, gated=gated)
 
 
 def inj_forward(self, hidden_states, context=None, mask=None):

@@ -177,13 +177,14 @@ def check_fused_errors(modules):
         raise PwwHipError(_TIMEOUT_MESSAGE)
 
 
-def _cross_opts(B, N, coeff_dev, bias_cols, compact, keep):
+def _cross_opts(B, N, coeff_dev, bias_cols, compact, keep, gated=0):
     """pww_cross_opts_t for the *_ex entry points (None if nothing optional is asked for)."""
-    if coeff_dev is None and not bias_cols and compact is None:
+    if coeff_dev is None and not bias_cols and compact is None and not gated:
         return None
     op = CrossOpts()
     op.size = ctypes.sizeof(CrossOpts)
     op.bias_cols = int(bias_cols or 0)
+    op.gated_images = int(gated or 0)
     if coeff_dev is not None:
         if coeff_dev.dtype != torch.float32 or coeff_dev.numel() != 1 or not coeff_dev.is_cuda:
             raise PwwHipError("coeff_dev must be a one-element float32 device tensor")
@@ -210,7 +211,7 @@ COMPACT_MAX_R = 32     # pww_cross.hip: the compact form holds at most 32 non-ze
 
 
 def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None, scratch=None, stats_out=None, coeff_dev=None,
-              bias_cols=0, compact=None):
+              bias_cols=0, compact=None, gated=0):
     """softmax((Q K^T + c * bias) * scale) V on [B, tokens, heads*D] tensors (diffusers layout, no
     head-split copies). bias: fp32 tensor broadcastable to [B, heads, N, M] or None;
     bias_coeff: optional fp32 [B] device tensor of per-image coefficients (with `stat`: the row gate);
@@ -219,7 +220,8 @@ def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None, scra
     FusedScratch in `scratch`: the statistic is then computed in the same launch (pww_cross_attn_fwd_fused, M <= 128).
     With `stat`: coeff_dev = one-element fp32 device tensor that replaces the python scalar when the kernel runs (hipGraph
     replays across denoise steps); bias_cols = columns >= bias_cols of the map are zero; compact = (values [B?, N, R] fp32,
-    col_idx [B?, R] int32) the compact form of the same map (fused launch only)."""
+    col_idx [B?, R] int32) the compact form of the same map (fused launch only); gated = the caller's hint that bias_coeff is
+    non-zero exactly for the first `gated` images (a CFG-folded batch), 0 = unknown (fused launch only: work distribution)."""
     _require_gpu(q, k, v, bias, bias_coeff)
     if not (q.dtype == k.dtype == v.dtype):
         raise PwwHipError("q/k/v dtypes differ: %s %s %s" % (q.dtype, k.dtype, v.dtype))
@@ -256,7 +258,7 @@ def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None, scra
                 keep = []
                 if compact is not None and compact[0].shape[-1] > COMPACT_MAX_R:
                     compact = None
-                op = _cross_opts(B, N, coeff_dev, bias_cols, compact, keep)
+                op = _cross_opts(B, N, coeff_dev, bias_cols, compact, keep, gated)
                 rc = lib.pww_cross_attn_fwd_fused_ex(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(bias), int(kind), float(scalar),
                                                      _ptr(bias_coeff), ctypes.byref(d), _ptr(stats_out), _ptr(state), state.numel() * 8,
                                                      _ptr(ws), ws.numel() * 8, ctypes.byref(op) if op is not None else None, _stream())

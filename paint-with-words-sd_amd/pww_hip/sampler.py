@@ -18,7 +18,7 @@ Three execution modes over the SAME arithmetic:
 import torch
 
 from . import ops
-from .attention import install, refresh_kv_cache, refresh_orig_cache, ROW_GATE, KV_CACHE, COEFF_SLOTS, CoeffSlots, COMPACT_W, COMPACT_IDX
+from .attention import install, refresh_kv_cache, refresh_orig_cache, ROW_GATE, KV_CACHE, COEFF_SLOTS, CoeffSlots, COMPACT_W, COMPACT_IDX, GATED_ROWS
 
 
 def initial_latents(seed, in_channels, height, width, region_masks=None, extra_seeds=None, batch_seeds=None):
@@ -69,6 +69,7 @@ def _fold_context(cond, uncond, n_images, device):
     folded.pop("_PWW_ORIG_CACHE", None)
     folded["CONTEXT_TENSOR"] = torch.cat([rows(conds), rows(unconds)], dim=0).contiguous()
     folded[ROW_GATE] = torch.cat([torch.ones(n_images), torch.zeros(n_images)]).to(device=device, dtype=torch.float32)
+    folded[GATED_ROWS] = n_images        # what the gate holds, for the host side (work distribution of the fused launch)
     if not shared:
         for key in [k for k in conds[0] if k.startswith("CROSS_ATTENTION_WEIGHT_")]:
             maps = [c[key] for c in conds]

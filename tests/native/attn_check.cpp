@@ -234,7 +234,7 @@ static void run_case(const Case &c, bool timing) {
             HIPCHECK(hipDeviceSynchronize());
             std::vector<uint16_t> h1(q.size()), h2(q.size());
             HIPCHECK(hipMemcpy(h1.data(), o1, h1.size() * 2, hipMemcpyDeviceToHost));
-            for (int variant = 0; variant < 5; ++variant) {
+            for (int variant = 0; variant < 8; ++variant) {
                 pww_cross_opts_t op; memset(&op, 0, sizeof(op)); op.size = sizeof(op);
                 const float *use_bias = dbias;
                 const char *what = "";
@@ -242,7 +242,12 @@ static void run_case(const Case &c, bool timing) {
                 else if (variant == 1) { if (!c.bias_cols) continue; op.bias_cols = c.bias_cols; what = "bias_cols"; }
                 else if (variant == 2) { if (!R) continue; op.bias_compact = dcompact; op.col_idx = dcidx; op.R = R; op.compact_stride[1] = R; op.bias_cols = c.bias_cols; what = "compact + dense"; }
                 else if (variant == 3) { if (!R) continue; op.bias_compact = dcompact; op.col_idx = dcidx; op.R = R; op.compact_stride[1] = R; op.bias_cols = c.bias_cols; use_bias = nullptr; what = "compact only"; }
-                else { op.coeff_scalar_dev = dscalar; op.bias_cols = c.bias_cols; if (R) { op.bias_compact = dcompact; op.col_idx = dcidx; op.R = R; op.compact_stride[1] = R; } what = "all options"; }
+                else if (variant == 4) { op.coeff_scalar_dev = dscalar; op.bias_cols = c.bias_cols; if (R) { op.bias_compact = dcompact; op.col_idx = dcidx; op.R = R; op.compact_stride[1] = R; } what = "all options"; }
+                // the gated-images hint only moves work between workgroups: right (all but the last image), wrong (1 although more are
+                // gated in: the others just get the short end), and with the compact form
+                else if (variant == 5) { if (B < 2) continue; op.gated_images = B - 1; op.bias_cols = c.bias_cols; what = "gated_images = B - 1 (right)"; }
+                else if (variant == 6) { if (B < 3) continue; op.gated_images = 1; op.bias_cols = c.bias_cols; what = "gated_images = 1 (wrong)"; }
+                else { if (B < 2 || !R) continue; op.gated_images = B - 1; op.bias_cols = c.bias_cols; op.bias_compact = dcompact; op.col_idx = dcidx; op.R = R; op.compact_stride[1] = R; what = "gated_images + compact"; }
                 HIPCHECK(hipMemset(o2, 0xee, q.size() * 2));
                 int r2 = pww_cross_attn_fwd_fused_ex(dq, dk, dv, o2, use_bias, PWW_STAT_MAX, op.coeff_scalar_dev ? -1.f : s0, dgate, &d, nullptr, dsync, sync_bytes, fws, fws_bytes, &op, nullptr);
                 HIPCHECK(hipDeviceSynchronize());
@@ -274,8 +279,8 @@ static void run_case(const Case &c, bool timing) {
             std::vector<float> gate(coeff); if (B > 1) for (int b = B / 2; b < B; ++b) gate[b] = 0.f;     // folded CFG batch: second half unconditional
             HIPCHECK(hipMemcpy(dgate, gate.data(), B * 4, hipMemcpyHostToDevice));
             if (g_timeline) {
-                pww_cross_opts_t op; memset(&op, 0, sizeof(op)); op.size = sizeof(op); op.bias_cols = c.bias_cols;
-                timeline_report(c.name, "fused cross-attention (stamps: 0 entry, 1 K/V staged, 2 partials published, 3 statistic folded, 4 outputs stored, 5 exit)", [&]() {
+                pww_cross_opts_t op; memset(&op, 0, sizeof(op)); op.size = sizeof(op); op.bias_cols = c.bias_cols; op.gated_images = B > 1 ? B / 2 : 0;
+                timeline_report(c.name, "fused cross-attention with bias_cols and the gated-images hint (stamps: 0 entry, 1 K/V staged, 2 partials published, 3 statistic folded, 4 outputs stored, 5 exit)", [&]() {
                     pww_cross_attn_fwd_fused_ex(dq, dk, dv, o2, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, nullptr, dsync, sync_bytes, fws, fws_bytes, &op, nullptr); });
             }
             float ms_f = 0, ms_s = 0;
@@ -300,6 +305,17 @@ static void run_case(const Case &c, bool timing) {
                 HIPCHECK(hipEventRecord(e1, nullptr)); HIPCHECK(hipEventSynchronize(e1));
                 HIPCHECK(hipEventElapsedTime(&ms_e, e0, e1));
                 printf("TIME %-28s fused_ex with bias_cols=%d: %.2f us/call\n", c.name, c.bias_cols, ms_e * 1e3 / iters);
+                if (B > 1) {               // what the product passes for a CFG-folded batch: + the hint that the first half is gated in
+                    op.gated_images = B / 2;
+                    for (int i = 0; i < 5 + iters; ++i) {
+                        if (i == 5) HIPCHECK(hipEventRecord(e0, nullptr));
+                        pww_cross_attn_fwd_fused_ex(dq, dk, dv, o2, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, nullptr, dsync, sync_bytes, fws, fws_bytes, &op, nullptr);
+                    }
+                    HIPCHECK(hipEventRecord(e1, nullptr)); HIPCHECK(hipEventSynchronize(e1));
+                    HIPCHECK(hipEventElapsedTime(&ms_e, e0, e1));
+                    printf("TIME %-28s fused_ex with bias_cols=%d and gated_images=%d: %.2f us/call\n", c.name, c.bias_cols, B / 2, ms_e * 1e3 / iters);
+                    op.gated_images = 0;
+                }
                 if (!ccols.empty()) {      // the compact form of the same map
                     const int R = (int)ccols.size();
                     std::vector<float> comp((size_t)N * R);

@@ -368,7 +368,7 @@ def test_bias_hints_do_not_change_a_bit(gpu_device, shape, dtype, B):
 def test_opt_in_compact_maps_through_the_product(gpu_device, monkeypatch):
     """conditioning.COMPACT_BIAS (env PWW_COMPACT_BIAS=1) adds the compact [N, R] + col_idx form of every weight map to the
     conditional context; the folded batch stacks them and pww_attention hands them to the fused kernel. Off by default (slower
-    than the dense LDS tile in every measured shape); on, the latents must be bit-identical to the default route."""
+    than the dense LDS tile in every measured shape); on, the latents must equal the default route's."""
     import paint_with_words as pw
     from pww_hip import conditioning
     from pww_hip.attention import COMPACT_IDX
@@ -388,7 +388,12 @@ def test_opt_in_compact_maps_through_the_product(gpu_device, monkeypatch):
             assert COMPACT_IDX in sampler._static_folded and sampler._graphed.captures == 2     # new context tensors: re-captured once
     finally:
         uninstall_all()
-    assert torch.equal(on, base)
+    # (two separately captured graphs of the same UNet are not bitwise repeatable -- profiles/r02_determinism.md: the stock GEMM / conv
+    # kernels -- so the bar is the one of the other graph-vs-graph tests; the kernel-level bit-identity of the two forms is
+    # test_bias_hints_do_not_change_a_bit's. A wrong or missing compact map would move the latents by the whole PwW effect, > 1e-1.)
+    d = rel_l2(on, base)
+    print(f"compact maps through the product vs the dense route: rel-L2 {d:.3e}")
+    assert d <= 5e-3
 
 
 # ---- 8: the inpaint pipeline class, called --------------------------------------------------------------------------------------
