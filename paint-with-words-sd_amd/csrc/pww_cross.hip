@@ -108,15 +108,20 @@ __device__ __forceinline__ void tile_slab_store(const u32x4 (&reg)[4], char *til
     }
 }
 // LDS-direct form of the same copy (several query blocks per workgroup): `buffer_load_dwordx4 ... lds` writes lane-linear
-// (wave-uniform base + lane * 16), so thread t fills the physical chunks t + i * NT of the tile and the swizzle goes onto the
-// SOURCE address. No staging registers, and the copy of block i + 1 is in flight while block i is computed. The tile's physical row
-// is a power of two wide (4 / 8 / 16 chunks for 16 / 32 / 48 columns), so step i of a thread is the same chunk NT / cpr rows further
-// down -- which leaves the swizzle alone: ONE register (rel0 = the thread's source offset within a block, or OOB_OFF for the padding
-// chunks of a 48-column tile) describes all of a thread's copies. Rows past N lie beyond the descriptor's range and arrive as zeros.
-template <int NT>
-__device__ __forceinline__ unsigned tile_glds_plan(int cpr, int cols, long b_sn, int tid) {
-    const int row = tid / cpr, pc = tid - row * cpr, c = pc ^ tile_swz(row, cpr);
-    return c * 4 < cols ? (unsigned)((row * b_sn + c * 4) * 4) : OOB_OFF;
+// (wave-uniform base + lane * 16), so the swizzle goes onto the SOURCE address. No staging registers, and the copy of block i + 1
+// is in flight while block i is computed. EVERY WAVE COPIES ITS OWN 32 ROWS (a contiguous 32 * cpr * 16-byte piece of the tile, cpr / 2
+// copies of 1 KB): nobody else reads them, so the wave's own `s_waitcnt vmcnt` is all the synchronisation there is -- pass 2 has no
+// barrier. The tile's physical row is a power of two wide (4 / 8 / 16 chunks for 16 / 32 / 48 columns); copy i of a lane is the
+// same physical chunk 64 / cpr rows further down, and the swizzle repeats every 16 rows, i.e. every P = cpr / 4 copies: P source
+// offsets per lane (rel[j], or OOB_OFF for the padding chunks of a 48-column tile) describe all of them. Rows past N lie beyond the
+// descriptor's range and arrive as zeros.
+constexpr int TILE_GLDS_PERIOD_MAX = 4;
+__device__ __forceinline__ void tile_glds_plan(unsigned (&rel)[TILE_GLDS_PERIOD_MAX], int cpr, int cols, long b_sn, int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < TILE_GLDS_PERIOD_MAX; ++j) {
+        const int g = lane + j * 64, rowl = g / cpr, pc = g - rowl * cpr, row = wave * 32 + rowl, c = pc ^ tile_swz(row, cpr);
+        rel[j] = (j * 4 < cpr && c * 4 < cols) ? (unsigned)((row * b_sn + c * 4) * 4) : OOB_OFF;
+    }
 }
 // The copies are issued as inline assembly ON PURPOSE: hipcc orders every later LDS read behind an LDS-direct load it knows about
 // (it cannot tell the K / V fragment reads and the other tile buffer from the copy's destination) and would wait for the copy at
@@ -128,21 +133,20 @@ __device__ __forceinline__ void glds16(const u32x4 srd, unsigned lds_dst, unsign
     __asm__ volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(srd) : "memory");
 }
-template <int NT, int CNT>
-__device__ __forceinline__ void tile_glds_n(unsigned rel0, unsigned step, const u32x4 srd, unsigned lds_dst) {
+template <int CNT, int P>
+__device__ __forceinline__ void tile_glds_n(const unsigned (&rel)[TILE_GLDS_PERIOD_MAX], unsigned base, unsigned step16, const u32x4 srd, unsigned lds_dst) {
 #pragma unroll
-    for (int i = 0; i < CNT; ++i) glds16(srd, lds_dst + (unsigned)(i * NT * 16), rel0 + (unsigned)i * step);
+    for (int i = 0; i < CNT; ++i) glds16(srd, lds_dst + (unsigned)(i * 1024), base + rel[i % P] + (unsigned)(i / P) * step16);
 }
-// (one straight-line sequence per width: 2 / 4 / 8 copies per thread)
-template <int NT>
-__device__ __forceinline__ void tile_glds(unsigned rel0, const u32x4 srd, const char *tile, long row0, long b_sn, int cpr, int wave) {
+// (one straight-line sequence per width: 2 / 4 / 8 copies per lane)
+__device__ __forceinline__ void tile_glds(const unsigned (&rel)[TILE_GLDS_PERIOD_MAX], const u32x4 srd, const char *tile, long row0, long b_sn, int cpr, int wave) {
     typedef __attribute__((address_space(3))) const char *lds_cp;
-    const unsigned base = rel0 + (unsigned)(row0 * b_sn * 4);            // (OOB_OFF + anything below 2^31 stays out of range)
-    const unsigned step = (unsigned)((NT / cpr) * b_sn * 4);
-    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_cp)tile + (unsigned)(wave * 64 * 16));   // wave-uniform (an SGPR): each lane lands 16 bytes further
-    if (cpr == 4) tile_glds_n<NT, 2>(base, step, srd, lds_dst);
-    else if (cpr == 8) tile_glds_n<NT, 4>(base, step, srd, lds_dst);
-    else tile_glds_n<NT, 8>(base, step, srd, lds_dst);
+    const unsigned base = (unsigned)(row0 * b_sn * 4);                   // (OOB_OFF + anything below 2^31 stays out of range)
+    const unsigned step16 = (unsigned)(16 * b_sn * 4);                   // the swizzle's period: 16 rows
+    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_cp)tile + (unsigned)(wave * 32 * cpr * 16));   // the wave's own rows (an SGPR)
+    if (cpr == 4) tile_glds_n<2, 1>(rel, base, step16, srd, lds_dst);
+    else if (cpr == 8) tile_glds_n<4, 2>(rel, base, step16, srd, lds_dst);
+    else tile_glds_n<8, 4>(rel, base, step16, srd, lds_dst);
 }
 // compact form: rows x R contiguous floats of the block, scattered to their columns (the tile was zeroed once: columns outside
 // col_idx stay zero for the whole launch)
@@ -272,7 +276,8 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     // dense form, several blocks per workgroup: LDS-direct copies (no staging registers), double-buffered when cp.tile_nbuf == 2
     const bool use_glds = !SINGLE && use_tile && !use_compact;
     const int tcpr = cp.tile_stride >> 2;      // physical 16-byte chunks per tile row (4 / 8 / 16 / 32)
-    const unsigned trel0 = use_glds ? tile_glds_plan<NT>(tcpr, p.bias_cols, p.b_sn, tid) : 0u;
+    unsigned trel[TILE_GLDS_PERIOD_MAX] = {0u, 0u, 0u, 0u};
+    if (use_glds) tile_glds_plan(trel, tcpr, p.bias_cols, p.b_sn, wave, lane);
     const float *cbase = nullptr;
     const int *cidx = nullptr;
     if (maybe_biased && !use_compact) {
@@ -326,6 +331,9 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     const bool f_sum = f_all || p.stat_kind == PWW_STAT_MEAN || p.stat_kind == PWW_STAT_STD;
     const bool f_sq = f_all || p.stat_kind == PWW_STAT_STD;
     if (need_stat) {
+        // Everything up to the folded statistic is the launch's critical path (every workgroup of the image waits for the slowest
+        // pass 1): these waves go ahead of the co-resident workgroups that are already in pass 2 (unconditional rows have no pass 1).
+        __builtin_amdgcn_s_setprio(3);
         // ---- pass 1: per query block (max, min, sum, sum of squares) of the raw scores, as pww_qk_reduce computes them.
         // Several blocks per workgroup: the Q fragments run THREE blocks ahead (a ring of named register sets: q1, q2, q3 -- pass 1
         // holds no accumulators, the registers are there), and the per-block partials are folded in GROUPS of up to RED_BLKS blocks:
@@ -381,7 +389,11 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
                                 }
                                 if (f_sum) {
 #pragma unroll
-                                    for (int r = 0; r < 16; ++r) { const float x = s[kb][r]; vsum += x; vsq += x * x; }
+                                    for (int r = 0; r < 16; ++r) {       // (product and sum rounded separately, as in the select form -- and in pww_qk_reduce)
+                                        const float x = s[kb][r];
+                                        vsum += x;
+                                        vsq = __fadd_rn(vsq, __fmul_rn(x, x));
+                                    }
                                 }
                             } else {
                                 if (f_max || f_min) {
@@ -436,7 +448,7 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
         if constexpr (!SINGLE) {   // pass 2 starts over at the first block: its fragments and its bias rows are requested before the hand-off
             __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);     // (nothing is in flight any more -- the ring's last requests lie past the last block -- and hipcc should know)
             request_q(qf, chunk);
-            if (use_glds) tile_glds<NT>(trel0, bias_srd4, tile, (long)chunk * NW * 32, p.b_sn, tcpr, wave);
+            if (use_glds) tile_glds(trel, bias_srd4, tile, (long)chunk * NW * 32, p.b_sn, tcpr, wave);
         }
         // ---- hand-off + fold: every workgroup folds the image's partials itself (the order of pww_qk_reduce's
         // last-arriver fold), re-reading them until none is empty
@@ -498,27 +510,25 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
             if (p.bias_coeff) coeff = coeff * gate;
             if (!*ok_flag) coeff = __builtin_nanf("");     // a hand-off that timed out must not look like a result
         }
+        __builtin_amdgcn_s_setprio(0);
         tl_stamp(p, 3);
     } else if (biased) {
         coeff = coeff_scalar_of(p);
         if (p.bias_coeff) coeff = coeff * gate;
         if constexpr (!SINGLE)
-            if (use_glds) tile_glds<NT>(trel0, bias_srd4, tile, (long)chunk * NW * 32, p.b_sn, tcpr, wave);
+            if (use_glds) tile_glds(trel, bias_srd4, tile, (long)chunk * NW * 32, p.b_sn, tcpr, wave);
     }
 
     // ---- pass 2: bias -> softmax -> PV per query block
-    // Dense bias rows with several blocks per workgroup (use_glds): block i's rows were copied into LDS (LDS-direct) while block
-    // i - 1 was computed -- every wave waits for its own copies (vmcnt) at the end of a block, before it issues the block's output
-    // stores, and ONE barrier at the top of the next block makes them visible and tells that the other buffer is free again. With a
-    // single buffer (tile_nbuf == 1) the copy can only start once every wave is done with the previous block: its latency shows.
+    // Dense bias rows with several blocks per workgroup (use_glds): every wave copied ITS rows of block i into LDS (LDS-direct) while
+    // it computed block i - 1, and waits for those copies itself (vmcnt) at the end of block i - 1, before it issues that block's output
+    // stores (a later wait would also wait for the stores). No barrier: the waves of a workgroup drift apart freely. With a single
+    // buffer (tile_nbuf == 1) a wave can only start the copy when it is done with the previous block: its latency shows.
     const float c1 = p.scale_log2e;
     const bool glds_on = !SINGLE && use_glds && biased;          // workgroup-uniform
     const bool two_buf = glds_on && cp.tile_nbuf == 2;
     if constexpr (!SINGLE) {
-        if (glds_on) {
-            __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);     // the first block's rows (requested before the hand-off) have landed ...
-            __syncthreads();                                         // ... in every wave's part of the tile
-        }
+        if (glds_on) __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);     // the first block's rows (requested before the hand-off) have landed
     }
     V8 qn[KS];
     int it2 = 0;
@@ -527,12 +537,9 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
         const bool qvalid = qrow < p.N;
         const char *cur_tile = tile + (two_buf && (it2 & 1) ? tile_bytes : 0);
         if constexpr (!SINGLE) {
-            if (glds_on && it2 > 0) {
-                __syncthreads();              // every wave is done with block it2 - 1 (and has waited for its copies of this block's rows)
-                if (!two_buf) tile_glds<NT>(trel0, bias_srd4, tile, (long)qb * NW * 32, p.b_sn, tcpr, wave);
-            }
+            if (glds_on && !two_buf && it2 > 0) tile_glds(trel, bias_srd4, tile, (long)qb * NW * 32, p.b_sn, tcpr, wave);
             if (two_buf && qb + nchunk < cp.nqb)
-                tile_glds<NT>(trel0, bias_srd4, tile + ((it2 & 1) ? 0 : tile_bytes), (long)(qb + nchunk) * NW * 32, p.b_sn, tcpr, wave);
+                tile_glds(trel, bias_srd4, tile + ((it2 & 1) ? 0 : tile_bytes), (long)(qb + nchunk) * NW * 32, p.b_sn, tcpr, wave);
             request_q(qn, qb + nchunk);
             // compact form: this block's values are requested now, they land under the first sub-tile's score MFMAs
             if (biased && use_compact) tile_request<NT>(treg, true, cbase, bias.srd, (long)qb * NW * 32, p.N, cp.c_sn, p.b_sn, cp.R, p.bias_cols, tid);
@@ -554,7 +561,6 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
                     __syncthreads();
                 } else if (!two_buf && it2 > 0) {
                     __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
-                    __syncthreads();
                 }
                 if (use_glds) bias_ref_tile(bias, cur_tile, wave * 32 + l31, cp.tile_stride, p.bias_cols, hi);
             }
@@ -576,7 +582,7 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
         }
         if constexpr (!SINGLE) {
             // the next block's fragments and bias rows have had this block's compute to arrive: wait for them HERE, before the output
-            // stores are issued (a wait at the next barrier would also wait for the stores)
+            // stores are issued
             if (two_buf) __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
@@ -730,9 +736,8 @@ static int launch_cross(CrossParams cp, hipStream_t stream, bool *launched) {
     const long n_wgs = cp.n_gated ? (long)p.H * (cp.n_gated * (long)cp.nchunk + (p.B - cp.n_gated) * (long)cp.nchunk_u) : BH * nchunk;
     const bool single = cp.nchunk == cp.nqb && cp.nchunk_u == cp.nqb;
     cp.tile_nbuf = 1;
-    if (!COMPACT && !single && cp.tile_stride > 0 && ((NW == 2 && cp.tile_stride > 32) || bias_tile_mode() == 1)) {
-        // (the LDS-direct plan needs NT / chunks-per-row to be a multiple of the swizzle period: 128 threads x 16 chunks is not --
-        // the narrow workgroups keep per-lane loads there; smaller LDS, so the residency answer above still holds)
+    if (!COMPACT && !single && cp.tile_stride > 0 && bias_tile_mode() == 1) {
+        // (A/B switch: per-lane loads in multi-block launches; smaller LDS, so the residency answer above still holds)
         lds -= tile_bytes;
         cp.tile_stride = 0;
     }
