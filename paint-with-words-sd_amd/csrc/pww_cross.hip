@@ -81,6 +81,13 @@ __device__ __forceinline__ void load_q_frags_buf(typename Vec<T>::v8 (&qf)[KS], 
         qf[ks] = __builtin_bit_cast(V8, v);
     }
 }
+// acc + x * x with the product rounded before the sum: what the select form `acc += live ? x * x : 0` compiles to here and in
+// pww_qk_reduce (the select keeps hipcc from contracting it into an fma); the statistics of the two paths are compared bit for bit.
+__device__ __forceinline__ float add_square_unfused(float acc, float x) {
+#pragma clang fp contract(off)
+    const float sq = x * x;
+    return acc + sq;
+}
 constexpr int WAIT_VMCNT0 = 0x0F70;     // s_waitcnt vmcnt(0) only (gfx9 encoding: expcnt 7, lgkmcnt 15 = "do not wait")
 
 // ---- bias tile staging -------------------------------------------------------------------------------------------------
@@ -392,7 +399,7 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
                                     for (int r = 0; r < 16; ++r) {       // (product and sum rounded separately, as in the select form -- and in pww_qk_reduce)
                                         const float x = s[kb][r];
                                         vsum += x;
-                                        vsq = __fadd_rn(vsq, __fmul_rn(x, x));
+                                        vsq = add_square_unfused(vsq, x);
                                     }
                                 }
                             } else {
@@ -564,7 +571,9 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
                 }
                 if (use_glds) bias_ref_tile(bias, cur_tile, wave * 32 + l31, cp.tile_stride, p.bias_cols, hi);
             }
-            attn_tile_sm_pv<T, KS, DT, 2, true, false>(s0, oacc, m_run, l_run, smem + KT::BYTES, 0, p.M, l31, hi, bias, coeff, c1);
+            // (with the 77 prompt tokens the first 64 keys are all live: no per-score key compare there)
+            if (p.M >= KVBLK) attn_tile_sm_pv<T, KS, DT, 2, false, false>(s0, oacc, m_run, l_run, smem + KT::BYTES, 0, p.M, l31, hi, bias, coeff, c1);
+            else attn_tile_sm_pv<T, KS, DT, 2, true, false>(s0, oacc, m_run, l_run, smem + KT::BYTES, 0, p.M, l31, hi, bias, coeff, c1);
             if (KVBLK < p.M)
                 attn_tile<T, KS, DT, 2, true, false>(oacc, m_run, l_run, qf, smem + SUB_BYTES, smem + SUB_BYTES + KT::BYTES, KVBLK, p.M, l31, hi, bias, coeff, c1);
         } else {
@@ -575,6 +584,8 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
                     const char *Ks = smem + sub * SUB_BYTES;
                     if (biased)
                         attn_tile<T, KS, DT, 1, true, false>(oacc, m_run, l_run, qf, Ks, Ks + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
+                    else if (key0 + KVBLK <= p.M)      // a full 64-key tile (the first one of the 77 prompt tokens): no key compares
+                        attn_tile<T, KS, DT, 0, false, false>(oacc, m_run, l_run, qf, Ks, Ks + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
                     else
                         attn_tile<T, KS, DT, 0, true, false>(oacc, m_run, l_run, qf, Ks, Ks + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
                 }
@@ -654,9 +665,9 @@ static int fused_assume_resident() {   // PWW_CROSS_ASSUME_RESIDENT=n: TEST HOOK
 }
 
 static int bias_tile_mode();
-static int gate_balance_weight() {   // PWW_CROSS_GATE_WEIGHT: cost of a gated-in image's query block in units of a gated-out one's (default 3; 1 = ignore the hint)
+static int gate_balance_weight() {   // PWW_CROSS_GATE_WEIGHT: cost of a gated-in image's query block in units of a gated-out one's (default 2 -- measured best of 2 / 3 / 4; 1 = ignore the hint)
     static int w = -1;
-    if (w < 0) { const char *e = getenv("PWW_CROSS_GATE_WEIGHT"); w = e ? atoi(e) : 3; if (w < 1) w = 1; }
+    if (w < 0) { const char *e = getenv("PWW_CROSS_GATE_WEIGHT"); w = e ? atoi(e) : 2; if (w < 1) w = 1; }
     return w;
 }
 static int tile_nbuf_mode() {   // PWW_CROSS_TILE_NBUF=1: never double-buffer the bias tile (A/B testing); default 2: when it costs no residency
