@@ -28,6 +28,8 @@ static uint16_t to_t(float f, int dt) { return dt == PWW_DTYPE_F16 ? to_f16(f) :
 static float from_t(uint16_t u, int dt) { return dt == PWW_DTYPE_F16 ? from_f16(u) : from_bf16(u); }
 
 static int g_fail = 0;
+static bool g_product_only = false;  // --product-only: for a cross-attention case, ONLY the launch the product issues (fused_ex with bias_cols and the
+                                     // gated-images hint, first half of the gates open), 20 times, no checks: what a PMC pass should see
 static bool g_timeline = false;      // --timeline: print the phase time stamps of the case's launches (pww_debug_timeline)
 
 // one launch under pww_debug_timeline: per stamp slot, microseconds since the earliest kernel-entry stamp of the launch
@@ -127,6 +129,22 @@ static void run_case(const Case &c, bool timing) {
     const size_t ws_bytes = pww_workspace_bytes(&d);
     void *dws = dalloc<char>(ws_bytes + 8);
 
+    if (g_product_only) {
+        if (c.bias_mode != 1 || M > 128) { printf("SKIP %-28s --product-only needs a cross-attention case with the [N, M] map\n", c.name); return; }
+        const size_t fws_bytes = pww_cross_fused_workspace_bytes(&d), sync_bytes = pww_cross_fused_state_bytes(&d);
+        void *fws = dalloc<char>(fws_bytes + 8); unsigned *dsync = dalloc<unsigned>(sync_bytes / 4 + 1);
+        HIPCHECK(hipMemset(dsync, 0, sync_bytes));
+        std::vector<float> gate(coeff); if (B > 1) for (int b = B / 2; b < B; ++b) gate[b] = 0.f;
+        float *dgate = dalloc<float>(B); HIPCHECK(hipMemcpy(dgate, gate.data(), B * 4, hipMemcpyHostToDevice));
+        pww_cross_opts_t op; memset(&op, 0, sizeof(op)); op.size = sizeof(op); op.bias_cols = c.bias_cols; op.gated_images = B > 1 ? B / 2 : 0;
+        int r = 0;
+        for (int i = 0; i < 20 && !r; ++i)
+            r = pww_cross_attn_fwd_fused_ex(dq, dk, dv, dout, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, nullptr, dsync, sync_bytes, fws, fws_bytes, &op, nullptr);
+        HIPCHECK(hipDeviceSynchronize());
+        printf("%s %-28s product-only: 20 x fused_ex (bias_cols=%d, gated_images=%d) rc=%d\n", r ? "FAIL" : "PASS", c.name, op.bias_cols, op.gated_images, r);
+        if (r) g_fail++;
+        return;
+    }
     int rc = c.bias_mode ? pww_cross_attn_fwd(dq, dk, dv, dout, dbias, dcoeff, &d, nullptr)
                          : pww_self_attn_fwd(dq, dk, dv, dout, &d, nullptr);
     if (rc) { printf("FAIL %-28s attn rc=%d err=%s\n", c.name, rc, pww_last_error()); g_fail++; return; }
@@ -527,6 +545,7 @@ static void check_errors() {
 
 int main(int argc, char **argv) {
     if (argc > 1 && !strcmp(argv[1], "--timeline")) { g_timeline = true; --argc; ++argv; }
+    if (argc > 1 && !strcmp(argv[1], "--product-only")) { g_product_only = true; --argc; ++argv; }
     const bool quick = argc > 1 && !strcmp(argv[1], "--quick");
     const char *only = (argc > 2 && !strcmp(argv[1], "--only")) ? argv[2] : nullptr;
     const char *match = (argc > 2 && !strcmp(argv[1], "--match")) ? argv[2] : nullptr;     // substring of the case name

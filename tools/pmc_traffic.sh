@@ -1,10 +1,10 @@
 #!/bin/bash
 # HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes as the guide prescribes) for one native-harness case.
-R=$PWD; CASE=${1:-sd15_self_n4096_d40_f16_b2}; OUT=$R/${2:-gpurun_out/pmc_traffic}
+R=$PWD; CASE=${1:-sd15_self_n4096_d40_f16_b2}; OUT=$R/${2:-gpurun_out/pmc_traffic}; FLAGS=${3:-}   # e.g. --product-only
 export TMPDIR=/tmp; cd /tmp; mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | tr ' ' '_')
-  timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$n -o pmc -- $R/tests/native/attn_check --only $CASE > $OUT/$n.log 2>&1
+  timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/$n -o pmc -- $R/tests/native/attn_check $FLAGS --only $CASE > $OUT/$n.log 2>&1
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections, json
