@@ -33,6 +33,15 @@ def test_struct_layout_matches_header():
     # int32 x6, int64 x12, float (+pad), int64 x4
     assert ctypes.sizeof(AttnDesc) == 24 + 96 + 8 + 32
     assert AttnDesc.q_stride.offset == 24 and AttnDesc.scale.offset == 120 and AttnDesc.bias_stride.offset == 128
+    # pww_cross_opts_t: uint32 size, int32 bias_cols, 3 pointers, int32 R, int32 gated_images (padding before ABI 1.21), int64 x3
+    from pww_hip._lib import CrossOpts
+    assert ctypes.sizeof(CrossOpts) == 64
+    assert (CrossOpts.bias_cols.offset, CrossOpts.coeff_scalar_dev.offset, CrossOpts.col_idx.offset, CrossOpts.R.offset,
+            CrossOpts.gated_images.offset, CrossOpts.compact_stride.offset, CrossOpts.col_idx_stride.offset) == (4, 8, 24, 32, 36, 40, 56)
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "pww_hip.h")).read()
+    body = header[header.index("typedef struct pww_cross_opts {"):header.index("} pww_cross_opts_t;")]
+    assert [m for m in re.findall(r"\b(\w+)(?:\[\d+\])?;", body)] == ["size", "bias_cols", "coeff_scalar_dev", "bias_compact", "col_idx", "R", "gated_images",
+                                                                    "compact_stride", "col_idx_stride"]
 
 
 def test_no_cpu_fallback():
@@ -384,6 +393,8 @@ def test_fold_context_per_image_maps():
     assert torch.equal(f["CROSS_ATTENTION_WEIGHT_16"][2, 0], conds[2]["CROSS_ATTENTION_WEIGHT_16"]) and float(f["CROSS_ATTENTION_WEIGHT_16"][3:].abs().sum()) == 0.0
     assert f["CROSS_ATTENTION_WEIGHT_ORIG"].shape == (6, 8, 8, 77)
     assert f[ROW_GATE].tolist() == [1, 1, 1, 0, 0, 0]
+    from pww_hip.attention import GATED_ROWS
+    assert f[GATED_ROWS] == 3                 # what the gate holds, as a host-side int: the fused launch's work-distribution hint
     shared = _fold_context(conds[0], unc, 3, "cpu")
     assert shared["CROSS_ATTENTION_WEIGHT_16"] is conds[0]["CROSS_ATTENTION_WEIGHT_16"] and shared["CONTEXT_TENSOR"].shape == (6, 77, 8)
     with pytest.raises(ValueError):

@@ -338,7 +338,8 @@ def test_one_graph_serves_thirty_steps_and_the_fallback_still_works(gpu_device):
 def test_bias_hints_do_not_change_a_bit(gpu_device, shape, dtype, B):
     """pww_cross_attn_fwd_fused_ex: the bias rows of a query block staged in LDS from the dense map (all columns, or only
     those below the column bound) or from the compact [N, R] + col_idx form give bit-identical outputs -- and the same as
-    the per-lane global loads of round 2 would (checked natively, tests/native/attn_check.cpp)."""
+    the per-lane global loads of round 2 would (checked natively, tests/native/attn_check.cpp). The gated-images hint (right or
+    wrong) only moves work between workgroups."""
     from pww_hip import ops
     case = cases.make_attention_case(shape)
     N, C, H = case["N"], case["C"], case["H"]
@@ -358,7 +359,9 @@ def test_bias_hints_do_not_change_a_bit(gpu_device, shape, dtype, B):
     wc[:, :cols.numel()] = w[:, cols]
     dev_word = torch.tensor([0.37], device=gpu_device)
     for name, kw in (("bias_cols", dict(bias_cols=32)), ("compact", dict(bias_cols=32, compact=(wc, idx))),
-                     ("compact+device word", dict(bias_cols=32, compact=(wc, idx), coeff_dev=dev_word))):
+                     ("compact+device word", dict(bias_cols=32, compact=(wc, idx), coeff_dev=dev_word)),
+                     ("gated hint", dict(bias_cols=32, gated=B // 2)), ("gated hint, wrong", dict(bias_cols=32, gated=max(B // 2 - 1, 0) or B - 1)),
+                     ("gated hint + compact", dict(bias_cols=32, compact=(wc, idx), gated=B // 2))):
         out = run(**kw)
         assert torch.equal(out, base), (name, (out.float() - base.float()).abs().max().item())
     two = ops.attention(q, k, v, H, (C // H) ** -0.5, bias=w, bias_coeff=gate, stat=(ops.qk_stats(q, k, H), ops.STAT_MAX, 0.37))
