@@ -369,12 +369,19 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
                 slot_publish(slot + 2, dsum); slot_publish(slot + 3, dsq);
             }
         };
+        // Extremes only (qk.max() -- the shipped weight functions -- / min / absmax, nobody asked for the statistics back): max and min are
+        // idempotent, so the workgroup keeps ONE running per-lane extreme over all its blocks, reduces it across lanes and waves once, and
+        // publishes that value into every one of its blocks' slots -- the image's folded maximum is the same number, and the per-block
+        // cross-lane reduction (six dependent shuffles), the LDS hand-over and the fold leave the loop. Sums keep the per-block partials
+        // (their fold order is what makes the statistics bit-identical to pww_qk_reduce).
+        const bool lazy_ext = !f_sum;
+        float vmax = -INFINITY, vmin = INFINITY, vsum = 0.f, vsq = 0.f;
         int it = 0;
         for (int qb = chunk; qb < cp.nqb; qb += nchunk, ++it) {
             const int qrow = (qb * NW + wave) * 32 + l31;
             const bool qvalid = qrow < p.N;
             const bool rows_full = (qb * NW + wave) * 32 + 32 <= p.N;      // wave-uniform: every row of the wave is a real row
-            float vmax = -INFINITY, vmin = INFINITY, vsum = 0.f, vsq = 0.f;
+            if (!lazy_ext) { vmax = -INFINITY; vmin = INFINITY; vsum = 0.f; vsq = 0.f; }
 #pragma unroll
             for (int sub = 0; sub < NSUB; ++sub) {
                 const int key0 = sub * KVBLK;
@@ -386,13 +393,13 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
                         if (key0 + kb * 32 < p.M) {         // (a 32-key block past M holds no live key)
                             if (rows_full && key0 + kb * 32 + 32 <= p.M) {
                                 // every score of the block is live (all but the last key block of all but the last query block): no selects
-                                if (f_max) {
+                                if (f_max) {      // (four-element groups: a dependent chain of 4 per block instead of 16)
 #pragma unroll
-                                    for (int r = 0; r < 16; ++r) vmax = fmaxf(vmax, s[kb][r]);
+                                    for (int r = 0; r < 16; r += 4) vmax = fmaxf(vmax, fmaxf(fmaxf(s[kb][r], s[kb][r + 1]), fmaxf(s[kb][r + 2], s[kb][r + 3])));
                                 }
                                 if (f_min) {
 #pragma unroll
-                                    for (int r = 0; r < 16; ++r) vmin = fminf(vmin, s[kb][r]);
+                                    for (int r = 0; r < 16; r += 4) vmin = fminf(vmin, fminf(fminf(s[kb][r], s[kb][r + 1]), fminf(s[kb][r + 2], s[kb][r + 3])));
                                 }
                                 if (f_sum) {
 #pragma unroll
@@ -426,31 +433,45 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
                     }
                 }
             }
-            if (f_max) {
+            if (!lazy_ext) {
+                if (f_max) {
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
-            }
-            if (f_min) {
+                    for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+                }
+                if (f_min) {
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) vmin = fminf(vmin, __shfl_xor(vmin, off));
-            }
-            if (f_sum) {
+                    for (int off = 32; off >= 1; off >>= 1) vmin = fminf(vmin, __shfl_xor(vmin, off));
+                }
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) { vsum += __shfl_xor(vsum, off); vsq += __shfl_xor(vsq, off); }
+                // (the groups alternate between two buffers: thread t still reads group g while the waves already park group g + 1)
+                if (lane == 0) {
+                    float *rp = red + ((((it / RED_BLKS) & 1) * RED_BLKS + it % RED_BLKS) * NW + wave) * 4;
+                    rp[0] = vmax; rp[1] = vmin; rp[2] = vsum; rp[3] = vsq;
+                }
+                if (it % RED_BLKS == RED_BLKS - 1) fold_group(it / RED_BLKS, RED_BLKS);
             }
-            // (the groups alternate between two buffers: thread t still reads group g while the waves already park group g + 1)
-            if (lane == 0) {
-                float *rp = red + ((((it / RED_BLKS) & 1) * RED_BLKS + it % RED_BLKS) * NW + wave) * 4;
-                rp[0] = vmax; rp[1] = vmin; rp[2] = vsum; rp[3] = vsq;
-            }
-            if (it % RED_BLKS == RED_BLKS - 1) fold_group(it / RED_BLKS, RED_BLKS);
             if constexpr (!SINGLE) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) { qf[ks] = q1[ks]; q1[ks] = q2[ks]; q2[ks] = q3[ks]; }
                 request_q(q3, qb + 4 * nchunk);
             }
         }
-        if (it % RED_BLKS) fold_group(it / RED_BLKS, it % RED_BLKS);
+        if (!lazy_ext) {
+            if (it % RED_BLKS) fold_group(it / RED_BLKS, it % RED_BLKS);
+        } else {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { vmax = fmaxf(vmax, __shfl_xor(vmax, off)); vmin = fminf(vmin, __shfl_xor(vmin, off)); }
+            if (lane == 0) { red[wave * 4 + 0] = vmax; red[wave * 4 + 1] = vmin; }
+            __syncthreads();
+            double dmax = -INFINITY, dmin = INFINITY;
+            for (int w = 0; w < NW; ++w) { dmax = fmax(dmax, (double)red[w * 4 + 0]); dmin = fmin(dmin, (double)red[w * 4 + 1]); }
+            for (int t = tid; t < it; t += NT) {        // one slot set per block of this workgroup, all with the workgroup's extremes
+                unsigned long long *slot = cp.slots + ((long)b * cp.nqb * p.H + (long)(chunk + t * nchunk) * p.H + h) * 4;
+                slot_publish(slot + 0, dmax); slot_publish(slot + 1, dmin);
+                slot_publish(slot + 2, 0.0); slot_publish(slot + 3, 0.0);
+            }
+        }
         tl_stamp(p, 2);
         if constexpr (!SINGLE) {   // pass 2 starts over at the first block: its fragments and its bias rows are requested before the hand-off
             __builtin_amdgcn_s_waitcnt(WAIT_VMCNT0);     // (nothing is in flight any more -- the ring's last requests lie past the last block -- and hipcc should know)

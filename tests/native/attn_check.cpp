@@ -252,6 +252,28 @@ static void run_case(const Case &c, bool timing) {
             HIPCHECK(hipDeviceSynchronize());
             std::vector<uint16_t> h1(q.size()), h2(q.size());
             HIPCHECK(hipMemcpy(h1.data(), o1, h1.size() * 2, hipMemcpyDeviceToHost));
+            // without stats_out the extremes-only statistics (max / min / absmax) take the workgroup-wide running extreme instead of
+            // per-block partials: same outputs as the two launches, bit for bit
+            for (int kind : {PWW_STAT_MAX, PWW_STAT_MIN, PWW_STAT_ABSMAX}) {
+                HIPCHECK(hipMemset(o2, 0xee, q.size() * 2)); HIPCHECK(hipMemset(o1, 0xdd, q.size() * 2));
+                int ra = pww_cross_attn_fwd_stat(dq, dk, dv, o2, dbias, dstats, kind, (double)H * N * M, s0, dgate, &d, nullptr);
+                int rb = 0;
+                for (int rep = 0; rep < 2 && !rb; ++rep)
+                    rb = pww_cross_attn_fwd_fused(dq, dk, dv, o1, dbias, kind, s0, dgate, &d, nullptr, dsync, sync_bytes, fws, fws_bytes, nullptr);
+                HIPCHECK(hipDeviceSynchronize());
+                std::vector<uint16_t> ha(q.size()), hb(q.size()); std::vector<unsigned> hs(sync_bytes / 4);
+                HIPCHECK(hipMemcpy(ha.data(), o2, ha.size() * 2, hipMemcpyDeviceToHost)); HIPCHECK(hipMemcpy(hb.data(), o1, hb.size() * 2, hipMemcpyDeviceToHost));
+                HIPCHECK(hipMemcpy(hs.data(), dsync, sync_bytes, hipMemcpyDeviceToHost));
+                long diff = 0, dirty = 0; for (size_t i = 0; i < ha.size(); ++i) diff += ha[i] != hb[i];
+                for (unsigned w : hs) dirty += w != 0;
+                const bool ok = ra == 0 && rb == 0 && diff == 0 && dirty == 0;
+                printf("%s %-28s fused kind=%d without stats_out (running extremes): %ld differing outputs vs two launches, %ld dirty state words (rc %d %d)\n", ok ? "PASS" : "FAIL", c.name, kind, diff, dirty, ra, rb);
+                if (!ok) g_fail++;
+            }
+            HIPCHECK(hipMemset(o1, 0xff, q.size() * 2));
+            r1 = pww_cross_attn_fwd_fused(dq, dk, dv, o1, dbias, PWW_STAT_MAX, s0, dgate, &d, nullptr, dsync, sync_bytes, fws, fws_bytes, nullptr);
+            HIPCHECK(hipDeviceSynchronize());
+            HIPCHECK(hipMemcpy(h1.data(), o1, h1.size() * 2, hipMemcpyDeviceToHost));
             for (int variant = 0; variant < 8; ++variant) {
                 pww_cross_opts_t op; memset(&op, 0, sizeof(op)); op.size = sizeof(op);
                 const float *use_bias = dbias;
