@@ -514,3 +514,15 @@ def test_pipeline_accepts_a_missing_color_map():
     assert seeds == {} and cond["CONTEXT_TENSOR"].shape == (1, 77, 64)
     assert cond["CROSS_ATTENTION_WEIGHT_4096"].shape == (4096, 77) and float(cond["CROSS_ATTENTION_WEIGHT_4096"].abs().sum()) == 0.0
     assert cond["CROSS_ATTENTION_WEIGHT_ORIG"].shape == (512, 512, 77) and uncond["CROSS_ATTENTION_WEIGHT_64"] == 0
+
+
+@pytest.mark.slow
+def test_kernel_invariants_static():
+    """tools/check_kernel_invariants.py: compiler-dependent properties the measured kernel times rest on (register budgets, counted
+    vmcnt waits of the Q ring, back-to-back LDS-direct copies), checked on the gfx950 ISA hipcc produces here. ~5 minutes of compiling:
+    PWW_SLOW=1."""
+    import subprocess
+    import sys as _sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([_sys.executable, os.path.join(repo, "tools", "check_kernel_invariants.py")], capture_output=True, text=True, timeout=1800)
+    assert out.returncode == 0, out.stdout[-3000:]

@@ -1,0 +1,118 @@
+#!/usr/bin/env python
+"""Static checks of compiler-dependent properties the measured kernel times rest on (no GPU needed: hipcc cross-compiles gfx950).
+
+Each of these was found by measurement in rounds 2 / 3 and can be undone silently by a source change or a compiler
+update, with correct results and slower kernels:
+
+ 1. register budget: the hot kernels stay inside the occupancy they were tuned for, without scratch in their hot variants
+    (hipcc -Rpass-analysis=kernel-resource-usage);
+ 2. cross_fused_kernel, several query blocks per workgroup: the Q loads are unconditional buffer loads (a load under an `if` is waited
+    for at the join: the prefetch becomes synchronous), the pass-1 loop waits with a COUNTED vmcnt (the ring of three blocks in flight
+    survives), and the LDS-direct bias copies are issued back to back (inline asm: no wait between two copies).
+
+    python tools/check_kernel_invariants.py            # prints one line per check, exit code 1 on a violation
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(REPO, "paint-with-words-sd_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", CSRC, "-I", os.path.join(REPO, "include")]
+
+
+def resource_usage(src):
+    out = subprocess.run([HIPCC] + FLAGS + ["-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
+    rows, cur = {}, None
+    for line in out.splitlines():
+        m = re.search(r"remark: [^:]*:\d+:\d+:\s+(.*?)\s*\[-Rpass", line) or re.search(r"remark:\s+(.*?)\s*\[-Rpass", line)
+        if not m:
+            continue
+        t = m.group(1)
+        if t.startswith("Function Name:"):
+            cur = rows.setdefault(t.split(":", 1)[1].strip(), {})
+        elif cur is not None and ":" in t:
+            k, v = t.split(":", 1)
+            cur[k.strip()] = v.strip()
+    return rows
+
+
+def kernel_isa(src, symbol_regex):
+    with tempfile.TemporaryDirectory() as tmp:
+        asm = os.path.join(tmp, "k.s")
+        subprocess.run([HIPCC] + FLAGS + ["-S", "--cuda-device-only", src, "-o", asm], capture_output=True, text=True, check=True)
+        text = open(asm).read()
+    out = {}
+    for m in re.finditer(r"^(%s):.*?s_endpgm" % symbol_regex, text, re.M | re.S):
+        out[m.group(1)] = m.group(0).splitlines()
+    return out
+
+
+def main():
+    bad = []
+
+    def check(ok, what):
+        print(("ok   " if ok else "FAIL ") + what)
+        if not ok:
+            bad.append(what)
+
+    # ---- 1. register budgets -------------------------------------------------------------------------------------------------
+    attn = resource_usage(os.path.join(CSRC, "pww_attn.hip"))
+    for name, r in attn.items():
+        if "attn_fwd_fold_kernel" in name and not name.endswith("ELi2EEEvNS_10AttnParamsE"):      # d = 40 folded kernels, 8- and 4-wave workgroups
+            # (the dominant launch; the 2-wave variant serves under-filled launches at one wave per SIMD): two waves per SIMD, no scratch
+            check(int(r["Occupancy [waves/SIMD]"]) >= 2 and int(r["ScratchSize [bytes/lane]"]) == 0,
+                  "%s: %s VGPRs, occupancy %s, %s B scratch (>= 2 waves per SIMD, no scratch)" % (name, r["VGPRs"], r["Occupancy [waves/SIMD]"], r["ScratchSize [bytes/lane]"]))
+    cross = resource_usage(os.path.join(CSRC, "pww_cross.hip"))
+    for name, r in cross.items():
+        m = re.match(r"_ZN3pww18cross_fused_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])EEE", name)
+        if not m:
+            continue
+        ks, single, compact = int(m.group(2)), m.group(5) == "1", m.group(6) == "1"
+        if ks <= 3 and not compact:              # the d = 40 dense kernels (SD1.5 at N = 4096: the batched launch of configs 3 / 4): no scratch
+            check(int(r["ScratchSize [bytes/lane]"]) == 0 and int(r["Occupancy [waves/SIMD]"]) >= 2,
+                  "%s (d <= 48, dense, %s): %s VGPRs, %s B scratch, occupancy %s" % (name, "one block" if single else "several blocks", r["VGPRs"],
+                                                                                      r["ScratchSize [bytes/lane]"], r["Occupancy [waves/SIMD]"]))
+
+    # ---- 2. the several-blocks-per-workgroup cross kernel (bf16, d = 40, dense) -----------------------------------------------
+    isa = kernel_isa(os.path.join(CSRC, "pww_cross.hip"), r"_ZN3pww18cross_fused_kernelIDF16bLi3ELi2ELi4ELb0ELb0EEEvNS_11CrossParamsE")
+    lines = next(iter(isa.values()))
+    body = "\n".join(lines)
+    check("global_load_dwordx4" not in body, "Q fragments: no flat / global (conditional) 16-byte loads left, buffer loads only")
+    # LDS-direct copies come in runs (2 / 4 / 8 per block): no s_waitcnt between the copies of a run
+    runs, cur, waits_inside = [], 0, 0
+    pending_wait = 0
+    for line in lines:
+        s = line.strip()
+        if s.startswith("buffer_load_dwordx4") and s.endswith("lds"):
+            if cur:
+                waits_inside += pending_wait
+            cur += 1
+            pending_wait = 0
+        elif s.startswith("s_waitcnt") and "vmcnt" in s and cur:
+            pending_wait += 1
+        elif s.startswith("s_cbranch") or s.startswith(".LBB") or s.startswith("s_branch"):
+            if cur:
+                runs.append(cur)
+            cur, pending_wait = 0, 0
+    check(len(runs) >= 3 and waits_inside == 0, "LDS-direct bias copies: %d runs of %s copies, %d vmcnt waits between copies of a run" % (len(runs), sorted(set(runs)), waits_inside))
+    # the pass-1 loop: the first inner loop that holds MFMAs and requests the ring's next block; its header must not drain vmcnt
+    loop_heads = [i for i, line in enumerate(lines) if "Loop Header" in line] + [len(lines)]
+    found = False
+    for h, nxt_h in zip(loop_heads, loop_heads[1:]):
+        loop = "\n".join(lines[h:nxt_h])
+        if "v_mfma" in loop and "sc1" in loop and "v_exp_f32" not in loop:      # MFMAs and the published partials, no softmax: pass 1
+            waits = [s.strip() for s in lines[h:h + 12] if "s_waitcnt" in s and "vmcnt" in s]
+            found = True
+            check(bool(waits) and all("vmcnt(0)" not in w for w in waits), "pass-1 loop header waits with a counted vmcnt (ring of 3 blocks in flight): %s" % waits)
+            break
+    check(found, "pass-1 loop located")
+    print("%d violation(s)" % len(bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
