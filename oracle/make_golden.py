@@ -408,6 +408,107 @@ def gen_ref_timing(ref):
     print("ref_cpu_timing", rec)
 
 
+# ---- round-4 fixtures: BASELINE configs 4 and 5 pinned END TO END at full size, pipeline classes ------------------
+
+def gen_config4():
+    """BASELINE configs[3] end to end (missing 2): the reference's own `paint_with_words_inpaint`
+    (paint_with_words_inpaint.py:137-270) on the FULL-SIZE SD1.5-inpainting stand-in (9 input channels), aurora_1.png +
+    the 4-region context + moon_mask.png + the synthetic init image, 30 LMS steps, strength 1.0, fp32 CPU; final latents of
+    images 0 and 5 of bench.py's batch of 8 (seeds 81 and 86)."""
+    import warnings
+    warnings.filterwarnings("ignore")
+    ref = ref_loader.load_reference_inpaint()
+    inj = ref_loader.load_reference()["inj_forward"]
+    au = np.array(Image.open(os.path.join(GOLDEN, "aurora_1.png")).convert("RGB"))
+    init = cases.synthetic_init_image()
+    out = {"steps": 30, "seeds": np.array([81, 86])}
+    captured = {}
+
+    def grab(vae, latents):
+        captured["latents"] = latents.detach().clone()
+        return [Image.new("RGB", (8, 8))]
+    ref["_pil_from_latents"] = grab
+    for seed in (81, 86):
+        tools = cases.build_tools("sd15_inpaint")
+        _install_ref({"inj_forward": inj}, tools[1])
+        try:
+            t0 = time.time()
+            ref["paint_with_words_inpaint"](color_context=dict(cases.INPAINT_CONTEXT), color_map_image=Image.fromarray(au),
+                                            mask_image=Image.open(os.path.join(GOLDEN, "moon_mask_L.png")), init_image=Image.fromarray(init),
+                                            input_prompt=cases.AURORA_PROMPT, num_inference_steps=30, guidance_scale=7.5, seed=seed,
+                                            device="cpu", weight_function=cases.weight_fn_inpaint, preloaded_utils=tools, strength=1.0)
+            dt = time.time() - t0
+        finally:
+            _uninstall_ref()
+        out[f"latents_{seed}"] = captured["latents"].numpy()
+        out[f"seconds_{seed}"] = np.float64(dt)
+        print("loop sd15_inpaint lms30 seed %d: %.1fs latents std %.4f" % (seed, dt, out[f"latents_{seed}"].std()), flush=True)
+        np.savez_compressed(os.path.join(GOLDEN, "loop_sd15_inpaint_lms30.npz"), **out)
+
+
+def gen_config5(ref):
+    """BASELINE configs[4] end to end: the reference's own `paint_with_words` (paint_with_words.py:393-510, region seeds
+    :445-457) on the FULL-SIZE SD2.1 stand-in at 768x768 (N = 9216, head dim 64), 12-region grid with per-region seeds
+    1000+k, 0.4 w log(1+sigma^2) qk.std() (README.md:152), 30 LMS steps, fp32 CPU.
+      image 0: bench.py's request (seed 0);
+      image 2: the same grid rolled by one cell to the right (cases.grid_batch_case(2): its own weight maps and its own
+               region-seed placement -- the per-image path of paint_with_words_batch at this size), seed 2.
+    (With the shared grid every latent pixel is overwritten by a region seed (:451-455), so the images of bench.py's batch
+    are identical by construction; the rolled map is what makes a second image informative.)"""
+    import warnings
+    warnings.filterwarnings("ignore")
+    path = os.path.join(GOLDEN, "loop_sd21_grid768_lms30.npz")
+    out = dict(np.load(path)) if os.path.isfile(path) else {"steps": 30}
+    for j in (0, 2):
+        if f"latents_{j}" in out:
+            continue
+        img, ctx, prompt = cases.grid_batch_case(j)
+        lat, dt = _run_loop(ref, "sd21", 30, img, ctx, prompt, cases.weight_fn_std, seed=j)
+        out[f"latents_{j}"] = lat
+        out[f"seconds_{j}"] = np.float64(dt)
+        print("loop sd21 grid768 lms30 image %d: %.1fs latents std %.4f" % (j, dt, lat.std()), flush=True)
+        np.savez_compressed(path, **out)
+
+
+def gen_pipelines():
+    """The reference's two pipeline CLASSES (paint_with_words.py:513-842, paint_with_words_inpaint.py:273-575), AST-loaded and exec'd
+    unmodified over a stand-in of the diffusers base class (ref_loader._StableDiffusionPipelineStub), on the tiny UNets: final
+    latents (grabbed at `decode_latents`) and the (step, timestep) pairs the callback saw, for the cases of cases.pipe_case."""
+    import warnings
+    from types import SimpleNamespace
+    warnings.filterwarnings("ignore")
+    ns_inp = ref_loader.load_reference_inpaint(classes=True)
+    ns = ns_inp["_base_namespace"]
+    out = {}
+    for name in cases.PIPE_CASES:
+        config, kind, kwargs, gseed = cases.pipe_case(name)
+        vae, unet, text, tok, sch = cases.build_tools(config)
+        vae.config = SimpleNamespace(block_out_channels=(1, 1, 1, 1), latent_channels=4)       # what the diffusers base class reads
+        cls = ns["PaintWithWord_StableDiffusionPipeline"] if kind == "txt2img" else ns_inp["PaintWithWord_StableDiffusionInpaintPipeline"]
+        try:
+            pipe = cls(vae=vae, text_encoder=text, tokenizer=tok, unet=unet, scheduler=sch, safety_checker=None, feature_extractor=None)
+            captured, calls = {}, []
+            decode = pipe.decode_latents
+
+            def grab(latents):
+                captured["latents"] = latents.detach().clone()
+                return decode(latents)
+            pipe.decode_latents = grab
+            if gseed is not None:
+                torch.manual_seed(gseed)
+            t0 = time.time()
+            res = pipe(callback=lambda i, t, lat: calls.append((int(i), float(t))), output_type="np", **kwargs)
+            dt = time.time() - t0
+        finally:
+            _uninstall_ref()
+        out[f"{name}_latents"] = captured["latents"].numpy()
+        out[f"{name}_callbacks"] = np.array(calls, dtype=np.float64).reshape(-1, 2)
+        out[f"{name}_image_mean"] = np.float64(np.asarray(res.images).mean())
+        print("pipeline %s: %.1fs latents %s std %.4f callbacks %s" % (name, dt, tuple(captured["latents"].shape), captured["latents"].std(),
+                                                                      [c[0] for c in calls]), flush=True)
+    np.savez_compressed(os.path.join(GOLDEN, "pipeline_classes.npz"), **out)
+
+
 if __name__ == "__main__":
     assert ref_loader.available(), "reference not found at %s" % ref_loader.REFERENCE_ROOT
     os.makedirs(GOLDEN, exist_ok=True)
@@ -436,3 +537,9 @@ if __name__ == "__main__":
         gen_config3(ref)
     if "reftime" in which:
         gen_ref_timing(ref)
+    if "pipelines" in which:
+        gen_pipelines()
+    if "config4" in which:
+        gen_config4()
+    if "config5" in which:
+        gen_config5(ref)

@@ -186,13 +186,14 @@ def orig_weight_fallback(w_orig, n_tokens):
 
 
 def encode_text_color_inputs(text_encoder, tokenizer, color_map_rgb, color_context, input_prompt,
-                             unconditional_input_prompt="", verbose=False):
-    """:315-388. Returns (extra_seeds, regions, cond_dict, uncond_dict) with the reference's key names."""
+                             unconditional_input_prompt="", verbose=False, use_sigma=True):
+    """:315-388. Returns (extra_seeds, regions, cond_dict, uncond_dict) with the reference's key names.
+    use_sigma=False: the pipeline classes' own copy of this function (:561-627) parses the blur sigmas and drops them (:574)."""
     text_input = tokenizer([input_prompt], padding="max_length", max_length=tokenizer.model_max_length,
                            truncation=True, return_tensors="pt")
     color_context, extra_seeds, extra_sigmas = extract_seed_and_sigma(color_context)
     regions, width, height = separate_regions(color_map_rgb, color_context, tokenizer, verbose)
-    for k, sigma in extra_sigmas.items():
+    for k, sigma in (extra_sigmas.items() if use_sigma else ()):
         regions[k] = (regions[k][0], gaussian_blur(regions[k][1], sigma))
     ids = text_input["input_ids"][0].tolist()
     cond = {"CONTEXT_TENSOR": text_encoder(text_input.input_ids)[0],
@@ -392,3 +393,85 @@ def paint_with_words_inpaint_latents(color_context, color_map_rgb, mask_l, init_
         eps_u = unet(x, t, encoder_hidden_states=uncond).sample
         latents = scheduler.step(cfg_combine(eps_c, eps_u, guidance_scale), t, latents).prev_sample
     return latents
+
+
+# --------------------------------------------------------------------------------------------
+# pipeline classes (paint_with_words.py:513-842, paint_with_words_inpaint.py:273-575)
+
+
+def _denoise(unet, scheduler, cond, uncond, latents, timesteps, guidance_scale, weight_function, extra=None, callback=None,
+             callback_steps=1):
+    """The classes' denoising loop (:787-816 / paint_with_words_inpaint.py:520-559): sigma looked up by timestep equality,
+    two batch-1 UNet calls, CFG, scheduler.step, `callback(i, t, latents)` when i % callback_steps == 0."""
+    for i, t in enumerate(timesteps):
+        sigma = scheduler.sigmas[int((scheduler.timesteps == t).nonzero().item())]
+        x = scheduler.scale_model_input(latents, t)
+        if extra is not None:
+            x = torch.cat([x, extra], dim=1)
+        cond.update({"SIGMA": sigma, "WEIGHT_FUNCTION": weight_function})
+        eps_c = unet(x, t, encoder_hidden_states=cond).sample
+        uncond.update({"SIGMA": sigma, "WEIGHT_FUNCTION": lambda w, sigma, qk: 0.0})
+        eps_u = unet(x, t, encoder_hidden_states=uncond).sample
+        latents = scheduler.step(cfg_combine(eps_c, eps_u, guidance_scale), t, latents).prev_sample
+        if callback is not None and i % callback_steps == 0:
+            callback(i, t, latents)
+    return latents
+
+
+def _strength_timesteps(scheduler, num_inference_steps, strength):
+    """:733-741 (and :434-441): the tail of the schedule an img2img / inpaint request runs."""
+    offset = scheduler.config.get("steps_offset", 0)
+    init_timestep = min(int(num_inference_steps * strength) + offset, num_inference_steps)
+    return scheduler.timesteps[max(num_inference_steps - init_timestep + offset, 0):]
+
+
+def _preprocess_rgb(rgb):
+    """paint_with_words.py:28-35 for an image whose sides are multiples of 32 (no resampling): uint8 [H, W, 3] -> [-1, 1] NCHW."""
+    assert rgb.shape[0] % 32 == 0 and rgb.shape[1] % 32 == 0
+    return 2.0 * torch.from_numpy(rgb.astype(np.float32) / 255.0)[None].permute(0, 3, 1, 2) - 1.0
+
+
+def pipeline_call_latents(vae, unet, text_encoder, tokenizer, scheduler, prompt, color_map_rgb=None, color_context=None,
+                          weight_function=lambda w, sigma, qk: 0.1 * w * math.log(sigma + 1) * qk.max(), height=None, width=None,
+                          num_inference_steps=30, guidance_scale=7.5, negative_prompt="", eta=0.5, seed=0, image_rgb=None,
+                          callback=None, callback_steps=1):
+    """PaintWithWord_StableDiffusionPipeline.__call__ (:629-842) up to the final latent. What differs from the function API:
+    height / width default to sample_size * 8 and size the LATENT (:700-701, :756) while the color map sizes the weight maps;
+    blur sigmas are dropped (:574); `negative_prompt` is the unconditional prompt; with `image` the schedule is cut by `eta`
+    (:735) and the noise comes from the GLOBAL generator (:771)."""
+    height = height or unet.config.sample_size * 8
+    width = width or unet.config.sample_size * 8
+    extra_seeds, regions, cond, uncond = encode_text_color_inputs(text_encoder, tokenizer, color_map_rgb, dict(color_context or {}),
+                                                                  prompt, negative_prompt, use_sigma=False)
+    scheduler.set_timesteps(num_inference_steps)
+    if image_rgb is None:
+        timesteps = scheduler.timesteps
+        latents = initial_latents(seed, unet.in_channels, height, width, regions, extra_seeds) * scheduler.init_noise_sigma
+    else:
+        timesteps = _strength_timesteps(scheduler, num_inference_steps, eta)
+        init_latents = 0.18215 * vae.encode(_preprocess_rgb(image_rgb)).latent_dist.sample()
+        latents = scheduler.add_noise(init_latents, torch.randn(init_latents.shape), timesteps[:1])
+    return _denoise(unet, scheduler, cond, uncond, latents, timesteps, guidance_scale, weight_function, None, callback, callback_steps)
+
+
+def inpaint_pipeline_call_latents(vae, unet, text_encoder, tokenizer, scheduler, prompt, image_rgb, mask_l, color_map_rgb=None,
+                                  color_context=None, weight_function=lambda w, sigma, qk: 0.1 * w * math.log(sigma + 1) * qk.max(),
+                                  height=None, width=None, num_inference_steps=30, guidance_scale=7.5, negative_prompt="", eta=1.0,
+                                  seed=0, callback=None, callback_steps=1):
+    """PaintWithWord_StableDiffusionInpaintPipeline.__call__ (paint_with_words_inpaint.py:340-575) up to the final latent: color map
+    and mask are taken as given (no resize to the init image), the latent mask is sized by height / width (:427-432, :498-508),
+    `eta` is the strength (:441), the noise comes from `seed` (:467-473)."""
+    height = height or unet.config.sample_size * 8
+    width = width or unet.config.sample_size * 8
+    _, _, cond, uncond = encode_text_color_inputs(text_encoder, tokenizer, color_map_rgb, dict(color_context or {}), prompt,
+                                                  negative_prompt, use_sigma=False)
+    mask, masked_image = prepare_mask_and_masked_image(image_rgb, mask_l)
+    scheduler.set_timesteps(num_inference_steps)
+    timesteps = _strength_timesteps(scheduler, num_inference_steps, eta)
+    generator = torch.manual_seed(seed)
+    init_latents = 0.18215 * vae.encode(_preprocess_rgb(image_rgb)).latent_dist.sample()
+    latents = scheduler.add_noise(init_latents, torch.randn(init_latents.shape, generator=generator), timesteps[:1])
+    mask_lat = torch.from_numpy(nearest_resize(mask.numpy(), height // 8, width // 8))
+    extra = torch.cat([mask_lat, 0.18215 * vae.encode(masked_image).latent_dist.sample()], dim=1)
+    assert latents.shape[1] + extra.shape[1] == unet.in_channels
+    return _denoise(unet, scheduler, cond, uncond, latents, timesteps, guidance_scale, weight_function, extra, callback, callback_steps)

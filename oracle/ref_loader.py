@@ -64,16 +64,80 @@ class _GaussianBlur:
         return x.reshape(shape)
 
 
-def load_reference(filename="paint_with_words.py", extra=None):
-    """Return a namespace dict with the reference's top-level functions of `filename`."""
+class _StableDiffusionPipelineStub:
+    """The members of diffusers==0.10.0's `StableDiffusionPipeline` that the reference's two pipeline classes call on `self`
+    (paint_with_words.py:513-842, paint_with_words_inpaint.py:273-575), restated from the published 0.10.0 sources (the package
+    is not installable offline): module registration, `vae_scale_factor`, `_execution_device`, `check_inputs`,
+    `prepare_extra_step_kwargs`, `progress_bar`, `decode_latents`, `numpy_to_pil`. The reference's classes are exec'd UNMODIFIED
+    with this class bound to the name `StableDiffusionPipeline`."""
+
+    def __init__(self, vae, text_encoder, tokenizer, unet, scheduler, safety_checker, feature_extractor, requires_safety_checker=True):
+        self.vae, self.text_encoder, self.tokenizer, self.unet, self.scheduler = vae, text_encoder, tokenizer, unet, scheduler
+        self.safety_checker, self.feature_extractor = safety_checker, feature_extractor
+        self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)
+
+    @property
+    def device(self):
+        return next(self.unet.parameters()).device
+
+    @property
+    def _execution_device(self):
+        return self.device
+
+    def check_inputs(self, prompt, height, width, callback_steps):
+        if not isinstance(prompt, str) and not isinstance(prompt, list):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if (callback_steps is None) or (callback_steps is not None and (not isinstance(callback_steps, int) or callback_steps <= 0)):
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type {type(callback_steps)}.")
+
+    def prepare_extra_step_kwargs(self, generator, eta):
+        import inspect
+        accepted = set(inspect.signature(self.scheduler.step).parameters.keys())
+        kw = {}
+        if "eta" in accepted:
+            kw["eta"] = eta
+        if "generator" in accepted:
+            kw["generator"] = generator
+        return kw
+
+    def progress_bar(self, iterable=None, total=None):
+        import contextlib
+
+        class _Bar:
+            def update(self, n=1):
+                pass
+        return contextlib.nullcontext(_Bar())
+
+    def decode_latents(self, latents):
+        latents = 1 / 0.18215 * latents
+        image = self.vae.decode(latents).sample
+        image = (image / 2 + 0.5).clamp(0, 1)
+        return image.cpu().permute(0, 2, 3, 1).float().numpy()
+
+    @staticmethod
+    def numpy_to_pil(images):
+        if images.ndim == 3:
+            images = images[None, ...]
+        images = (images * 255).round().astype("uint8")
+        return [Image.fromarray(image) for image in images]
+
+
+def load_reference(filename="paint_with_words.py", extra=None, classes=False):
+    """Return a namespace dict with the reference's top-level functions of `filename` (and, with `classes`, its classes:
+    the pipeline classes subclass diffusers' StableDiffusionPipeline, bound here to _StableDiffusionPipelineStub)."""
     from sd_standin import LMSDiscreteScheduler
     path = os.path.join(REFERENCE_ROOT, "paint_with_words", filename)
     src = open(path).read()
-    defs = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef)]
+    kinds = (ast.FunctionDef, ast.ClassDef) if classes else (ast.FunctionDef,)
+    defs = [n for n in ast.parse(src).body if isinstance(n, kinds)]
     ns = dict(math=math, np=np, torch=torch, F=F, PIL=PIL, Image=Image, tqdm=lambda it, **kw: it,
               Callable=Callable, Dict=Dict, List=List, Optional=Optional, Tuple=Tuple, Union=Union,
               LMSDiscreteScheduler=LMSDiscreteScheduler, UNet2DConditionModel=None, CLIPTextModel=None,
-              CLIPTokenizer=None, AutoencoderKL=None, PNDMScheduler=None,
+              CLIPTokenizer=None, AutoencoderKL=None, PNDMScheduler=None, CLIPFeatureExtractor=None,
+              StableDiffusionPipeline=_StableDiffusionPipelineStub,
+              StableDiffusionPipelineOutput=lambda images, nsfw_content_detected: SimpleNamespace(images=images, nsfw_content_detected=nsfw_content_detected),
               T=SimpleNamespace(GaussianBlur=_GaussianBlur))
     if extra:
         ns.update(extra)
@@ -81,7 +145,10 @@ def load_reference(filename="paint_with_words.py", extra=None):
     return ns
 
 
-def load_reference_inpaint():
-    base = load_reference("paint_with_words.py")
-    extra = {k: base[k] for k in ("pww_load_tools", "preprocess", "_pil_from_latents", "_encode_text_color_inputs")}
-    return load_reference("paint_with_words_inpaint.py", extra=extra)
+def load_reference_inpaint(classes=False):
+    base = load_reference("paint_with_words.py", classes=classes)
+    names = ("pww_load_tools", "preprocess", "_pil_from_latents", "_encode_text_color_inputs") + (("PaintWithWord_StableDiffusionPipeline",) if classes else ())
+    extra = {k: base[k] for k in names}
+    ns = load_reference("paint_with_words_inpaint.py", extra=extra, classes=classes)
+    ns["_base_namespace"] = base
+    return ns

@@ -32,13 +32,28 @@ struct F32Tap {
     }
 };
 
+// One launch builds up to four resolutions (the 8 / 16 / 32 / 64 maps of one request were four launches of 10 - 13 us each --
+// launch latency, not bytes): workgroup -> (level, 64-pixel block) through the levels' block offsets. The per-element arithmetic is
+// unchanged, so every level is bit-identical to a launch of its own.
+struct MaskLevels {
+    int n;
+    int Hr[4], Wr[4];
+    int blk0[5];          // first workgroup of level i (blk0[n] = grid size)
+    float *out[4];
+};
+
 template <typename Tap>
 __global__ void __launch_bounds__(MASK_THREADS)
-mask_build_kernel(Tap tap, int H, int W, int Hr, int Wr, int R, const int32_t *col_ptr,
-                  const int32_t *col_reg, int T, float *out) {
+mask_build_kernel(Tap tap, int H, int W, MaskLevels lv, int R, const int32_t *col_ptr, const int32_t *col_reg, int T) {
     __shared__ float vals[MASK_PIX][MASK_MAX_R + 1];
     const int tid = threadIdx.x;
-    const int pix0 = blockIdx.x * MASK_PIX;
+    int level = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < lv.n && (int)blockIdx.x >= lv.blk0[i]) level = i;
+    const int Hr = lv.Hr[level], Wr = lv.Wr[level];
+    float *out = lv.out[level];
+    const int pix0 = ((int)blockIdx.x - lv.blk0[level]) * MASK_PIX;
     const int npix = Hr * Wr;
     // ATen: area_pixel_compute_scale(align_corners=True) = (in - 1) / (out - 1) in fp32, 0 if out == 1
     const float sy = Hr > 1 ? __fdiv_rn((float)(H - 1), (float)(Hr - 1)) : 0.f;
@@ -77,14 +92,30 @@ mask_build_kernel(Tap tap, int H, int W, int Hr, int Wr, int R, const int32_t *c
 static int round_div(int a, int ratio) { return (int)((2L * a + ratio) / (2L * ratio)); }
 
 template <typename Tap>
+static int launch_mask_levels(Tap tap, int H, int W, int n, const int *ratios, float *const *outs, int R, const int32_t *col_ptr,
+                              const int32_t *col_reg, int T, hipStream_t stream) {
+    MaskLevels lv;
+    lv.n = 0;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!outs[i]) continue;
+        const int Hr = round_div(H, ratios[i]), Wr = round_div(W, ratios[i]);
+        if (Hr <= 0 || Wr <= 0) { set_error("mask_build: image %dx%d too small for ratio %d", H, W, ratios[i]); return PWW_EINVAL; }
+        lv.Hr[lv.n] = Hr; lv.Wr[lv.n] = Wr; lv.out[lv.n] = outs[i]; lv.blk0[lv.n] = blocks;
+        blocks += (Hr * Wr + MASK_PIX - 1) / MASK_PIX;
+        ++lv.n;
+    }
+    if (!lv.n) return PWW_OK;
+    for (int i = lv.n; i < 4; ++i) { lv.Hr[i] = lv.Wr[i] = 1; lv.out[i] = nullptr; }
+    for (int i = lv.n; i < 5; ++i) lv.blk0[i] = blocks;
+    hipLaunchKernelGGL((mask_build_kernel<Tap>), dim3(blocks), dim3(MASK_THREADS), 0, stream, tap, H, W, lv, R, col_ptr, col_reg, T);
+    return check_hip(hipGetLastError(), "mask_build_kernel launch");
+}
+
+template <typename Tap>
 static int launch_mask(Tap tap, int H, int W, int ratio, int R, const int32_t *col_ptr,
                        const int32_t *col_reg, int T, float *out, hipStream_t stream) {
-    const int Hr = round_div(H, ratio), Wr = round_div(W, ratio);
-    if (Hr <= 0 || Wr <= 0) { set_error("mask_build: image %dx%d too small for ratio %d", H, W, ratio); return PWW_EINVAL; }
-    const int npix = Hr * Wr;
-    hipLaunchKernelGGL((mask_build_kernel<Tap>), dim3((npix + MASK_PIX - 1) / MASK_PIX), dim3(MASK_THREADS), 0,
-                       stream, tap, H, W, Hr, Wr, R, col_ptr, col_reg, T, out);
-    return check_hip(hipGetLastError(), "mask_build_kernel launch");
+    return launch_mask_levels(tap, H, W, 1, &ratio, &out, R, col_ptr, col_reg, T, stream);
 }
 
 static int check_mask_args(const void *src, int H, int W, int R, const int32_t *col_ptr, const int32_t *col_reg, int T) {
@@ -103,11 +134,16 @@ int mask_build(const uint8_t *rgb, int H, int W, const pww_region_t *regions, in
     RgbTap tap{rgb, W, regions};
     float *outs[4] = {out8, out16, out32, out64};
     const int ratios[4] = {8, 16, 32, 64};
-    for (int i = 0; i < 4; ++i) {
-        if (!outs[i]) continue;
-        if (int rc = launch_mask(tap, H, W, ratios[i], R, col_ptr, col_reg, T, outs[i], stream)) return rc;
-    }
-    return PWW_OK;
+    return launch_mask_levels(tap, H, W, 4, ratios, outs, R, col_ptr, col_reg, T, stream);      // ONE launch for the four maps
+}
+
+int mask_build_f32_levels(const float *masks, int H, int W, int R, const int32_t *col_ptr, const int32_t *col_reg, int T,
+                          float *out8, float *out16, float *out32, float *out64, hipStream_t stream) {
+    if (int rc = check_mask_args(masks, H, W, R, col_ptr, col_reg, T)) return rc;
+    F32Tap tap{masks, H, W};
+    float *outs[4] = {out8, out16, out32, out64};
+    const int ratios[4] = {8, 16, 32, 64};
+    return launch_mask_levels(tap, H, W, 4, ratios, outs, R, col_ptr, col_reg, T, stream);
 }
 
 int mask_build_rgb(const uint8_t *rgb, int H, int W, const pww_region_t *regions, int R, const int32_t *col_ptr,

@@ -94,6 +94,13 @@ def grid_case(rows=3, cols=4, height=768, width=768, seeds=True):
     return img, ctx, "a painting of " + " ".join(words[: rows * cols])
 
 
+def grid_batch_case(j, rows=3, cols=4, height=768, width=768):
+    """Image j of a config-5 style batch with PER-IMAGE maps: the grid rolled by j cells to the right (so the weight maps and
+    the region-seed placement differ per image), same color_context and prompt, seed j. j = 0 is bench.py's request."""
+    img, ctx, prompt = grid_case(rows, cols, height, width, seeds=True)
+    return np.ascontiguousarray(np.roll(img, j * (width // cols), axis=1)), ctx, prompt
+
+
 def load_example_rgb():
     """The reference's contents/example_input.png, re-saved under tests/golden/ by make_golden.py."""
     from PIL import Image
@@ -203,3 +210,43 @@ def build_tools(config_name="tiny", dtype=torch.float32, device="cpu", scheduler
     else:
         sch = PLMSScheduler()
     return vae, unet, text, tok, sch
+
+
+# ---- pipeline-class cases: keyword arguments shared by the reference's classes (AST-loaded, oracle/make_golden.py
+# pipelines) and this repo's classes -- both have the reference's __call__ signature (paint_with_words.py:629-650,
+# paint_with_words_inpaint.py:340-362). Every case exercises something the pipeline classes do DIFFERENTLY from the function API.
+PIPE_SEED_SIGMA_CONTEXT = {(0, 0, 0): "cat,1.0,42,4.0", (255, 255, 255): "dog,1.0,7", (13, 255, 0): "tree,1.5,-1,9.5",
+                           (90, 206, 255): "sky,0.2", (74, 18, 1): "ground,0.2"}
+PIPE_INPAINT_CONTEXT = dict(INPAINT_CONTEXT)
+PIPE_INPAINT_CONTEXT[(136, 178, 92)] = "full moon,1.5,-1,6.0"       # a blur sigma the class parses and drops (:574)
+
+
+def pipe_case(name):
+    """(unet config, class kind, call kwargs, global torch seed or None) of a pipeline-class case.
+      txt2img  region seeds used, blur sigmas IGNORED (:574), negative_prompt, callback every 2nd step
+      hw384    height = width = 384 with a 512 x 512 color map: the latent is sized by height / width (:756), the weight maps by
+               the color map -> every layer takes the CROSS_ATTENTION_WEIGHT_ORIG fallback (:96-101)
+      img2img  image= + eta as the img2img strength (:735); the noise comes from the GLOBAL generator (:771)
+      inpaint  the inpaint class: eta as strength (paint_with_words_inpaint.py:441), seed-driven noise (:467-473), callback"""
+    from PIL import Image
+    ex, au = Image.fromarray(load_example_rgb()), Image.fromarray(load_aurora_rgb())
+    init = Image.fromarray(synthetic_init_image())
+    if name == "txt2img":
+        return "tiny", "txt2img", dict(prompt=RUNNER_PROMPT, color_map_image=ex, color_context=dict(PIPE_SEED_SIGMA_CONTEXT),
+                                       weight_function=weight_fn_runner, num_inference_steps=6, guidance_scale=7.5,
+                                       negative_prompt="blurry, low quality", seed=3, callback_steps=2), None
+    if name == "hw384":
+        return "tiny", "txt2img", dict(prompt=RUNNER_PROMPT, color_map_image=ex, color_context=dict(RUNNER_CONTEXT),
+                                       weight_function=weight_fn_runner, height=384, width=384, num_inference_steps=4, guidance_scale=5.0,
+                                       seed=5), None
+    if name == "img2img":
+        return "tiny", "txt2img", dict(prompt=RUNNER_PROMPT, color_map_image=ex, color_context=dict(RUNNER_CONTEXT),
+                                       weight_function=weight_fn_default, num_inference_steps=6, eta=0.6, seed=9, image=init), 123
+    if name == "inpaint":
+        return "tiny_inpaint", "inpaint", dict(prompt=AURORA_PROMPT, image=init, mask_image=load_moon_mask(), color_map_image=au,
+                                               color_context=dict(PIPE_INPAINT_CONTEXT), weight_function=weight_fn_inpaint,
+                                               num_inference_steps=8, guidance_scale=7.5, eta=0.75, seed=81, callback_steps=3), None
+    raise KeyError(name)
+
+
+PIPE_CASES = ("txt2img", "hw384", "img2img", "inpaint")
