@@ -176,6 +176,13 @@ class EventTimer:
             return self._timed(key, fn, (q, k, v, heads, scale), dict(bias=bias, **kw), kernel_only=True)
         return wrapped
 
+    def wrap_qproj(self, fn):
+        """the to_q GEMM with the score statistic in its epilogue (pww_qproj_stat): kernel-only like the attention launches"""
+        def wrapped(x, weight, k, heads, kind, gate=None):
+            key = ("qproj+stat", x.shape[0], x.shape[1], k.shape[1], weight.shape[0] // heads, heads, x.shape[2])
+            return self._timed(key, fn, (x, weight, k, heads, kind), dict(gate=gate), kernel_only=True)
+        return wrapped
+
     def wrap_stats(self, fn):
         def wrapped(q, k, heads):
             key = ("qk_reduce", q.shape[0], q.shape[1], k.shape[1], q.shape[2] // heads, heads, k.shape[0])
@@ -241,8 +248,12 @@ def replay_us(call, reps=40):
 
 def kernel_row(kind, us, B, N, M, D, Hh, Bk, elem_bytes, launches, label=None):
     C = Hh * D
-    names = {"qk_reduce": "qk_reduce (ticket init + reduce)", "cross+stat": "cross (score statistic + attention, one launch)"}
-    if kind == "qk_reduce":
+    names = {"qk_reduce": "qk_reduce (ticket init + reduce)", "cross+stat": "cross (attention with the statistic: folded partials, or formed in the launch)",
+             "qproj+stat": "to_q GEMM + score-statistic partials (pww_qproj_stat)"}
+    if kind == "qproj+stat":      # (Bk carries Cin here) algorithmic: the GEMM alone -- the score blocks of the epilogue are not counted
+        flops = 2.0 * B * N * C * Bk
+        nbytes = elem_bytes * (B * N * Bk + B * N * C + C * Bk)
+    elif kind == "qk_reduce":
         flops = 2.0 * B * Hh * N * M * D
         nbytes = elem_bytes * (B * N * C + Bk * M * C)
     else:
@@ -468,6 +479,8 @@ def main():
                     help="memory format of the UNet (a stock PyTorch setting: MIOpen's bf16/fp16 convolutions are NHWC kernels, NCHW pays a "
                          "transpose either side). auto = channels_last for the SD1.5 topologies (measured +4.6 %% at batch 1, +1..3 %% at "
                          "batch 8), NCHW for SD2.1 at 768x768 (channels_last measured -6 %% there)")
+    ap.add_argument("--tiny", action="store_true", help="1/8-width stand-in of the workload's topology (tests of the launcher / sharding plumbing on a GPU; the line says so)")
+    ap.add_argument("--dump-latents", default=None, metavar="PREFIX", help="save this rank's final latents of the last timed step to PREFIX_rank<r>.npy")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: spawn / rendezvous (gloo) / broadcast a 1/8-width model and the request, print the line with value null")
     args = ap.parse_args()
 
@@ -505,7 +518,7 @@ def main():
     pw_api.DEFAULT_MODE = args.mode
 
     log("cpu_count", os.cpu_count(), "torch threads", torch.get_num_threads(), "rank", rank, "world", world, "config", args.config)
-    tools, build_info = build_tools(device, dtype, cfg["scheduler"], cfg["model"], tiny=not on_gpu)
+    tools, build_info = build_tools(device, dtype, cfg["scheduler"], cfg["model"], tiny=not on_gpu or args.tiny)
     log("tools built", build_info)
     vae, unet, text, tok, sched = tools
     channels_last = args.memory_format == "channels_last" or (args.memory_format == "auto" and cfg["model"] != "sd21")
@@ -543,7 +556,7 @@ def main():
                                                                         args.guidance, cfg["wf"], cfg["batch"]),
                    "baseline_config": args.config, "mode": args.mode, "images_per_step": n_global,
                    "stock_op_settings": "MIOpen find mode%s" % (", UNet in channels_last memory format" if channels_last else ""),
-                   "parallelism": "image-sharded x%d, no data-path collective" % world,
+                   "parallelism": "image-sharded x%d, no data-path collective" % world, "backend": pdist.backend_name(),
                    "weight_broadcast": build_info, "weight_broadcast_s": build_info.get("weight_broadcast_s"), "request_broadcast_s": round(req_bcast_s, 4)},
     }
     if args.config != 2 or cfg["denoise_steps"] != 30:     # (an overridden step count must not carry the headline's "30 steps" label)
@@ -582,6 +595,10 @@ def main():
     for smp in getattr(unet, "_pww_samplers", {}).values():
         smp.check_errors()            # fused hand-off time-outs of any timed request (raises; the requests are complete: synchronised above)
     assert torch.isfinite(lat).all(), "non-finite latents"
+    if args.dump_latents:
+        np.save("%s_rank%d.npy" % (args.dump_latents, rank), lat.float().cpu().numpy())
+    if args.tiny:
+        result["data"] = "synthetic (1/8-width model: plumbing test, not a measurement)"
     log("timed region done: %.3f s for %d steps" % (elapsed, args.steps))
     images = args.steps * n_global
     result["value"] = round(images / elapsed, 4)
@@ -591,8 +608,8 @@ def main():
         # instrumented pass (same workload, folded mode so single launches can be bracketed by HIP events
         # on the launch stream): dominant kernel = self-attention at the finest resolution
         timer = EventTimer()
-        orig, orig_stats, orig_mask, orig_cfg = ops.attention, ops.qk_stats, ops.mask_build, ops.cfg_combine
-        ops.attention, ops.qk_stats = timer.wrap_attention(orig), timer.wrap_stats(orig_stats)
+        orig, orig_stats, orig_mask, orig_cfg, orig_qproj = ops.attention, ops.qk_stats, ops.mask_build, ops.cfg_combine, ops.qproj_stat
+        ops.attention, ops.qk_stats, ops.qproj_stat = timer.wrap_attention(orig), timer.wrap_stats(orig_stats), timer.wrap_qproj(orig_qproj)
         # K4: reads the RGB map once per resolution, writes the [N_r, 77] fp32 maps; CFG combine: 2 half reads + 1 fp32 write
         ops.mask_build = timer.wrap_stream("mask_build", orig_mask, lambda rgb, regions, cols, ratios=(8, 16, 32, 64):
                                            sum(rgb.numel() + (-(-rgb.shape[0] // r)) * (-(-rgb.shape[1] // r)) * len(cols) * 4 for r in ratios))
@@ -601,7 +618,7 @@ def main():
         try:
             one_step(0)
         finally:
-            ops.attention, ops.qk_stats, ops.mask_build, ops.cfg_combine = orig, orig_stats, orig_mask, orig_cfg
+            ops.attention, ops.qk_stats, ops.mask_build, ops.cfg_combine, ops.qproj_stat = orig, orig_stats, orig_mask, orig_cfg, orig_qproj
             pw_api.DEFAULT_MODE = args.mode
         H, W = request["rgb"].shape[:2]
         n_dom = (H // 8) * (W // 8)

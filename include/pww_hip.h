@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define PWW_VERSION 121 /* 0.1.21: pww_cross_opts_t.gated_images (was padding); 0.1.20: + pww_cross_attn_fwd_fused_ex / pww_cross_attn_fwd_stat_ex (pww_cross_opts_t: device-side coefficient word, bias column bound,
+#define PWW_VERSION 122 /* 0.1.22: pww_qproj_stat / pww_qproj_parts / pww_cross_attn_fwd_parts (score statistic formed in the to_q GEMM's epilogue), pww_mask_build_f32_levels, PWW_STAT_ALL; 0.1.21: pww_cross_opts_t.gated_images (was padding); 0.1.20: + pww_cross_attn_fwd_fused_ex / pww_cross_attn_fwd_stat_ex (pww_cross_opts_t: device-side coefficient word, bias column bound,
                            compact bias), pww_debug_timeline (0.1.11: pww_profile_*; 0.1.10: fused cross-attention, blur, resize, inpaint prep) */
 
 #define PWW_OK 0
@@ -117,6 +117,7 @@ int pww_cross_attn_fwd(const void *q, const void *k, const void *v, void *o,
 #define PWW_STAT_MEAN 3   /* qk.mean()  = sum / count */
 #define PWW_STAT_STD 4    /* qk.std()   = unbiased, like torch.std (README.md:152) */
 #define PWW_STAT_ABSMAX 5 /* qk.abs().max() */
+#define PWW_STAT_ALL 6    /* pww_qproj_stat only: form all four fields of the partials */
 
 /*
  * pww_cross_attn_fwd with the per-image bias coefficient formed INSIDE the kernel:
@@ -207,6 +208,50 @@ int pww_cross_attn_fwd_stat_ex(const void *q, const void *k, const void *v, void
                                const float *gate, const pww_attn_desc_t *desc, const pww_cross_opts_t *opts, void *stream);
 
 /*
+ * Query projection of a cross-attention layer WITH the score statistic's partials (version >= 122):
+ *     Q = X W^T                         paint_with_words.py:76   query = self.to_q(hidden_states)   (bias-free Linear)
+ *     partials[b][i] = { max, min, sum, sum of squares } of Q_tile K_h^T over tile i's heads, rows and the M prompt keys
+ *                                       paint_with_words.py:87 + the global reduction weight_function applies to it
+ *                                       (:402-405 qk.max(); runner.py:104; README.md:152 qk.std())
+ * The statistic must exist before any softmax of the image can start (:106 -> :112). Formed here -- in the epilogue of the GEMM
+ * that produces Q, on the rounded Q tile it still holds -- the boundary between this launch and the attention launch is the
+ * synchronisation: pww_cross_attn_fwd_parts folds the partials at entry and reads Q once (no in-kernel hand-off, no residency
+ * requirement, no time-out path).
+ *   x         [B][N][Cin]   addressed x + b*x_stride[0] + n*x_stride[1] + c
+ *   w         [H*D][Cin]    row-major nn.Linear weight, contiguous
+ *   q (out)   [B][N][H*D]   addressed q + b*q_stride[0] + n*q_stride[1] + c
+ *   k         [B?][M][H*D]  the layer's projected prompt keys (k_stride[0] = 0: one prompt shared by every image), M <= 128
+ *   gate      fp32 [B] or NULL: images with gate[b] == 0 (unconditional rows of a CFG-folded batch) get Q but no partials
+ *   stat_kind PWW_STAT_*: only the fields that statistic is made of are formed (PWW_STAT_ALL: all four, PWW_STAT_NONE: none)
+ *   partials  double [B][pww_qproj_parts(desc)][4], 16-byte aligned; rows of gated-out images are left untouched
+ * Supported: H*D a multiple of 320 (or 160) that holds whole heads, Cin a multiple of 80, D a multiple of 8; anything else
+ * returns PWW_ENOTSUP and pww_qproj_parts() returns 0 (the caller keeps its own projection and pww_cross_attn_fwd_fused).
+ * Statistics are those of the ROUNDED Q (what the attention kernel reads), accumulated in fp32 per 48-score lane slice and in fp64
+ * from there: within 1e-6 (relative to the largest score) of pww_qk_reduce on the same Q.
+ */
+typedef struct pww_qproj_desc {
+    int32_t dtype;        /* PWW_DTYPE_* of x, w, q, k */
+    int32_t B, N, Cin, H, D, M;
+    int64_t x_stride[2];  /* b, n */
+    int64_t q_stride[2];  /* b, n */
+    int64_t k_stride[2];  /* b, m */
+} pww_qproj_desc_t;
+
+int pww_qproj_stat(const void *x, const void *w, void *q, const void *k, const float *gate, const pww_qproj_desc_t *desc,
+                   int32_t stat_kind, double *partials, size_t partials_bytes, void *stream);
+int32_t pww_qproj_parts(const pww_qproj_desc_t *desc);
+
+/*
+ * pww_cross_attn_fwd_fused_ex with the statistic's partials supplied by pww_qproj_stat instead of formed in the launch:
+ *   c[b] = coeff_scalar * stat(fold(partials[b][0 .. nparts-1])) * gate[b]
+ * `stats_out` (optional, double [B][4]) receives the folded fields that were formed. No state or workspace buffers: nothing in this
+ * launch waits for another workgroup.
+ */
+int pww_cross_attn_fwd_parts(const void *q, const void *k, const void *v, void *o, const float *bias, int32_t stat_kind,
+                             float coeff_scalar, const float *gate, const pww_attn_desc_t *desc, const double *partials,
+                             int32_t nparts, double *stats_out, const pww_cross_opts_t *opts, void *stream);
+
+/*
  * Per-image global statistics of the raw score tensor S = Q K^T over all heads, rows and keys
  * (what weight_function reduces: qk.max(), qk.min(), qk.mean(), qk.std()).
  *   stats      double [B][4] = { max, min, sum, sum of squares } per image b (fully overwritten).
@@ -255,6 +300,10 @@ int pww_mask_build_rgb(const uint8_t *rgb, int32_t H, int32_t W,
 int pww_mask_build_f32(const float *masks, int32_t H, int32_t W, int32_t R,
                        const int32_t *col_ptr, const int32_t *col_reg, int32_t T,
                        int32_t ratio, float *out, void *stream);
+
+/* The four maps of pww_mask_build (ratios 8 / 16 / 32 / 64) from float masks, ONE launch (version >= 122). Any output may be NULL. */
+int pww_mask_build_f32_levels(const float *masks, int32_t H, int32_t W, int32_t R, const int32_t *col_ptr, const int32_t *col_reg,
+                              int32_t T, float *out8, float *out16, float *out32, float *out64, void *stream);
 
 /*
  * CROSS_ATTENTION_WEIGHT_ORIG [H][W][T] -> [n_tokens][T]: the reference's fallback when a layer's token count has no

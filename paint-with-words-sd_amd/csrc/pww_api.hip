@@ -63,7 +63,9 @@ bool profile_take(hipEvent_t *start, hipEvent_t *stop, hipStream_t stream) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;   // event-stamped launches cannot be captured: stay armed
     std::lock_guard<std::mutex> lock(g_prof_mutex);
-    ProfileSlot &sl = g_prof_slots[(size_t)(g_prof_armed % PWW_PROFILE_SLOTS)];
+    const size_t idx = (size_t)(g_prof_armed % PWW_PROFILE_SLOTS);
+    if (idx >= g_prof_slots.size()) { g_prof_armed = -1; return false; }      // another thread reset the pool since this thread armed
+    ProfileSlot &sl = g_prof_slots[idx];
     const bool mine = sl.owner == g_prof_armed;
     g_prof_armed = -1;
     if (!mine) return false;          // the pair was recycled by a later arm before this launch happened
@@ -115,10 +117,11 @@ static void profile_reset() {
 }
 
 // ---- phase time stamps (pww_debug_timeline): one process-wide debug pointer handed to every attention launch
+// (pointer and size are read by concurrent launches: both live behind the same mutex as the timing slots)
 static unsigned long long *g_timeline = nullptr;
 static size_t g_timeline_bytes = 0;
-unsigned long long *debug_timeline() { return g_timeline; }
-size_t debug_timeline_bytes() { return g_timeline_bytes; }
+unsigned long long *debug_timeline() { std::lock_guard<std::mutex> lock(g_prof_mutex); return g_timeline_bytes ? g_timeline : nullptr; }
+size_t debug_timeline_bytes() { std::lock_guard<std::mutex> lock(g_prof_mutex); return g_timeline ? g_timeline_bytes : 0; }
 
 int attn_fwd(const void *q, const void *k, const void *v, void *o, const float *bias, const float *bias_coeff,
              const pww_attn_desc_t *d, hipStream_t stream, const double *stats = nullptr, int stat_kind = PWW_STAT_NONE,
@@ -128,7 +131,13 @@ int qk_reduce(const void *q, const void *k, const pww_attn_desc_t *d, double *st
 size_t qk_reduce_workspace_bytes(const pww_attn_desc_t *d);
 int cross_attn_fused(const void *q, const void *k, const void *v, void *o, const float *bias, int stat_kind, float coeff_scalar,
                      const float *gate, const pww_attn_desc_t *d, double *stats_out, void *state, size_t state_bytes,
-                     void *workspace, size_t workspace_bytes, const pww_cross_opts_t *opts, hipStream_t stream);
+                     void *workspace, size_t workspace_bytes, const pww_cross_opts_t *opts, hipStream_t stream,
+                     const double *ext_part = nullptr, int ext_nparts = 0);
+int qproj_stat(const void *x, const void *w, void *q, const void *k, const float *gate, const pww_qproj_desc_t *d, int stat_kind,
+               double *partials, size_t partials_bytes, hipStream_t stream);
+int qproj_parts(const pww_qproj_desc_t *d);
+int mask_build_f32_levels(const float *masks, int H, int W, int R, const int32_t *col_ptr, const int32_t *col_reg, int T,
+                          float *out8, float *out16, float *out32, float *out64, hipStream_t stream);
 size_t cross_fused_workspace_bytes(const pww_attn_desc_t *d);
 size_t cross_fused_state_bytes(const pww_attn_desc_t *d);
 int mask_build(const uint8_t *rgb, int H, int W, const pww_region_t *regions, int R, const int32_t *col_ptr,
@@ -205,7 +214,28 @@ int pww_cross_attn_fwd_stat_ex(const void *q, const void *k, const void *v, void
                          coeff_scalar, dev);
 }
 
+int pww_qproj_stat(const void *x, const void *w, void *q, const void *k, const float *gate, const pww_qproj_desc_t *desc,
+                   int32_t stat_kind, double *partials, size_t partials_bytes, void *stream) {
+    return pww::qproj_stat(x, w, q, k, gate, desc, stat_kind, partials, partials_bytes, static_cast<hipStream_t>(stream));
+}
+
+int32_t pww_qproj_parts(const pww_qproj_desc_t *desc) { return pww::qproj_parts(desc); }
+
+int pww_cross_attn_fwd_parts(const void *q, const void *k, const void *v, void *o, const float *bias, int32_t stat_kind,
+                             float coeff_scalar, const float *gate, const pww_attn_desc_t *desc, const double *partials,
+                             int32_t nparts, double *stats_out, const pww_cross_opts_t *opts, void *stream) {
+    if (!partials) { pww::set_error("pww_cross_attn_fwd_parts: null partials"); return PWW_EINVAL; }
+    return pww::cross_attn_fused(q, k, v, o, bias, stat_kind, coeff_scalar, gate, desc, stats_out, nullptr, 0, nullptr, 0, opts,
+                                 static_cast<hipStream_t>(stream), partials, nparts);
+}
+
+int pww_mask_build_f32_levels(const float *masks, int32_t H, int32_t W, int32_t R, const int32_t *col_ptr, const int32_t *col_reg,
+                              int32_t T, float *out8, float *out16, float *out32, float *out64, void *stream) {
+    return pww::mask_build_f32_levels(masks, H, W, R, col_ptr, col_reg, T, out8, out16, out32, out64, static_cast<hipStream_t>(stream));
+}
+
 void pww_debug_timeline(void *device_buffer, size_t bytes) {
+    std::lock_guard<std::mutex> lock(pww::g_prof_mutex);
     pww::g_timeline = static_cast<unsigned long long *>(device_buffer);
     pww::g_timeline_bytes = device_buffer ? bytes : 0;
 }

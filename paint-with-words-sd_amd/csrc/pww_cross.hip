@@ -51,6 +51,11 @@ struct CrossParams {
     const int *col_idx;          // [B?][R], -1 = unused slot
     int R;
     long c_sb, c_sn, ci_sb;      // compact strides (image, row) and col_idx image stride, in elements
+    // statistics partials formed by the PRODUCER of Q (pww_qproj.hip: the to_q GEMM's epilogue): [B][ext_nparts][4] plain fp64
+    // { max, min, sum, sum of squares }. When set, the kernel folds them at entry and runs pass 2 only: no pass 1, no slots, no
+    // hand-off, no residency requirement, Q read once -- the kernel boundary was the synchronisation.
+    const double *ext_part;
+    int ext_nparts;
 };
 
 constexpr unsigned long long SPIN_LIMIT_TICKS = 100000000ull;   // wall_clock64 runs at 100 MHz: 1 s (the grid is sized to be resident:
@@ -302,6 +307,7 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
         cidx = cidx_lds;
     }
     u32x4 treg[4];                          // staging registers of the bias tile
+    u32x4 ext_lo = {0u, 0u, 0u, 0u}, ext_hi = {0u, 0u, 0u, 0u};     // external partials: this thread's first one (max, min | sum, sum of squares)
 
     // K and V of this head -> LDS (rows past M and the head-dim padding are zeros)
     for (int i = tid * 16; i < STAGE_BYTES; i += NT * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0u, 0u, 0u, 0u};
@@ -315,6 +321,16 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
         u32x4 kreg[KPT];
         u32x4 vreg[VPT];
         stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);
+        // external partials: thread t's first partial travels with K and V too (folded below, once the gate is known). UNCONDITIONAL
+        // buffer loads (a load under an `if` would make everything in flight wait at the join): without partials the descriptor covers
+        // zero bytes and the loads return zeros without touching memory
+        {
+            const unsigned ext_bytes = cp.ext_part ? (unsigned)cp.ext_nparts * 32u : 0u;
+            const auto srd_e = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(cp.ext_part + (cp.ext_part ? (long)b * cp.ext_nparts * 4 : 0)), 0, ext_bytes, 0x00020000);
+            const unsigned eo = tid < cp.ext_nparts ? (unsigned)tid * 32u : OOB_OFF;
+            ext_lo = __builtin_amdgcn_raw_buffer_load_b128(srd_e, eo, 0, 0);
+            ext_hi = __builtin_amdgcn_raw_buffer_load_b128(srd_e, eo + 16u, 0, 0);
+        }
         // SINGLE: the (only) block's bias rows travel with K and V (one latency for all three)
         if (SINGLE && use_tile) tile_request<NT>(treg, use_compact, cbase, bias.srd, (long)chunk * NW * 32, p.N, cp.c_sn, p.b_sn, cp.R, p.bias_cols, tid);
         tl_stamp(p, 6);
@@ -337,7 +353,40 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     const bool f_min = f_all || p.stat_kind == PWW_STAT_MIN || p.stat_kind == PWW_STAT_ABSMAX;
     const bool f_sum = f_all || p.stat_kind == PWW_STAT_MEAN || p.stat_kind == PWW_STAT_STD;
     const bool f_sq = f_all || p.stat_kind == PWW_STAT_STD;
-    if (need_stat) {
+    if (need_stat && cp.ext_part) {
+        // ---- the statistic's partials came with Q (pww_qproj.hip): fold the image's partials -- a few hundred doubles, requested with K / V
+        const bool mine = tid < cp.ext_nparts;
+        auto as_double = [](unsigned lo, unsigned hi32) { return __longlong_as_double((long long)(((unsigned long long)hi32 << 32) | lo)); };
+        double dmax = mine ? as_double(ext_lo[0], ext_lo[1]) : -INFINITY, dmin = mine ? as_double(ext_lo[2], ext_lo[3]) : INFINITY;
+        double dsum = mine ? as_double(ext_hi[0], ext_hi[1]) : 0.0, dsq = mine ? as_double(ext_hi[2], ext_hi[3]) : 0.0;
+        for (int i = tid + NT; i < cp.ext_nparts; i += NT) {
+            const double *pp = cp.ext_part + ((long)b * cp.ext_nparts + i) * 4;
+            dmax = fmax(dmax, pp[0]); dmin = fmin(dmin, pp[1]); dsum += pp[2]; dsq += pp[3];
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            dmax = fmax(dmax, __shfl_xor(dmax, off));
+            dmin = fmin(dmin, __shfl_xor(dmin, off));
+            dsum += __shfl_xor(dsum, off);
+            dsq += __shfl_xor(dsq, off);
+        }
+        if (lane == 0) { fin[wave * 4 + 0] = dmax; fin[wave * 4 + 1] = dmin; fin[wave * 4 + 2] = dsum; fin[wave * 4 + 3] = dsq; }
+        __syncthreads();
+        for (int w = 0; w < NW; ++w) {
+            if (w == 0) { dmax = fin[0]; dmin = fin[1]; dsum = fin[2]; dsq = fin[3]; }
+            else { dmax = fmax(dmax, fin[w * 4 + 0]); dmin = fmin(dmin, fin[w * 4 + 1]); dsum += fin[w * 4 + 2]; dsq += fin[w * 4 + 3]; }
+        }
+        if (tid == 0 && cp.stats_out && h == 0 && chunk == 0) {
+            double *st = cp.stats_out + (long)b * 4;
+            st[0] = dmax; st[1] = dmin; st[2] = dsum; st[3] = dsq;
+        }
+        const double st[4] = {dmax, dmin, dsum, dsq};
+        coeff = stat_coefficient(coeff_scalar_of(p), p.stat_kind, st, p.stat_count);
+        if (p.bias_coeff) coeff = coeff * gate;
+        tl_stamp(p, 3);
+        if constexpr (!SINGLE)
+            if (use_glds) tile_glds(trel, bias_srd4, tile, (long)chunk * NW * 32, p.b_sn, tcpr, wave);
+    } else if (need_stat) {
         // Everything up to the folded statistic is the launch's critical path (every workgroup of the image waits for the slowest
         // pass 1): these waves go ahead of the co-resident workgroups that are already in pass 2 (unconditional rows have no pass 1).
         __builtin_amdgcn_s_setprio(3);
@@ -628,7 +677,7 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     // ---- the last workgroup of an image to leave puts the image's state words back to zero. (Every other workgroup of
     // the image has finished reading the slots: a workgroup leaves only after its fold. Last of its head -> bumps the
     // image's heads_left word; last of those -> everybody is out.)
-    if (need_stat) {
+    if (need_stat && !cp.ext_part) {
         if (tid == 0) {
             int last = 0;
             if (*ok_flag && depart_prev == (unsigned)nchunk - 1u) {
@@ -663,13 +712,16 @@ int qk_reduce(const void *q, const void *k, const pww_attn_desc_t *d, double *st
 size_t qk_reduce_workspace_bytes(const pww_attn_desc_t *d);
 bool attn_wide_groups(const pww_attn_desc_t *d);
 
-static int device_cus() {
-    static thread_local int cus = 0;
-    if (!cus) {
-        int dev = 0;
+static int current_device() { int dev = 0; return hipGetDevice(&dev) == hipSuccess ? dev : -1; }
+
+static int device_cus() {      // per device (a thread may drive several GPUs)
+    static thread_local int cus = 0, cus_dev = -1;
+    const int dev = current_device();
+    if (!cus || dev != cus_dev) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        if (dev < 0 || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
         cus = prop.multiProcessorCount;
+        cus_dev = dev;
     }
     return cus;
 }
@@ -708,7 +760,10 @@ static int launch_cross(CrossParams cp, hipStream_t stream, bool *launched) {
     static thread_local int per_cu_seen[16];
     static thread_local int n_seen = 0;
     static thread_local size_t lds_attr = 0;
+    static thread_local int seen_dev = -1;       // the answers and the function attribute are per DEVICE: start over when the thread switched GPUs
     auto resident = [&](size_t lds, int *per_cu_out) -> int {
+        const int dev = current_device();
+        if (dev != seen_dev) { n_seen = 0; lds_attr = 0; seen_dev = dev; }
         for (int i = 0; i < n_seen; ++i) if (lds_seen[i] == lds) { *per_cu_out = per_cu_seen[i]; return PWW_OK; }
         // (the kernels also own a few hundred bytes of static LDS: stay clear of the 160 KiB a workgroup can have)
         if (lds > 156 * 1024) { *per_cu_out = 0; return PWW_OK; }
@@ -741,8 +796,10 @@ static int launch_cross(CrossParams cp, hipStream_t stream, bool *launched) {
     const long BH = (long)p.B * p.H;
     cp.nqb = (p.N + NW * 32 - 1) / (NW * 32);
     const long cap = (long)per_cu * device_cus();
-    if (cap < BH) { *launched = false; return PWW_OK; }      // cannot be made resident: the caller takes the two-launch path
+    const bool ext = cp.ext_part != nullptr;      // partials came with Q: nothing waits for another workgroup, any grid is correct
+    if (cap < BH && !ext) { *launched = false; return PWW_OK; }      // cannot be made resident: the caller takes the two-launch path
     long nchunk = cap / BH;
+    if (nchunk < 1) nchunk = 1;
     if (nchunk > cp.nqb) nchunk = cp.nqb;
     cp.nchunk = cp.nchunk_u = (int)nchunk;
     const int hint = cp.n_gated;
@@ -753,14 +810,17 @@ static int launch_cross(CrossParams cp, hipStream_t stream, bool *launched) {
         // and a workgroup's lifetime is what the launch lasts: give those images c workgroups per head and the others u so that both
         // kinds finish together, within the resident capacity (g * c + (B - g) * u <= cap / H).
         const long per_head = cap / p.H, g = hint, rest = p.B - hint;
-        const int w = gate_balance_weight();
+        // cost of a gated-in query block in HALVES of a gated-out one: pass 1 + pass 2 with bias = 2 x (fused), pass 2 with bias alone
+        // = 1.5 x (external partials: 3.5 vs 2.6 us measured per block in round 3); + the hand-off (fused only)
+        const int w2 = ext ? 3 : 2 * gate_balance_weight();
+        const long extra2 = ext ? 0 : 4;
         long best_c = nchunk, best_u = nchunk, best_cost = -1;
         for (long c = 1; c <= cp.nqb; ++c) {
             long u = (per_head - g * c) / rest;
             if (u < 1) break;
             if (u > cp.nqb) u = cp.nqb;
             const long bc = (cp.nqb + c - 1) / c, bu = (cp.nqb + u - 1) / u;
-            const long cost = bc * w + 2 > bu ? bc * w + 2 : bu;        // (+2: the hand-off, in units of an unbiased block)
+            const long cost = bc * w2 + extra2 > 2 * bu ? bc * w2 + extra2 : 2 * bu;
             if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_c = c; best_u = u; }
         }
         if (best_c != best_u) { cp.n_gated = hint; cp.nchunk = (int)best_c; cp.nchunk_u = (int)best_u; }
@@ -828,8 +888,14 @@ static int bias_tile_mode() {
 
 int cross_attn_fused(const void *q, const void *k, const void *v, void *o, const float *bias, int stat_kind, float coeff_scalar,
                      const float *gate, const pww_attn_desc_t *d, double *stats_out, void *state, size_t state_bytes,
-                     void *workspace, size_t workspace_bytes, const pww_cross_opts_t *opts, hipStream_t stream) {
+                     void *workspace, size_t workspace_bytes, const pww_cross_opts_t *opts, hipStream_t stream,
+                     const double *ext_part, int ext_nparts) {
     if (int rc = attn_validate(q, k, v, o, bias, d)) return rc;
+    const bool ext = ext_part != nullptr;
+    if (ext && (ext_nparts < 1 || (reinterpret_cast<uintptr_t>(ext_part) & 15) || (long)ext_nparts * 32 >= (1L << 31))) {
+        set_error("cross_attn_parts: partials must be 16-byte aligned, 1 <= nparts (got %d)", ext_nparts);
+        return PWW_EINVAL;
+    }
     pww_cross_opts_t op;
     memset(&op, 0, sizeof(op));
     if (opts) {
@@ -840,11 +906,11 @@ int cross_attn_fused(const void *q, const void *k, const void *v, void *o, const
     if (!bias && !compact) { set_error("cross_attn_fused: bias map required (dense, compact or both)"); return PWW_EINVAL; }
     if (d->M > 2 * KVBLK) { set_error("cross_attn_fused: at most %d keys (got %d)", 2 * KVBLK, d->M); return PWW_ENOTSUP; }
     if (stat_kind < PWW_STAT_NONE || stat_kind > PWW_STAT_ABSMAX) { set_error("cross_attn_fused: bad statistic selector %d", stat_kind); return PWW_EINVAL; }
-    if (!state || state_bytes < cross_fused_state_bytes(d) || (reinterpret_cast<uintptr_t>(state) & 7)) {
+    if (!ext && (!state || state_bytes < cross_fused_state_bytes(d) || (reinterpret_cast<uintptr_t>(state) & 7))) {
         set_error("cross_attn_fused: state buffer missing, misaligned or too small (need %zu bytes, 8-byte aligned)", cross_fused_state_bytes(d));
         return PWW_EINVAL;
     }
-    if (!workspace || workspace_bytes < cross_fused_workspace_bytes(d) || (reinterpret_cast<uintptr_t>(workspace) & 7)) {
+    if (!ext && (!workspace || workspace_bytes < cross_fused_workspace_bytes(d) || (reinterpret_cast<uintptr_t>(workspace) & 7))) {
         set_error("cross_attn_fused: workspace missing, misaligned or too small (need %zu bytes, 8-byte aligned)", cross_fused_workspace_bytes(d));
         return PWW_EINVAL;
     }
@@ -865,8 +931,9 @@ int cross_attn_fused(const void *q, const void *k, const void *v, void *o, const
     cp.a.stats = nullptr; cp.a.stat_kind = stat_kind; cp.a.stat_count = (double)d->H * d->N * d->M; cp.a.coeff_scalar = coeff_scalar;
     cp.a.coeff_scalar_dev = op.coeff_scalar_dev;
     cp.a.bias_cols = bias_cols;
-    cp.sync = reinterpret_cast<unsigned *>(state);
-    cp.slots = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(state) + state_sync_bytes(d));
+    cp.sync = ext ? nullptr : reinterpret_cast<unsigned *>(state);
+    cp.slots = ext ? nullptr : reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(state) + state_sync_bytes(d));
+    cp.ext_part = ext_part; cp.ext_nparts = ext ? ext_nparts : 0;
     cp.stats_out = stats_out;
     cp.nqb = cp.nchunk = cp.nchunk_u = 0;
     cp.n_gated = op.gated_images > 0 && op.gated_images < d->B ? op.gated_images : 0;
@@ -888,6 +955,7 @@ int cross_attn_fused(const void *q, const void *k, const void *v, void *o, const
     if (d->dtype == PWW_DTYPE_F16) rc = wide ? dispatch_cross_form<f16, 4>(cp, stream, &launched) : dispatch_cross_form<f16, 2>(cp, stream, &launched);
     else rc = wide ? dispatch_cross_form<bf16, 4>(cp, stream, &launched) : dispatch_cross_form<bf16, 2>(cp, stream, &launched);
     if (rc || launched) return rc;
+    if (ext) { set_error("cross_attn_parts: internal error (launch with external partials not issued)"); return PWW_EINVAL; }
     // more (image, head) pairs than resident workgroups: statistic and attention as two launches, same arithmetic
     if (!bias) { set_error("cross_attn_fused: this launch cannot be made resident (B*H = %d) and the two-launch path needs the dense bias map", d->B * d->H); return PWW_ENOTSUP; }
     char *ws = reinterpret_cast<char *>(workspace);

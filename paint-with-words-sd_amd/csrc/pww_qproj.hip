@@ -1,0 +1,372 @@
+// Query projection of a cross-attention layer with the score statistic formed in the GEMM's epilogue.
+//
+//     Q = X W_q^T                               (paint_with_words/paint_with_words.py:76   query = self.to_q(hidden_states))
+//     partial(image, tile) = (max, min, sum, sum of squares) of Q_tile K_h^T over the tile's heads, rows and the M prompt keys
+//                                               (:87 attention_scores = Q K^T, reduced by weight_function: :402-405 qk.max(),
+//                                                runner.py:104, README.md:152 qk.std())
+//
+// Why here: the statistic has to exist before ANY softmax of the image can start (:106 -> :112). Rounds 2-3 formed it inside the
+// attention launch -- pass 1 over Q, a device-scope hand-off between all workgroups of an image (5-7 us, the launch had to be
+// resident as a whole, a 1 s spin limit for the impossible case), pass 2 over Q again. The producer of Q already holds every
+// Q tile in registers: multiplying the finished [32 tokens x head] tile with the request-cached K_h (77 keys) costs 9-30 extra MFMAs
+// per head and tile, and the KERNEL BOUNDARY between this launch and the attention launch is the synchronisation. The attention
+// kernel folds <= a few hundred fp64 partials per image at entry (pww_cross.hip, CrossParams::ext_part) and runs its second pass only.
+//
+// Shape of the work (gfx950, wave64):
+//   * workgroup = 4 waves, tile = (32 TW) tokens of ONE image x TN = 32 NB channels (whole heads), TW x KW = 4: TW waves own 32 tokens
+//     each, KW waves split the contraction (small layers: more workgroups; the partial accumulators meet in LDS).
+//   * Q^T tile = W_tile X_tile^T on v_mfma_f32_32x32x16: A = W rows fed in swap23 order, B = the lane's own token row -- so register r of
+//     accumulator block nb is channel 32 nb + 16 (r >> 3) + 8 hi + (r & 7) of token (lane & 31): 8 consecutive registers = 8 consecutive
+//     channels = (after rounding to T) one 16-byte piece of the Q row AND one B-operand fragment of the score MFMA (pww_tile.h).
+//   * both operands stream global -> registers (buffer loads, a ring of P k-steps in flight; rows past N read the image's last row); K of the tile's heads sits in LDS (requested first, parked while the ring fills).
+//   * epilogue: accumulators -> T -> LDS tile; the workgroup stores the tile with coalesced 16-byte row pieces, and the (token wave,
+//     head) units are dealt to the 4 waves: score blocks S^T = K_h Q^T on the MFMA, masked (rows >= N, keys >= M), reduced per lane,
+//     per wave, per workgroup -> ONE fp64 partial per workgroup. Statistics are those of the ROUNDED Q the attention kernel reads.
+#include <string.h>
+#include "pww_attn_core.h"
+
+namespace pww {
+
+struct QprojParams {
+    const void *x, *w, *k;
+    void *q;
+    const float *gate;        // [B] or null: images with gate 0 (unconditional rows of a CFG-folded batch) get Q but no statistic
+    double *partials;         // [B][nparts][4] = { max, min, sum, sum of squares }; rows of gated-out images are not written
+    int B, N, Cin, C, D, M;
+    long x_sb, x_sn, q_sb, q_sn, k_sb, k_sm;     // elements
+    int ntile, ncg, nparts;   // token tiles per image, channel groups, partials per image (= ntile * ncg)
+    int fields;               // which of the four fields anybody will read: bit 0 max, 1 min, 2 sum, 3 sum of squares
+};
+
+constexpr int QP_RING = 5;            // k-steps (16 channels of the contraction) in flight per wave
+constexpr int QP_MAX_KEYS = 128;
+
+template <typename T, int NB, int TW, int KW>
+__global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p) {
+    typedef typename Vec<T>::v8 V8;
+    static_assert(TW * KW == 4, "four waves per workgroup");
+    constexpr int TN = NB * 32, TM = TW * 32, P = QP_RING;
+    constexpr int ROWB = TN * 2 + 16;                 // LDS row of TN channels: +16 bytes makes 16 rows read at one column hit 16 different 4-bank groups
+    constexpr int CPR = TN / 8;                       // 16-byte chunks per row
+    constexpr int RED_BYTES = NB * 16 * 64 * 4;       // one wave's fp32 accumulators
+    constexpr int NRED = KW == 1 ? 0 : (KW == 2 ? TW : 2);
+    constexpr int KCH = (QP_MAX_KEYS * CPR + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [K tile: M rows][work: reduction buffers / Q tile][red: 4 x 4 f64]
+    const int kt_bytes = (p.M * ROWB + 15) & ~15;
+    char *Kt = smem;
+    char *work = smem + kt_bytes;
+    constexpr int WORK_BYTES = NRED * RED_BYTES > TM * ROWB ? NRED * RED_BYTES : TM * ROWB;
+    double *red = reinterpret_cast<double *>(work + WORK_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int tw = wave % TW, kw = wave / TW;
+
+    // workgroup -> (image, token tile, channel group): XCD x (= blockIdx & 7) always works on channel group x % ncg, so an XCD's L2
+    // holds ONE slice of W_q (<= 820 KB) for the whole launch
+    int cg, t;
+    if ((8 % p.ncg) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = 8 / p.ncg;
+        cg = xcd % p.ncg;
+        t = j * per + xcd / p.ncg;
+    } else {
+        cg = blockIdx.x % p.ncg;
+        t = blockIdx.x / p.ncg;
+    }
+    if (t >= p.B * p.ntile) return;          // (whole workgroup: no barrier is skipped by a part of it)
+    const int b = t / p.ntile, tile = t - b * p.ntile;
+    const int row0 = tile * TM;              // first token of the tile
+
+    const T *Xb = reinterpret_cast<const T *>(p.x) + b * p.x_sb;
+    const T *Wg = reinterpret_cast<const T *>(p.w) + (long)cg * TN * p.Cin;
+    const T *Kb = reinterpret_cast<const T *>(p.k) + b * p.k_sb + cg * TN;
+    T *Qb = reinterpret_cast<T *>(p.q) + b * p.q_sb + cg * TN;
+    const float gate = p.gate ? p.gate[b] : 1.f;          // (requested early, looked at in the epilogue)
+
+    // X and W: every address the loop forms is valid memory (token rows past N are CLAMPED to the last row: their Q rows are never stored
+    // and their scores are masked), so these two descriptors span the whole 2 GiB window and nothing depends on how the range check
+    // treats the scalar offset that carries the k-step
+    const auto srd_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Xb), 0, 0x80000000u, 0x00020000);
+    const auto srd_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Wg), 0, 0x80000000u, 0x00020000);
+    const auto srd_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Kb), 0, (unsigned)((((long)p.M - 1) * p.k_sm + TN) * 2), 0x00020000);
+
+    // ---- K of the tile's heads: requested FIRST (its data returns first: vmcnt retires in order), parked in LDS while the operand ring fills
+    u32x4 kreg[KCH];
+    const int nkchunk = p.M * CPR;
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+        const int c = tid + i * 256, row = c / CPR, ch = c - row * CPR;
+        kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_k, c < nkchunk ? (unsigned)((row * p.k_sm + ch * 8) * 2) : OOB_OFF, 0, 0);
+    }
+
+    // ---- main loop: acc[nb] (32 channels x 32 tokens) += W[channels][16 k] X[tokens][16 k]^T over this wave's share of the contraction
+    const int S = p.Cin / (16 * KW);                       // k-steps of this wave (a multiple of P: the host checks)
+    const int nrow = row0 + tw * 32 + l31;
+    const unsigned kbase = (unsigned)(kw * S * 32);        // byte offset of the wave's first k-step within a row
+    const unsigned voff_x = (unsigned)((long)(nrow < p.N ? nrow : p.N - 1) * p.x_sn * 2) + (unsigned)(hi * 16) + kbase;
+    const unsigned voff_w = (unsigned)(swap23(l31) * p.Cin * 2 + hi * 16) + kbase;
+    const unsigned wblk = (unsigned)(32 * p.Cin * 2);      // bytes between two 32-channel blocks of W
+    V8 xr[P], wr[P][NB];
+    auto issue = [&](int slot, int ks) {
+        xr[slot] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff_x, (unsigned)(ks * 32), 0));
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+            wr[slot][nb] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(srd_w, voff_w, (unsigned)(ks * 32) + (unsigned)nb * wblk, 0));
+    };
+#pragma unroll
+    for (int j = 0; j < P; ++j) issue(j, j);
+
+    {   // park K (waits for the K loads only: the ring's loads were issued after them)
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int c = tid + i * 256;
+            if (c < nkchunk) { const int row = c / CPR, ch = c - row * CPR; *reinterpret_cast<u32x4 *>(Kt + row * ROWB + ch * 16) = kreg[i]; }
+        }
+    }
+
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    for (int ks0 = 0; ks0 + P < S; ks0 += P) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma32(wr[j][nb], xr[j], acc[nb]);
+            issue(j, ks0 + P + j);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < P; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma32(wr[j][nb], xr[j], acc[nb]);
+
+    // ---- the contraction split over KW waves: partial accumulators meet in LDS (fp32, lane-contiguous 16-byte pieces: conflict-free)
+    auto red_store = [&](char *buf) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                *reinterpret_cast<f32x4 *>(buf + ((nb * 4 + r4) * 64 + lane) * 16) = f32x4{acc[nb][r4 * 4], acc[nb][r4 * 4 + 1], acc[nb][r4 * 4 + 2], acc[nb][r4 * 4 + 3]};
+    };
+    auto red_add = [&](const char *buf) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(buf + ((nb * 4 + r4) * 64 + lane) * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[nb][r4 * 4 + j] += v[j];
+            }
+    };
+    if constexpr (KW == 2) {
+        if (kw == 1) red_store(work + tw * RED_BYTES);
+        __syncthreads();
+        if (kw == 0) red_add(work + tw * RED_BYTES);
+        __syncthreads();                     // (the Q tile below aliases the reduction buffers)
+    } else if constexpr (KW == 4) {
+        if (kw >= 2) red_store(work + (kw - 2) * RED_BYTES);
+        __syncthreads();
+        if (kw < 2) red_add(work + kw * RED_BYTES);
+        __syncthreads();
+        if (kw == 1) red_store(work);
+        __syncthreads();
+        if (kw == 0) red_add(work);
+        __syncthreads();
+    }
+
+    // ---- Q tile, rounded to T, into LDS: row = token, 16-byte piece (nb, half, hi) = channels 32 nb + 16 half + 8 hi .. + 7
+    char *Qt = work;
+    if (kw == 0) {
+        char *qrow = Qt + (tw * 32 + l31) * ROWB + hi * 16;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                V8 v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (T)acc[nb][half * 8 + j];
+                *reinterpret_cast<V8 *>(qrow + nb * 64 + half * 32) = v;
+            }
+    }
+    __syncthreads();
+
+    // ---- (a) the workgroup writes its tile: 16-byte pieces, consecutive threads = consecutive pieces of a row
+    for (int c = tid; c < TM * CPR; c += 256) {
+        const int row = c / CPR, ch = c - row * CPR;
+        if (row0 + row < p.N)
+            *reinterpret_cast<u32x4 *>(Qb + (long)(row0 + row) * p.q_sn + ch * 8) = *reinterpret_cast<const u32x4 *>(Qt + row * ROWB + ch * 16);
+    }
+
+    // ---- (b) statistic partial of the tile
+    if (p.fields == 0 || gate == 0.f) return;            // workgroup-uniform
+    const int HT = TN / p.D;                              // heads in the tile
+    const int nkb = (p.M + 31) >> 5;
+    const bool ragged_heads = (p.D & 15) != 0;            // head boundaries inside a 16-channel slice (d = 40): the foreign half is masked
+    const bool f_max = p.fields & 1, f_min = p.fields & 2, f_sum = p.fields & 4, f_sq = p.fields & 8;
+    float vmax = -INFINITY, vmin = INFINITY;
+    double dsum = 0.0, dsq = 0.0;
+    const int krow = swap23(l31);
+    for (int u = wave; u < TW * HT; u += 4) {
+        const int tu = u % TW, hh = u / TW;
+        const bool rvalid = row0 + tu * 32 + l31 < p.N;
+        const int ks_lo = (hh * p.D) >> 4, ks_hi = ((hh + 1) * p.D - 1) >> 4;
+        f32x16 s[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+        const char *qp = Qt + (tu * 32 + l31) * ROWB + hi * 16;
+        const char *kp = Kt + krow * ROWB + hi * 16;
+        for (int ks = ks_lo; ks <= ks_hi; ++ks) {
+            V8 qf = *reinterpret_cast<const V8 *>(qp + ks * 32);
+            if (ragged_heads && (ks * 16 + hi * 8) / p.D != hh) qf = zero8<V8>();
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+                if (kb < nkb) s[kb] = mfma32(*reinterpret_cast<const V8 *>(kp + kb * 32 * ROWB + ks * 32), qf, s[kb]);       // (rows past M: whatever LDS holds -- those scores are masked below)
+        }
+        float usum = 0.f, usq = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            if (kb < nkb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool live = rvalid && key_of(kb, r, hi) < p.M;
+                    const float x = s[kb][r];
+                    if (f_max) vmax = fmaxf(vmax, live ? x : -INFINITY);
+                    if (f_min) vmin = fminf(vmin, live ? x : INFINITY);
+                    if (f_sum) usum += live ? x : 0.f;
+                    if (f_sq) usq += live ? x * x : 0.f;
+                }
+            }
+        }
+        dsum += (double)usum;
+        dsq += (double)usq;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+        vmin = fminf(vmin, __shfl_xor(vmin, off));
+        dsum += __shfl_xor(dsum, off);
+        dsq += __shfl_xor(dsq, off);
+    }
+    if (lane == 0) { red[wave * 4 + 0] = (double)vmax; red[wave * 4 + 1] = (double)vmin; red[wave * 4 + 2] = dsum; red[wave * 4 + 3] = dsq; }
+    __syncthreads();
+    if (tid == 0) {
+        double m = red[0], n = red[1], a = red[2], q2 = red[3];
+        for (int w = 1; w < 4; ++w) { m = fmax(m, red[w * 4]); n = fmin(n, red[w * 4 + 1]); a += red[w * 4 + 2]; q2 += red[w * 4 + 3]; }
+        double *out = p.partials + ((long)b * p.nparts + (long)tile * p.ncg + cg) * 4;
+        out[0] = m; out[1] = n; out[2] = a; out[3] = q2;
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------------------
+
+struct QprojPlan { int nb, tw, kw; };
+
+// Tile shape for a problem: the widest tile that still gives the chip ~200 workgroups, else the one with the most workgroups.
+// TN = 320 channels needs C % 320 == 0 and whole heads per tile (320 % D == 0); TN = 160 likewise with 160.
+static bool qproj_plan(const pww_qproj_desc_t *d, QprojPlan *out) {
+    const int C = d->H * d->D;
+    const QprojPlan cand[] = {{10, 4, 1}, {10, 2, 2}, {10, 1, 4}, {5, 4, 1}, {5, 2, 2}, {5, 1, 4}};
+    long best_wg = 0;
+    bool found = false;
+    for (const QprojPlan &c : cand) {
+        const int tn = c.nb * 32, tm = c.tw * 32;
+        if (C % tn || tn % d->D || d->Cin % (16 * c.kw * QP_RING)) continue;
+        const long wgs = (long)d->B * ((d->N + tm - 1) / tm) * (C / tn);
+        if (wgs >= 200) { *out = c; return true; }
+        if (wgs > best_wg) { best_wg = wgs; *out = c; found = true; }
+    }
+    return found;
+}
+
+int qproj_parts(const pww_qproj_desc_t *d) {
+    QprojPlan pl;
+    if (!d || d->B <= 0 || d->N <= 0 || d->H <= 0 || d->D <= 0 || !qproj_plan(d, &pl)) return 0;
+    return ((d->N + pl.tw * 32 - 1) / (pl.tw * 32)) * (d->H * d->D / (pl.nb * 32));
+}
+
+template <typename T, int NB, int TW, int KW>
+static int launch_qproj(const QprojParams &p, hipStream_t stream) {
+    constexpr int TN = NB * 32, TM = TW * 32, ROWB = TN * 2 + 16, RED_BYTES = NB * 16 * 64 * 4;
+    constexpr int NRED = KW == 1 ? 0 : (KW == 2 ? TW : 2);
+    constexpr size_t work = (size_t)NRED * RED_BYTES > (size_t)TM * ROWB ? (size_t)NRED * RED_BYTES : (size_t)TM * ROWB;
+    const size_t lds = (((size_t)p.M * ROWB + 15) & ~(size_t)15) + work + 16 * sizeof(double);
+    auto kern = qproj_stat_kernel<T, NB, TW, KW>;
+    static thread_local size_t lds_attr[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // per device (hipFuncSetAttribute is per device)
+    int dev = 0;
+    if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return PWW_EHIP;
+    if (lds > 64 * 1024 && (dev >= 8 || lds > lds_attr[dev])) {
+        if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"))
+            return PWW_EHIP;
+        if (dev < 8) lds_attr[dev] = lds;
+    }
+    const long tiles = (long)p.B * p.ntile;
+    long grid;
+    if (8 % p.ncg == 0) { const int per = 8 / p.ncg; grid = ((tiles + per - 1) / per) * 8; }
+    else grid = tiles * p.ncg;
+    launch_attn_kernel(kern, dim3((unsigned)grid), dim3(256), lds, stream, p);
+    return check_hip(hipGetLastError(), "qproj_stat_kernel launch");
+}
+
+int qproj_stat(const void *x, const void *w, void *q, const void *k, const float *gate, const pww_qproj_desc_t *d, int stat_kind,
+               double *partials, size_t partials_bytes, hipStream_t stream) {
+    if (!x || !w || !q || !k || !d) { set_error("qproj_stat: null argument"); return PWW_EINVAL; }
+    if (!arch_ok()) return PWW_ENOTSUP;
+    if (d->dtype != PWW_DTYPE_F16 && d->dtype != PWW_DTYPE_BF16) { set_error("qproj_stat: dtype %d unsupported", d->dtype); return PWW_ENOTSUP; }
+    if (d->B <= 0 || d->N <= 0 || d->H <= 0 || d->D <= 0 || d->M <= 0 || d->Cin <= 0) { set_error("qproj_stat: empty problem"); return PWW_EINVAL; }
+    if (d->D % 8 || d->M > QP_MAX_KEYS) { set_error("qproj_stat: head dim %d must be a multiple of 8 and M = %d at most %d", d->D, d->M, QP_MAX_KEYS); return PWW_ENOTSUP; }
+    QprojPlan pl;
+    if (!qproj_plan(d, &pl)) {
+        set_error("qproj_stat: no tile shape for C = %d (a multiple of 160 or 320 holding whole heads of %d) and Cin = %d (a multiple of 80)", d->H * d->D, d->D, d->Cin);
+        return PWW_ENOTSUP;
+    }
+    const auto mis = [](const void *ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) != 0; };
+    if (mis(x) || mis(w) || mis(q) || mis(k) || d->x_stride[0] % 8 || d->x_stride[1] % 8 || d->q_stride[0] % 8 || d->q_stride[1] % 8 || d->k_stride[0] % 8 ||
+        d->k_stride[1] % 8) {
+        set_error("qproj_stat: pointers and strides must keep every row 16-byte aligned");
+        return PWW_EINVAL;
+    }
+    const int C = d->H * d->D;
+    if (d->x_stride[1] < d->Cin || d->q_stride[1] < C || d->k_stride[1] < C) { set_error("qproj_stat: row strides shorter than the rows"); return PWW_EINVAL; }
+    if (((long)d->N * d->x_stride[1] + d->Cin) * 2 >= (1L << 31) || (long)C * d->Cin * 2 >= (1L << 31)) { set_error("qproj_stat: an image's activations exceed 2 GiB"); return PWW_ENOTSUP; }
+    QprojParams p;
+    p.x = x; p.w = w; p.k = k; p.q = q; p.gate = gate; p.partials = partials;
+    p.B = d->B; p.N = d->N; p.Cin = d->Cin; p.C = C; p.D = d->D; p.M = d->M;
+    p.x_sb = d->x_stride[0]; p.x_sn = d->x_stride[1]; p.q_sb = d->q_stride[0]; p.q_sn = d->q_stride[1];
+    p.k_sb = d->k_stride[0]; p.k_sm = d->k_stride[1];
+    p.ntile = (d->N + pl.tw * 32 - 1) / (pl.tw * 32);
+    p.ncg = C / (pl.nb * 32);
+    p.nparts = p.ntile * p.ncg;
+    switch (stat_kind) {
+        case PWW_STAT_NONE: p.fields = 0; break;
+        case PWW_STAT_MAX: p.fields = 1; break;
+        case PWW_STAT_MIN: p.fields = 2; break;
+        case PWW_STAT_ABSMAX: p.fields = 3; break;
+        case PWW_STAT_MEAN: p.fields = 4; break;
+        case PWW_STAT_STD: p.fields = 12; break;
+        case PWW_STAT_ALL: p.fields = 15; break;
+        default: set_error("qproj_stat: bad statistic selector %d", stat_kind); return PWW_EINVAL;
+    }
+    if (p.fields) {
+        if (!partials || partials_bytes < (size_t)d->B * p.nparts * 4 * sizeof(double) || (reinterpret_cast<uintptr_t>(partials) & 7)) {
+            set_error("qproj_stat: partials buffer missing, misaligned or too small (need %zu bytes)", (size_t)d->B * p.nparts * 4 * sizeof(double));
+            return PWW_EINVAL;
+        }
+    }
+#define PWW_QP(T)                                                                      \
+    if (pl.nb == 10 && pl.tw == 4) return launch_qproj<T, 10, 4, 1>(p, stream);        \
+    if (pl.nb == 10 && pl.tw == 2) return launch_qproj<T, 10, 2, 2>(p, stream);        \
+    if (pl.nb == 10 && pl.tw == 1) return launch_qproj<T, 10, 1, 4>(p, stream);        \
+    if (pl.nb == 5 && pl.tw == 4) return launch_qproj<T, 5, 4, 1>(p, stream);          \
+    if (pl.nb == 5 && pl.tw == 2) return launch_qproj<T, 5, 2, 2>(p, stream);          \
+    return launch_qproj<T, 5, 1, 4>(p, stream);
+    if (d->dtype == PWW_DTYPE_F16) { PWW_QP(f16) }
+    PWW_QP(bf16)
+#undef PWW_QP
+}
+
+}  // namespace pww

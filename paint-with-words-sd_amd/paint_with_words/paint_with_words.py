@@ -175,7 +175,7 @@ def paint_with_words(
                         guidance_scale, weight_function, unconditional_input_prompt,
                         init_images=None if init_image is None else [init_image], strength=strength, shared=True)
     if return_latents:
-        return latents
+        return _sampler_for(tools[1], tools[4], DEFAULT_MODE).checked(latents)
     image = _pil_from_latents(tools[0], latents)[0]
     _sampler_for(tools[1], tools[4], DEFAULT_MODE).check_errors()     # (the decode above synchronised already)
     return image
@@ -232,7 +232,7 @@ def paint_with_words_batch(
         for c in {id(c): c for c in originals}.values():
             _extract_seed_and_sigma_from_context(c)
     if return_latents:
-        return latents
+        return _sampler_for(tools[1], tools[4], DEFAULT_MODE).checked(latents)
     images = _pil_from_latents(tools[0], latents)
     _sampler_for(tools[1], tools[4], DEFAULT_MODE).check_errors()
     return images

@@ -188,7 +188,7 @@ def paint_with_words_inpaint(
                                 [seed], num_inference_steps, guidance_scale, weight_function, unconditional_input_prompt,
                                 strength, shared=True)
     if return_latents:
-        return latents
+        return _sampler_for(tools[1], tools[4], _mode()).checked(latents)
     image = _pil_from_latents(tools[0], latents)[0]
     _sampler_for(tools[1], tools[4], _mode()).check_errors()
     return image
@@ -236,7 +236,7 @@ def paint_with_words_inpaint_batch(
     latents = _generate_inpaint(tools, device, ctxs, maps, masks, inits, prompts, seeds, num_inference_steps, guidance_scale,
                                 weight_function, unconditional_input_prompt, strength, shared=s1 and s2 and s3)
     if return_latents:
-        return latents
+        return _sampler_for(tools[1], tools[4], _mode()).checked(latents)
     images = _pil_from_latents(tools[0], latents)
     _sampler_for(tools[1], tools[4], _mode()).check_errors()
     return images

@@ -18,7 +18,8 @@ EXPORTS = ("pww_version", "pww_last_error", "pww_device_arch", "pww_self_attn_fw
            "pww_cross_attn_fwd_stat", "pww_cross_attn_fwd_fused", "pww_cross_attn_fwd_stat_ex", "pww_cross_attn_fwd_fused_ex",
            "pww_cross_fused_workspace_bytes", "pww_cross_fused_state_bytes",
            "pww_qk_reduce", "pww_mask_build", "pww_mask_build_rgb", "pww_mask_build_f32", "pww_resize_tokens", "pww_gauss_blur", "pww_inpaint_prep", "pww_cfg_combine", "pww_store_f32",
-           "pww_workspace_bytes", "pww_profile_arm", "pww_profile_elapsed_us", "pww_profile_reset", "pww_debug_timeline")
+           "pww_workspace_bytes", "pww_profile_arm", "pww_profile_elapsed_us", "pww_profile_reset", "pww_debug_timeline",
+           "pww_qproj_stat", "pww_qproj_parts", "pww_cross_attn_fwd_parts", "pww_mask_build_f32_levels")
 
 
 class AttnDesc(ctypes.Structure):
@@ -35,6 +36,13 @@ class CrossOpts(ctypes.Structure):
     _fields_ = [("size", ctypes.c_uint32), ("bias_cols", ctypes.c_int32), ("coeff_scalar_dev", ctypes.c_void_p),
                 ("bias_compact", ctypes.c_void_p), ("col_idx", ctypes.c_void_p), ("R", ctypes.c_int32), ("gated_images", ctypes.c_int32),
                 ("compact_stride", ctypes.c_int64 * 2), ("col_idx_stride", ctypes.c_int64)]
+
+
+class QprojDesc(ctypes.Structure):
+    """struct pww_qproj_desc (query projection + score-statistic partials)."""
+    _fields_ = [("dtype", ctypes.c_int32), ("B", ctypes.c_int32), ("N", ctypes.c_int32), ("Cin", ctypes.c_int32), ("H", ctypes.c_int32),
+                ("D", ctypes.c_int32), ("M", ctypes.c_int32), ("x_stride", ctypes.c_int64 * 2), ("q_stride", ctypes.c_int64 * 2),
+                ("k_stride", ctypes.c_int64 * 2)]
 
 
 class Region(ctypes.Structure):
@@ -73,6 +81,14 @@ def load():
                                                ctypes.POINTER(CrossOpts), vp]
     lib.pww_cross_attn_fwd_fused_ex.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp, ctypes.POINTER(AttnDesc), vp, vp, ctypes.c_size_t, vp,
                                                 ctypes.c_size_t, ctypes.POINTER(CrossOpts), vp]
+    lib.pww_qproj_stat.argtypes = [vp, vp, vp, vp, vp, ctypes.POINTER(QprojDesc), i32, vp, ctypes.c_size_t, vp]
+    lib.pww_qproj_stat.restype = ctypes.c_int
+    lib.pww_qproj_parts.argtypes = [ctypes.POINTER(QprojDesc)]
+    lib.pww_qproj_parts.restype = ctypes.c_int32
+    lib.pww_cross_attn_fwd_parts.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp, ctypes.POINTER(AttnDesc), vp, i32, vp, ctypes.POINTER(CrossOpts), vp]
+    lib.pww_cross_attn_fwd_parts.restype = ctypes.c_int
+    lib.pww_mask_build_f32_levels.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]
+    lib.pww_mask_build_f32_levels.restype = ctypes.c_int
     lib.pww_debug_timeline.argtypes = [vp, ctypes.c_size_t]
     lib.pww_debug_timeline.restype = None
     lib.pww_cross_fused_workspace_bytes.argtypes = [ctypes.POINTER(AttnDesc)]
@@ -101,8 +117,8 @@ def load():
                  "pww_cross_attn_fwd_stat_ex", "pww_cross_attn_fwd_fused_ex", "pww_qk_reduce", "pww_mask_build",
                  "pww_mask_build_rgb", "pww_mask_build_f32", "pww_resize_tokens", "pww_gauss_blur", "pww_inpaint_prep", "pww_cfg_combine"):
         getattr(lib, name).restype = ctypes.c_int
-    if lib.pww_version() // 100 != 1 or lib.pww_version() < 121:
-        raise PwwHipError("libpww_hip ABI version %d is not 1.x >= 1.21 (rebuild: python paint-with-words-sd_amd/build.py)" % lib.pww_version())
+    if lib.pww_version() // 100 != 1 or lib.pww_version() < 122:
+        raise PwwHipError("libpww_hip ABI version %d is not 1.x >= 1.22 (rebuild: python paint-with-words-sd_amd/build.py)" % lib.pww_version())
     _lib = lib
     return lib
 

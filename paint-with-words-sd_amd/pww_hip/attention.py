@@ -32,6 +32,10 @@ GATED_ROWS = "_PWW_GATED_ROWS"     # private context key: int, _PWW_ROW_GATE is 
 # statistic + attention in one launch (pww_cross_attn_fwd_fused); 0 = two launches (A/B). The fused launch needs all its workgroups
 # resident at once: two ranks sharing one device (PWW_DIST_ONE_DEVICE, a test mode) take the two-launch path.
 FUSED_CROSS = os.environ.get("PWW_FUSED_CROSS", "1") != "0" and os.environ.get("PWW_DIST_ONE_DEVICE", "0") != "1"
+# Default since round 4: the statistic's partials come out of the to_q GEMM's epilogue (pww_qproj_stat) and the attention launch folds them
+# at entry (pww_cross_attn_fwd_parts) -- no in-kernel hand-off, nothing has to be resident, no time-out path. 0 = the round-3 launch
+# (pww_cross_attn_fwd_fused: statistic + hand-off inside the attention kernel), kept as the A/B baseline and for shapes the GEMM does not cover.
+QPROJ_STAT = os.environ.get("PWW_QPROJ_STAT", "1") != "0"
 _warned = set()
 
 
@@ -136,13 +140,20 @@ class QKProxy:
     """
 
     def __init__(self, q, k, heads):
-        self._q, self._k, self._heads = q, k, heads
+        """q: the [B, N, C] query tensor, or a _LazyQuery (cross-attention: the projection itself is deferred -- when the weight
+        function only asks for a global reduction, Q and the statistic come out of ONE launch, ops.qproj_stat)."""
+        self._q_src, self._k, self._heads = q, k, heads
         self._stats = None
         self._full = None
         B, N, C = q.shape
         self.shape = torch.Size((B * heads, N, k.shape[1]))
         self.dtype = q.dtype
         self.device = q.device
+
+    @property
+    def _q(self):
+        src = self._q_src
+        return src.get() if isinstance(src, _LazyQuery) else src
 
     # -- lazily computed per-image statistics ---------------------------------------------------
     def _st(self):
@@ -151,7 +162,7 @@ class QKProxy:
         return self._stats
 
     def _count(self):
-        return self.shape[0] // self._q.shape[0] * self.shape[1] * self.shape[2]
+        return self.shape[0] // self._q_src.shape[0] * self.shape[1] * self.shape[2]
 
     def _shape_out(self, t):
         t = t.to(torch.float32)
@@ -257,6 +268,24 @@ class QKProxy:
         return self._materialize()[idx]
 
 
+class _LazyQuery:
+    """`attn.to_q(hidden_states)` (:76), evaluated on first use. Shape / dtype / device are known without running it."""
+
+    def __init__(self, attn, hidden_states, dtype):
+        self.attn, self.hidden, self.value = attn, hidden_states, None
+        self.shape = torch.Size((hidden_states.shape[0], hidden_states.shape[1], attn.to_q.weight.shape[0]))
+        self.dtype, self.device = dtype, hidden_states.device
+
+    @property
+    def done(self):
+        return self.value is not None
+
+    def get(self):
+        if self.value is None:
+            self.value = self.attn.to_q(self.hidden)
+        return self.value
+
+
 class _AbsQK:
     """``qk.abs()``: its max / mean-free reductions follow from the signed statistics."""
 
@@ -347,7 +376,7 @@ class _ProbeProxy(QKProxy):
     needs the symbolic result; anything that would touch the scores says so."""
 
     def __init__(self, shape, dtype, device):   # noqa: super().__init__ deliberately not called (no q / k here)
-        self._q = self._k = None
+        self._q_src = self._k = None
         self._heads, self._stats, self._full = 1, None, None
         self.shape, self.dtype, self.device = torch.Size(shape), dtype, device
 
@@ -377,8 +406,15 @@ class CoeffSlots:
     denoise step and every weight function of the same shape -- the host re-evaluates the user's function per site and step
     on symbolic stand-ins (microseconds) and rewrites the words before each replay (reference: paint_with_words.py:479-482
     refreshes SIGMA / WEIGHT_FUNCTION in the dict every step). A weight function that is not of the form
-    c * w * reduce(qk) marks the slots `unsupported`; the sampler then falls back to one graph per step."""
+    c * w * reduce(qk) marks the slots `unsupported`; the sampler then falls back to one graph per step.
+
+    EVERY dict-context cross-attention call registers a site, also the ones whose weight function came back with no bias at all
+    (a Python number, a 0-dim tensor, a bare statistic: kind NO_BIAS -- the captured graph then holds a bias-free kernel for that
+    site). update() re-classifies every site each step and reports a change of class (no bias <-> symbolic, another statistic) as
+    "re-capture": a graph captured while `lambda w, s, qk: 0` (or a sigma-thresholded function's zero branch) was in force is
+    never replayed for a function that wants the bias."""
     MAX = 64
+    NO_BIAS = -1
 
     def __init__(self, device):
         self.dev = torch.zeros(self.MAX, dtype=torch.float32, device=device)
@@ -402,15 +438,27 @@ class CoeffSlots:
             self.unsupported = True
             return None
         if self.discover:
-            rec = dict(kind=kind, w=w, qk_shape=tuple(qk_shape), dtype=dtype)
+            rec = dict(kind=kind, w=w, qk_shape=tuple(qk_shape), dtype=dtype, device=self.dev.device)
             if i < len(self.sites):
                 self.sites[i] = rec
             else:
                 self.sites.append(rec)
-            self.dev[i:i + 1].fill_(scalar)
+            if kind != self.NO_BIAS:
+                self.dev[i:i + 1].fill_(scalar)
         elif i >= len(self.sites) or self.sites[i]["kind"] != kind or self.sites[i]["w"] is not w:
             raise PwwHipError("cross-attention call sites changed between hipGraph capture passes (site %d)" % i)
         return self.dev[i:i + 1]
+
+    @classmethod
+    def classify(cls, result):
+        """(kind, scalar) of a weight function's result: (STAT_*, c) for c * w [* stat(qk)], (NO_BIAS, 0.0) when the result adds
+        nothing softmax can see (Python number, 0-dim tensor, bare statistic), None for anything else (a tensor-valued bias)."""
+        sym = _symbolic_scalar(result)
+        if sym is not None:
+            return sym
+        if isinstance(result, LazyStat) or isinstance(result, (int, float)) or (torch.is_tensor(result) and result.dim() == 0):
+            return cls.NO_BIAS, 0.0
+        return None
 
     def update(self, weight_function, sigma):
         """Re-evaluate the weight function for every registered site at this step's sigma and move the scalars to the device
@@ -419,11 +467,12 @@ class CoeffSlots:
             return True
         vals = []
         for i, rec in enumerate(self.sites):
+            w = rec["w"]
             try:
-                res = weight_function(ScaledW(rec["w"]), sigma, _ProbeProxy(rec["qk_shape"], rec["dtype"], rec["w"].device))
+                res = weight_function(ScaledW(w) if torch.is_tensor(w) and _LAZY_W else w, sigma, _ProbeProxy(rec["qk_shape"], rec["dtype"], rec["device"]))
             except _NotSymbolic:
                 return False
-            sym = _symbolic_scalar(res)
+            sym = self.classify(res)
             if sym is None or sym[0] != rec["kind"]:
                 return False
             vals.append(sym[1])
@@ -447,8 +496,10 @@ def refresh_orig_cache(context):
     """Recompute the cached fallback maps of a request context IN PLACE (hipGraph mode: a new color map was copied into
     the static CROSS_ATTENTION_WEIGHT_ORIG tensor; the captured graphs read the resized maps by address)."""
     cache = context.get("_PWW_ORIG_CACHE")
+    if not cache:           # no layer took the fallback: the full-resolution map is not even built (conditioning.PwWContext)
+        return
     w = context.get("CROSS_ATTENTION_WEIGHT_ORIG")
-    if not cache or not torch.is_tensor(w):
+    if not torch.is_tensor(w):
         return
     for n_img, t in cache.items():
         t.copy_(_orig_weight_to_tokens(w, n_img))
@@ -522,6 +573,7 @@ def pww_attention(attn, hidden_states, context=None):
     if hidden_states.dtype != wdt and not torch.is_autocast_enabled():
         hidden_states = hidden_states.to(wdt)
     C = attn.to_q.weight.shape[0]
+    query = lazy_q = None
     # Fused projections in the dtype the reference's path computes in: under torch.autocast("cuda") (how the reference runs,
     # :60 / :392: fp16 UNet or not, fp32 text encoder :171) that is the autocast dtype, and the concatenated weights are kept
     # in it, so autocast has nothing left to cast per call.
@@ -530,7 +582,10 @@ def pww_attention(attn, hidden_states, context=None):
         qkv = F.linear(hidden_states.to(pdt), w_qkv)            # self-attention: ONE GEMM, q/k/v are strided views
         query, key, value = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
     elif context is not None and (w_kv := _fused_weight(attn, ("to_k", "to_v"), pdt)) is not None:
-        query = attn.to_q(hidden_states)
+        if is_dict:
+            lazy_q = _LazyQuery(attn, hidden_states, pdt if pdt in _HALF else torch.bfloat16)      # deferred: see the symbolic-bias branch below
+        else:
+            query = attn.to_q(hidden_states)
         kv_cache = context.get(KV_CACHE) if is_dict else None
         ent = kv_cache.get(id(attn)) if kv_cache is not None else None
         if ent is None:
@@ -544,15 +599,19 @@ def pww_attention(attn, hidden_states, context=None):
         query = attn.to_q(hidden_states)
         key = attn.to_k(context_tensor)
         value = attn.to_v(context_tensor)
-    cdt = query.dtype if query.dtype in _HALF else torch.bfloat16
-    query, key, value = _half(query, cdt), _half(key, cdt), _half(value, cdt)
+    if lazy_q is not None:
+        cdt = key.dtype if key.dtype in _HALF else torch.bfloat16
+        key, value = _half(key, cdt), _half(value, cdt)
+    else:
+        cdt = query.dtype if query.dtype in _HALF else torch.bfloat16
+        query, key, value = _half(query, cdt), _half(key, cdt), _half(value, cdt)
 
     bias = None
     gate = None
     if context is not None and is_dict:
         gate = context.get(ROW_GATE)   # folded CFG batches: per-row coefficient (1 = cond row, 0 = uncond row)
         f = context["WEIGHT_FUNCTION"]
-        n_img = query.shape[1]
+        n_img = hidden_states.shape[1]
         try:
             w = context[f"CROSS_ATTENTION_WEIGHT_{n_img}"]
         except KeyError:
@@ -565,11 +624,12 @@ def pww_attention(attn, hidden_states, context=None):
             else:
                 w = 0
         lazy_w = ScaledW(w) if torch.is_tensor(w) and _LAZY_W else w
-        bias = f(lazy_w, context["SIGMA"], QKProxy(query, key, attn.heads))
+        bias = f(lazy_w, context["SIGMA"], QKProxy(lazy_q if lazy_q is not None else query, key, attn.heads))
 
     coeff = None
     stat = None
     scratch = None
+    parts = None
     coeff_dev = None
     bias_cols = 0
     compact = None
@@ -583,16 +643,27 @@ def pww_attention(attn, hidden_states, context=None):
         # the prompt tokens (M <= 128) the statistic is formed in the attention launch itself, unless the weight
         # function already forced it to exist as a tensor. In hipGraph mode the scalar travels in a device word.
         kind, scalar = sym
-        n_img, w_map = query.shape[1], bias.w
+        n_img, w_map = hidden_states.shape[1], bias.w
         bias_cols = int(context.get(BIAS_COLS, 0) or 0)
         gated = int(context.get(GATED_ROWS, 0) or 0) if gate is not None else 0
         wc, ci = context.get(COMPACT_W + str(n_img)), context.get(COMPACT_IDX)
         if torch.is_tensor(wc) and torch.is_tensor(ci) and context.get(f"CROSS_ATTENTION_WEIGHT_{n_img}") is w_map:
             compact = (wc, ci)
         if slots is not None and not slots.unsupported:
-            coeff_dev = slots.site(kind, scalar, w_map, (query.shape[0] * attn.heads, n_img, key.shape[1]), query.dtype)
+            coeff_dev = slots.site(kind, scalar, w_map, (hidden_states.shape[0] * attn.heads, n_img, key.shape[1]), cdt)
         have_stats = bias.stat is not None and bias.stat._proxy._stats is not None
-        if FUSED_CROSS and not have_stats and key.shape[1] <= ops.FUSED_MAX_KEYS:
+        # Q and the statistic's partials from ONE launch (the to_q GEMM with the score statistic in its epilogue): taken when the weight
+        # function left both untouched (nobody asked for the query or the statistics as tensors) and the GEMM covers the shape
+        if (QPROJ_STAT and lazy_q is not None and not lazy_q.done and not have_stats and kind != ops.STAT_NONE and pdt in _HALF
+                and key.dtype == pdt and key.shape[1] <= ops.FUSED_MAX_KEYS and getattr(attn.to_q, "bias", None) is None):
+            wq = _fused_weight(attn, ("to_q",), pdt)
+            x = hidden_states if hidden_states.dtype == pdt else hidden_states.to(pdt)
+            if wq is not None and ops.qproj_parts(x, wq, key, attn.heads) > 0:
+                query, parts = ops.qproj_stat(x, wq, key, attn.heads, kind, gate=gate)
+                stat = (None, kind, scalar)
+        if parts is not None:
+            pass
+        elif FUSED_CROSS and not have_stats and key.shape[1] <= ops.FUSED_MAX_KEYS:
             stat = (None, kind, scalar)
             scratch = attn.__dict__.get("_pww_fused_scratch")
             if scratch is None:
@@ -606,28 +677,34 @@ def pww_attention(attn, hidden_states, context=None):
         if bias.stat is not None:
             bias = ScaledW(bias.w, bias.coeff * bias.stat.materialize())
         c = bias.coeff
-        B = query.shape[0]
+        B = hidden_states.shape[0]
         if torch.is_tensor(c):
             coeff = c.reshape(-1).to(torch.float32)
             coeff = coeff.expand(B) if coeff.numel() == 1 else coeff
         else:
-            coeff = torch.full((B,), float(c), dtype=torch.float32, device=query.device)
+            coeff = torch.full((B,), float(c), dtype=torch.float32, device=hidden_states.device)
         if gate is not None:
             coeff = coeff * gate
         gate = coeff
         bias = bias.w
+    if query is None:       # (every path but the one above: the plain projection)
+        query = _half(lazy_q.get(), cdt)
     if isinstance(bias, QKProxy):
         bias = bias._materialize()
     if not torch.is_tensor(bias) or bias.dim() == 0:
         # python scalar / 0-dim tensor: a constant added to every logit of a row cancels in softmax
         # (the unconditional pass returns 0.0, :493)
         bias = None
+        if slots is not None and not slots.unsupported and is_dict:
+            # hipGraph mode: this call site is captured WITHOUT a bias kernel -- say so, or the graph would be replayed for a
+            # weight function that wants one (CoeffSlots.update re-classifies every site each step)
+            slots.site(CoeffSlots.NO_BIAS, 0.0, w, (hidden_states.shape[0] * attn.heads, hidden_states.shape[1], key.shape[1]), cdt)
     elif slots is not None and stat is None:
         slots.unsupported = True       # a materialised bias tensor depends on sigma through torch ops
     if bias is None:
         return ops.attention(query, key, value, attn.heads, attn.scale)
     return ops.attention(query, key, value, attn.heads, attn.scale, bias=bias, bias_coeff=gate, stat=stat, scratch=scratch,
-                         coeff_dev=coeff_dev, bias_cols=bias_cols, compact=compact, gated=gated)
+                         coeff_dev=coeff_dev, bias_cols=bias_cols, compact=compact, gated=gated, parts=parts)
 
 
 def inj_forward(self, hidden_states, context=None, mask=None):

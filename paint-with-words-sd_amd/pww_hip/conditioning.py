@@ -17,6 +17,50 @@ from . import ops
 COMPACT_BIAS = os.environ.get("PWW_COMPACT_BIAS", "0") == "1"   # see prepare_conditioning: private compact weight maps, opt-in
 
 
+class PwWContext(dict):
+    """The encoder_hidden_states dict of the PwW protocol (:370-386) with entries that are BUILT ON FIRST ACCESS.
+
+    `CROSS_ATTENTION_WEIGHT_ORIG` (:343-345) is 80.7 MB at 512 x 512 and is only ever read on inj_forward's KeyError path
+    (:95-101: a layer whose token count has no per-resolution map -- image sizes that are not multiples of 64, a latent sized
+    differently from the color map). The reference builds it for every request; here `context["CROSS_ATTENTION_WEIGHT_ORIG"]`
+    runs the mask kernel at ratio 1 the first time somebody asks (dict.__missing__), so requests that never take the fallback
+    never pay for it, and code that indexes the dict the way the reference does sees no difference. `in`, `.get()` and `.copy()`
+    know about the pending entries; `dict(ctx)` / `.items()` see only what has been built."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self._thunks = {}
+
+    def set_lazy(self, key, thunk):
+        self._thunks[key] = thunk
+        return self
+
+    def pending(self, key):
+        return key in self._thunks and not dict.__contains__(self, key)
+
+    def __missing__(self, key):
+        thunk = self._thunks.get(key)
+        if thunk is None:
+            raise KeyError(key)
+        value = thunk()
+        self[key] = value
+        return value
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._thunks
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def copy(self):
+        c = PwWContext(self)
+        c._thunks = dict(self._thunks)
+        return c
+
+
 def always_round(x):
     """:18-26 (round half up for the non-negative sizes it is applied to)."""
     intx = int(x)
@@ -83,8 +127,9 @@ def gaussian_blur_mask(mask, sigma, ksize=39):
     return ops.gauss_blur(mask, sigma, ksize)
 
 
-def build_weight_maps(color_map_rgb, table, token_lis, device, extra_sigmas=None, with_orig=True):
-    """RGB map -> {"ORIG": [H, W, T], N_8: [N, T], ...} fp32 device tensors, keyed like :370-377.
+def build_weight_maps(color_map_rgb, table, token_lis, device, extra_sigmas=None, with_orig=False):
+    """RGB map -> {N_8: [N, T], ...} fp32 device tensors, keyed like :370-377 -- ONE launch for the four resolutions -- plus
+    "ORIG_THUNK": a callable that builds the [H, W, T] ratio-1 map on demand (with_orig=True: built now, key "ORIG").
     color_map_rgb: uint8 numpy / tensor [H, W, 3]."""
     rgb = torch.as_tensor(np.ascontiguousarray(color_map_rgb), dtype=torch.uint8).to(device)
     H, W = rgb.shape[:2]
@@ -102,16 +147,17 @@ def build_weight_maps(color_map_rgb, table, token_lis, device, extra_sigmas=None
                 m = blurred[r] = gaussian_blur_mask(m, extra_sigmas[r])
             masks.append(m)
         masks = torch.stack(masks)
-        outs = ops.mask_build_f32(masks, cols, ratios + ((1,) if with_orig else ()))
+        outs = ops.mask_build_f32(masks, cols, ratios)
+        orig_thunk = lambda: ops.mask_build_f32(masks, cols, (1,))[1].reshape(H, W, len(token_lis))      # noqa: E731
     else:
         outs = ops.mask_build(rgb, regions, cols, ratios)
-        if with_orig:
-            outs.update(ops.mask_build(rgb, regions, cols, (1,)))
+        orig_thunk = lambda: ops.mask_build(rgb, regions, cols, (1,))[1].reshape(H, W, len(token_lis))    # noqa: E731
     maps = {}
     for r in ratios:
         maps[always_round(H / r) * always_round(W / r)] = outs[r]
+    maps["ORIG_THUNK"] = orig_thunk
     if with_orig:
-        maps["ORIG"] = outs[1].reshape(H, W, len(token_lis))
+        maps["ORIG"] = orig_thunk()
     maps["_BLURRED"] = blurred      # region ordinal -> blurred float mask (region seeding thresholds these, :300-304)
     maps["_COLS"] = [c for c, lst in enumerate(cols) if lst]     # prompt positions that carry any region weight (:257-268)
     return maps
@@ -154,7 +200,7 @@ def _encode_text_color_inputs(text_encoder, tokenizer, device, color_map_image, 
         nz_cols = maps.pop("_COLS")
     else:   # empty color_context (:242-243): all-zero maps
         maps = {k: torch.zeros((k, len(token_lis)), dtype=torch.float32, device=device) for k in keys}
-        maps["ORIG"] = torch.zeros((height, width, len(token_lis)), dtype=torch.float32, device=device)
+        maps["ORIG_THUNK"] = lambda: torch.zeros((height, width, len(token_lis)), dtype=torch.float32, device=device)
         blurred = {}
         nz_cols = None
 
@@ -165,7 +211,8 @@ def _encode_text_color_inputs(text_encoder, tokenizer, device, color_map_image, 
     if dtype is not None:
         cond_embeddings, uncond_embeddings = cond_embeddings.to(dtype), uncond_embeddings.to(dtype)
 
-    encoder_hidden_states = {"CONTEXT_TENSOR": cond_embeddings, "CROSS_ATTENTION_WEIGHT_ORIG": maps["ORIG"]}
+    # CROSS_ATTENTION_WEIGHT_ORIG (:343-345, :372) is built when somebody indexes it (PwWContext): only inj_forward's KeyError path does
+    encoder_hidden_states = PwWContext({"CONTEXT_TENSOR": cond_embeddings}).set_lazy("CROSS_ATTENTION_WEIGHT_ORIG", maps["ORIG_THUNK"])
     uncond_encoder_hidden_states = {"CONTEXT_TENSOR": uncond_embeddings, "CROSS_ATTENTION_WEIGHT_ORIG": 0}
     for k in keys:
         encoder_hidden_states[f"CROSS_ATTENTION_WEIGHT_{k}"] = maps[k]

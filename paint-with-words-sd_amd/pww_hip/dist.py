@@ -31,9 +31,22 @@ def init_from_env(device_type="cuda"):
             # N ranks of one node would otherwise run MIOpen's find mode against ONE shared user perf-db file (file-lock
             # contention, N x the same search racing on the same records): one user db per local rank. Must be in the environment
             # before the process's first MIOpen call, i.e. here.
-            base = os.environ.get("PWW_MIOPEN_DB_BASE", os.path.join(os.path.expanduser("~"), ".config", "miopen"))
-            os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(base, "pww_rank%d" % local))
-            os.makedirs(os.environ["MIOPEN_USER_DB_PATH"], exist_ok=True)
+            if "MIOPEN_USER_DB_PATH" not in os.environ:
+                base = os.environ.get("PWW_MIOPEN_DB_BASE", os.path.join(os.path.expanduser("~"), ".config", "miopen"))
+                path = os.path.join(base, "pww_rank%d" % local)
+                if not os.path.isdir(path):
+                    # first use: seed the rank's db with the user's existing one (a tuned perf-db keeps paying off: no rank
+                    # repeats a find search whose answer is already on disk)
+                    os.makedirs(path, exist_ok=True)
+                    import shutil
+                    for name in (os.listdir(base) if os.path.isdir(base) else []):
+                        src_file = os.path.join(base, name)
+                        if os.path.isfile(src_file):
+                            try:
+                                shutil.copy2(src_file, os.path.join(path, name))
+                            except OSError:
+                                pass
+                os.environ["MIOPEN_USER_DB_PATH"] = path
         backend = "nccl" if device_type == "cuda" else "gloo"
         # smoke-test hook for boxes with ONE GPU: PWW_DIST_ONE_DEVICE=1 puts every rank on cuda:0 and rendezvous over gloo
         # (RCCL refuses two ranks on one device). Same code path above the backend; not a production mode.
@@ -47,6 +60,11 @@ def init_from_env(device_type="cuda"):
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def backend_name():
+    """"nccl" (= RCCL on ROCm) / "gloo" of the default process group, or "none" without one."""
+    return dist.get_backend() if (dist.is_available() and dist.is_initialized()) else "none"
 
 
 def shard_range(n_items, rank, world):
@@ -77,7 +95,7 @@ def broadcast_module(module, src=0, group=None, bucket_bytes=None):
     by_dtype = {}
     for t in tensors:
         by_dtype.setdefault(t.dtype, []).append(t)
-    rank = dist.get_rank(group)
+    rank = dist.get_rank()       # GLOBAL rank: `src` of dist.broadcast is a global rank too (with a sub-group the group-local rank differs)
     total = 0
     for dtype, ts in sorted(by_dtype.items(), key=lambda kv: str(kv[0])):
         cap = max(1, bucket_bytes // ts[0].element_size())
@@ -122,7 +140,7 @@ def build_and_broadcast(build_fn, skeleton_fn, device, dtype, src=0, group=None,
     the meta device, then `to_empty`) and receives the values through ONE flat broadcast per dtype.
     Returns (module, bytes_broadcast); `timing` (a dict, optional) receives build_s / broadcast_s."""
     import time
-    rank = dist.get_rank(group) if (dist.is_available() and dist.is_initialized()) else 0
+    rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0      # global, like `src`
     t0 = time.time()
     if rank == src:
         module = build_fn().to(device=device, dtype=dtype)
@@ -149,7 +167,7 @@ def broadcast_request(payload, device, src=0, group=None):
     pickled in one byte tensor. payload on src: dict; None elsewhere. Returns the dict on every rank."""
     if not (dist.is_available() and dist.is_initialized()):
         return payload
-    rank = dist.get_rank(group)
+    rank = dist.get_rank()       # global, like `src`
     if rank == src:
         arrays = {k: np.ascontiguousarray(v) for k, v in payload.items() if isinstance(v, np.ndarray)}
         meta = {k: v for k, v in payload.items() if k not in arrays}
@@ -187,7 +205,7 @@ def gather_latents(latents, dst=0, group=None):
     pad[: latents.shape[0]] = latents
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad, group=group)
-    if dist.get_rank(group) != dst:
+    if dist.get_rank() != dst:      # (`dst`: a global rank)
         return None
     return [o[: int(c.item())] for o, c in zip(out, counts)]
 

@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import AttnDesc, CrossOpts, Region, PwwHipError
+from ._lib import AttnDesc, CrossOpts, QprojDesc, Region, PwwHipError
 
 _DT = {torch.float16: _lib.DTYPE_F16, torch.bfloat16: _lib.DTYPE_BF16}
 
@@ -67,7 +67,7 @@ def _prep(t):
     return t if _rows_ok(t) else t.contiguous()
 
 
-STAT_NONE, STAT_MAX, STAT_MIN, STAT_MEAN, STAT_STD, STAT_ABSMAX = 0, 1, 2, 3, 4, 5   # PWW_STAT_* of include/pww_hip.h
+STAT_NONE, STAT_MAX, STAT_MIN, STAT_MEAN, STAT_STD, STAT_ABSMAX, STAT_ALL = 0, 1, 2, 3, 4, 5, 6   # PWW_STAT_* of include/pww_hip.h
 
 
 FUSED_MAX_KEYS = 128   # pww_cross_attn_fwd_fused: one K/V stage
@@ -85,6 +85,7 @@ class FusedScratch:
         self.ws = None
         self._err_index = 0
         self._retired = []
+        self._err_sites = {}       # id(state buffer) -> (buffer, {error-word indices of every geometry launched into it})
 
     def _alloc(self, current, nbytes, device, zero):
         if current is not None and current.device == device and current.numel() * 8 >= nbytes:
@@ -100,6 +101,7 @@ class FusedScratch:
         self.state = self._alloc(self.state, int(lib.pww_cross_fused_state_bytes(ctypes.byref(d))), device, True)
         self.ws = self._alloc(self.ws, int(lib.pww_cross_fused_workspace_bytes(ctypes.byref(d))), device, False)
         self._err_index = d.B * d.H + d.B
+        self._err_sites.setdefault(id(self.state), (self.state, set()))[1].add(self._err_index)
         return self.state, self.ws
 
     def error_word(self):
@@ -107,9 +109,16 @@ class FusedScratch:
         timed out and the affected outputs are NaN), or None before the first call. No synchronisation."""
         return None if self.state is None else self.state.view(torch.int32)[self._err_index]
 
+    def error_words(self):
+        """The error words of EVERY geometry this call site was ever launched with, retired buffers included (graphs captured for
+        a smaller geometry keep replaying into them; a layer that alternates between batch geometries has its word at another
+        index each time): a list of 0-dim device tensors. No synchronisation."""
+        return [buf.view(torch.int32)[i] for buf, idxs in self._err_sites.values() for i in sorted(idxs)]
+
     def error(self):
         """True if a hand-off timed out (synchronises). The state words must then be re-zeroed: `reset()`."""
-        return self.state is not None and bool(self.error_word().item() != 0)
+        words = self.error_words()
+        return bool(words) and bool(torch.stack(words).ne(0).any().item())
 
     def reset(self):
         for t in [self.state] + self._retired:
@@ -130,15 +139,16 @@ class FusedErrorWatch:
 
     def post(self, modules):
         scratches = [m.__dict__["_pww_fused_scratch"] for m in modules if "_pww_fused_scratch" in getattr(m, "__dict__", {})]
-        words = [w for w in (s.error_word() for s in scratches) if w is not None]
+        words = [w for s in scratches for w in s.error_words()]
         if not words:
-            return
+            return False
         flag = torch.stack(words).ne(0).any().to(torch.int32)
         host = torch.empty((), dtype=torch.int32).pin_memory()
         host.copy_(flag, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         self.pending.append((ev, host, scratches))
+        return True
 
     def poll(self, wait=False):
         while self.pending:
@@ -167,7 +177,7 @@ def check_fused_errors(modules):
     stream holding compute units can starve it; PWW_FUSED_CROSS=0 selects the two-launch path). Dirty state is re-zeroed so
     that the next request starts clean."""
     scratches = [m.__dict__["_pww_fused_scratch"] for m in modules if "_pww_fused_scratch" in getattr(m, "__dict__", {})]
-    words = [w for w in (s.error_word() for s in scratches) if w is not None]
+    words = [w for s in scratches for w in s.error_words()]
     if not words:
         return
     if bool(torch.stack(words).ne(0).any().item()):
@@ -211,7 +221,7 @@ COMPACT_MAX_R = 32     # pww_cross.hip: the compact form holds at most 32 non-ze
 
 
 def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None, scratch=None, stats_out=None, coeff_dev=None,
-              bias_cols=0, compact=None, gated=0):
+              bias_cols=0, compact=None, gated=0, parts=None):
     """softmax((Q K^T + c * bias) * scale) V on [B, tokens, heads*D] tensors (diffusers layout, no
     head-split copies). bias: fp32 tensor broadcastable to [B, heads, N, M] or None;
     bias_coeff: optional fp32 [B] device tensor of per-image coefficients (with `stat`: the row gate);
@@ -221,7 +231,9 @@ def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None, scra
     With `stat`: coeff_dev = one-element fp32 device tensor that replaces the python scalar when the kernel runs (hipGraph
     replays across denoise steps); bias_cols = columns >= bias_cols of the map are zero; compact = (values [B?, N, R] fp32,
     col_idx [B?, R] int32) the compact form of the same map (fused launch only); gated = the caller's hint that bias_coeff is
-    non-zero exactly for the first `gated` images (a CFG-folded batch), 0 = unknown (fused launch only: work distribution)."""
+    non-zero exactly for the first `gated` images (a CFG-folded batch), 0 = unknown (fused launch only: work distribution).
+    parts: float64 [B, nparts, 4] partials of the statistic formed by qproj_stat with q (stat = (None, kind, scalar)): the launch
+    folds them at entry (pww_cross_attn_fwd_parts) -- no scratch, no hand-off."""
     _require_gpu(q, k, v, bias, bias_coeff)
     if not (q.dtype == k.dtype == v.dtype):
         raise PwwHipError("q/k/v dtypes differ: %s %s %s" % (q.dtype, k.dtype, v.dtype))
@@ -248,7 +260,21 @@ def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None, scra
                     bias_coeff = bias_coeff.expand(B).contiguous()
                 if bias_coeff.numel() != B:
                     raise PwwHipError("bias_coeff must have B=%d elements" % B)
-            if stat is not None and stat[0] is None and (scratch is not None or stat[1] != STAT_NONE):
+            if stat is not None and stat[0] is None and parts is not None:
+                _, kind, scalar = stat
+                if parts.dtype != torch.float64 or parts.dim() != 3 or parts.shape[0] != B or parts.shape[2] != 4 or not parts.is_contiguous() or M > FUSED_MAX_KEYS:
+                    raise PwwHipError("parts must be a contiguous float64 [B, nparts, 4] tensor (and M <= %d)" % FUSED_MAX_KEYS)
+                if stats_out is not None and (stats_out.dtype != torch.float64 or tuple(stats_out.shape) != (B, 4) or not stats_out.is_contiguous()):
+                    raise PwwHipError("stats_out must be a contiguous float64 [B, 4] tensor")
+                keep = []
+                if compact is not None and compact[0].shape[-1] > COMPACT_MAX_R:
+                    compact = None
+                op = _cross_opts(B, N, coeff_dev, bias_cols, compact, keep, gated)
+                rc = lib.pww_cross_attn_fwd_parts(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(bias), int(kind), float(scalar), _ptr(bias_coeff),
+                                                  ctypes.byref(d), _ptr(parts), int(parts.shape[1]), _ptr(stats_out),
+                                                  ctypes.byref(op) if op is not None else None, _stream())
+                _lib.check(rc, "pww_cross_attn_fwd_parts")
+            elif stat is not None and stat[0] is None and (scratch is not None or stat[1] != STAT_NONE):
                 _, kind, scalar = stat
                 if scratch is None or M > FUSED_MAX_KEYS:
                     raise PwwHipError("fused statistic needs a FusedScratch and at most %d keys" % FUSED_MAX_KEYS)
@@ -277,6 +303,65 @@ def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None, scra
                                             ctypes.byref(d), _stream())
                 _lib.check(rc, "pww_cross_attn_fwd")
     return out
+
+
+def _qproj_desc(x, weight, k, heads):
+    if x.dim() != 3 or k.dim() != 3 or weight.dim() != 2:
+        raise PwwHipError("qproj: x [B, N, Cin], weight [C, Cin], k [B or 1, M, C]")
+    B, N, Cin = x.shape
+    C = weight.shape[0]
+    if weight.shape[1] != Cin or k.shape[2] != C or k.shape[0] not in (1, B) or C % heads:
+        raise PwwHipError("qproj: shapes do not fit (x %s, weight %s, k %s, heads %d)" % (tuple(x.shape), tuple(weight.shape), tuple(k.shape), heads))
+    d = QprojDesc()
+    d.dtype = _DT[x.dtype]
+    d.B, d.N, d.Cin, d.H, d.D, d.M = B, N, Cin, heads, C // heads, k.shape[1]
+    d.x_stride[:] = [x.stride(0), x.stride(1)]
+    d.k_stride[:] = [k.stride(0) if k.shape[0] == B and B > 1 else 0, k.stride(1)]
+    return d
+
+
+def qproj_parts(x, weight, k, heads):
+    """Partials per image pww_qproj_stat forms for this problem, 0 if the shape is not supported (the caller then keeps its own
+    projection and the in-launch statistic)."""
+    if x.dtype not in _DT or not (x.dtype == weight.dtype == k.dtype) or k.shape[1] > FUSED_MAX_KEYS:
+        return 0
+    d = _qproj_desc(x, weight, k, heads)
+    d.q_stride[:] = [x.shape[1] * weight.shape[0], weight.shape[0]]
+    return int(_lib.load().pww_qproj_parts(ctypes.byref(d)))
+
+
+def qproj_stat(x, weight, k, heads, kind, gate=None):
+    """q = x @ weight.T (a bias-free to_q, paint_with_words.py:76) together with the partials of the per-image score statistic
+    of q k^T (:87; kind = STAT_*: only the fields that statistic needs are formed) -- one launch, the statistic comes out of the GEMM's
+    epilogue. Returns (q [B, N, C], parts float64 [B, nparts, 4]). gate: optional fp32 [B]; images with gate 0 get no partials."""
+    _require_gpu(x, weight, k, gate)
+    if not (x.dtype == weight.dtype == k.dtype):
+        raise PwwHipError("qproj: dtypes differ: %s %s %s" % (x.dtype, weight.dtype, k.dtype))
+    x, k = _prep(x), _prep(k)
+    weight = weight if weight.is_contiguous() else weight.contiguous()
+    B, N, Cin = x.shape
+    C = weight.shape[0]
+    q = torch.empty((B, N, C), dtype=x.dtype, device=x.device)
+    d = _qproj_desc(x, weight, k, heads)
+    d.q_stride[:] = [q.stride(0), q.stride(1)]
+    lib = _lib.load()
+    nparts = int(lib.pww_qproj_parts(ctypes.byref(d)))
+    if nparts <= 0:
+        raise PwwHipError("qproj_stat: unsupported shape (C = %d, head dim %d, Cin = %d): ask qproj_parts() first" % (C, C // heads, Cin))
+    parts = torch.empty((B, nparts, 4), dtype=torch.float64, device=x.device)
+    if gate is not None:
+        gate = gate.to(torch.float32).reshape(-1).contiguous()
+        if gate.numel() != B:
+            raise PwwHipError("gate must have B=%d elements" % B)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.pww_qproj_stat(_ptr(x), _ptr(weight), _ptr(q), _ptr(k), _ptr(gate), ctypes.byref(d), int(kind), _ptr(parts),
+                                      parts.numel() * 8, _stream()), "pww_qproj_stat")
+    return q, parts
+
+
+def fold_parts(parts):
+    """[B, nparts, 4] partials -> [B, 4] statistics (max, min, sum, sum of squares), as the attention kernel folds them."""
+    return torch.stack([parts[:, :, 0].amax(1), parts[:, :, 1].amin(1), parts[:, :, 2].sum(1), parts[:, :, 3].sum(1)], dim=1)
 
 
 def qk_stats(q, k, heads):
@@ -358,10 +443,16 @@ def mask_build_f32(masks, cols, ratios=(8, 16, 32, 64)):
     lib = _lib.load()
     with torch.cuda.device(dev):
         for r in ratios:
-            out = torch.empty((round_half_up_div(H, r) * round_half_up_div(W, r), T), dtype=torch.float32, device=dev)
-            rc = lib.pww_mask_build_f32(_ptr(masks), H, W, R, _ptr(col_ptr), _ptr(col_reg), T, r, _ptr(out), _stream())
+            outs[r] = torch.empty((round_half_up_div(H, r) * round_half_up_div(W, r), T), dtype=torch.float32, device=dev)
+        rest = list(ratios)
+        if all(r in outs for r in (8, 16, 32, 64)):       # the four maps of a request: ONE launch
+            rc = lib.pww_mask_build_f32_levels(_ptr(masks), H, W, R, _ptr(col_ptr), _ptr(col_reg), T, _ptr(outs[8]), _ptr(outs[16]),
+                                               _ptr(outs[32]), _ptr(outs[64]), _stream())
+            _lib.check(rc, "pww_mask_build_f32_levels")
+            rest = [r for r in ratios if r not in (8, 16, 32, 64)]
+        for r in rest:
+            rc = lib.pww_mask_build_f32(_ptr(masks), H, W, R, _ptr(col_ptr), _ptr(col_reg), T, r, _ptr(outs[r]), _stream())
             _lib.check(rc, "pww_mask_build_f32")
-            outs[r] = out
     return outs
 
 

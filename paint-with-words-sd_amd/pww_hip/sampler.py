@@ -19,6 +19,13 @@ import torch
 
 from . import ops
 from .attention import install, refresh_kv_cache, refresh_orig_cache, ROW_GATE, KV_CACHE, COEFF_SLOTS, CoeffSlots, COMPACT_W, COMPACT_IDX, GATED_ROWS
+from .conditioning import PwWContext
+
+ORIG = "CROSS_ATTENTION_WEIGHT_ORIG"
+
+
+def _orig_pending(d):
+    return isinstance(d, PwWContext) and d.pending(ORIG)
 
 
 def initial_latents(seed, in_channels, height, width, region_masks=None, extra_seeds=None, batch_seeds=None):
@@ -64,14 +71,21 @@ def _fold_context(cond, uncond, n_images, device):
             return t.expand(n_images, -1, -1) if t.shape[0] == 1 else t
         return torch.cat([d["CONTEXT_TENSOR"] for d in dicts], dim=0)
 
-    folded = dict(conds[0])
+    folded = conds[0].copy() if isinstance(conds[0], PwWContext) else PwWContext(conds[0])      # (keeps a pending ORIG map pending)
     folded[KV_CACHE] = {}
     folded.pop("_PWW_ORIG_CACHE", None)
     folded["CONTEXT_TENSOR"] = torch.cat([rows(conds), rows(unconds)], dim=0).contiguous()
     folded[ROW_GATE] = torch.cat([torch.ones(n_images), torch.zeros(n_images)]).to(device=device, dtype=torch.float32)
     folded[GATED_ROWS] = n_images        # what the gate holds, for the host side (work distribution of the fused launch)
     if not shared:
-        for key in [k for k in conds[0] if k.startswith("CROSS_ATTENTION_WEIGHT_")]:
+        if any(_orig_pending(c) for c in conds):
+            # per-image fallback maps, stacked on first use: [2n, H, W, 77] (zeros for the unconditional rows)
+            def stacked_orig(conds=conds):
+                w = torch.stack([c[ORIG] for c in conds], dim=0)
+                return torch.cat([w, torch.zeros_like(w)], dim=0)
+            folded.pop(ORIG, None)
+            folded.set_lazy(ORIG, stacked_orig)
+        for key in [k for k in dict.keys(conds[0]) if k.startswith("CROSS_ATTENTION_WEIGHT_") and not (k == ORIG and ORIG in folded._thunks)]:
             maps = [c[key] for c in conds]
             if not all(torch.is_tensor(m) for m in maps):
                 raise ValueError("per-image contexts must all carry a tensor for %s" % key)
@@ -225,27 +239,36 @@ class PwWSampler:
         self._graph_sig = None
         self._fallback_sig = None
         self._static_folded = None
+        self._request_folded = None
         self._scratch_modules = None
         self._errors = ops.FusedErrorWatch()
+        self.handoff_pending = False     # the last request issued launches with an in-kernel hand-off (PWW_QPROJ_STAT=0 / shapes the
+                                         # to_q GEMM does not cover): its latents must not reach a caller before check_errors() has looked
 
     def _static_context(self, folded, weight_function, latents, timesteps):
         """Captured graphs read the context tensors by ADDRESS: keep one set of static tensors alive and copy each new
         request's values into them; rebuild the graphs when the geometry changes. The weight function and the schedule are
         NOT part of the key while the function's scalars travel in device words (CoeffSlots) -- fresh lambdas, other
         constants, another step count all replay the same graph; only the per-step fall-back keys them."""
-        def tensor_sig(d):
-            return tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in d.items() if torch.is_tensor(v)))
+        def tensor_sig(d):      # (the full-resolution fallback map is not part of the geometry: it exists only once a layer asked for it)
+            return tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in d.items() if torch.is_tensor(v) and k != ORIG))
         sig = (tuple(latents.shape), tensor_sig(folded), tuple(sorted((k, v) for k, v in folded.items() if isinstance(v, int) and not isinstance(v, bool))))
+        self._request_folded = folded
         if sig != self._graph_sig:
             self._graphed.reset()
             self._graph_sig = sig
             self._fallback_sig = None
-            self._static_folded = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in folded.items()}
+            self._static_folded = PwWContext({k: (v.clone() if torch.is_tensor(v) else v) for k, v in folded.items() if k != ORIG})
+            # CROSS_ATTENTION_WEIGHT_ORIG stays pending in the static context too: the first layer that takes the fallback (in the
+            # eager warm-up pass before the capture) clones the CURRENT request's map; later requests copy theirs into it
+            self._static_folded.set_lazy(ORIG, lambda: self._request_folded[ORIG].clone())
             self._static_folded[COEFF_SLOTS] = CoeffSlots(latents.device)
         else:
             for k, v in folded.items():
-                if torch.is_tensor(v):
+                if torch.is_tensor(v) and k != ORIG:
                     self._static_folded[k].copy_(v)
+            if dict.__contains__(self._static_folded, ORIG) and torch.is_tensor(self._static_folded[ORIG]):
+                self._static_folded[ORIG].copy_(folded[ORIG])      # (builds this request's map: the captured layers read it)
             refresh_kv_cache(self._static_folded)     # new prompt embedding -> new K|V, same addresses
             refresh_orig_cache(self._static_folded)   # new color map -> new fallback maps, same addresses
         slots = self._static_folded[COEFF_SLOTS]
@@ -324,11 +347,21 @@ class PwWSampler:
         # event (ops.FusedErrorWatch): looked at when the next request starts and by check_errors() -- never a host stall here
         if self._scratch_modules is None:
             self._scratch_modules = [m for m in unet.modules() if m.__class__.__name__ in ("CrossAttention", "Attention")]
-        self._errors.post(self._scratch_modules)
+        self.handoff_pending = self._errors.post(self._scratch_modules)
         return latents
 
     def check_errors(self):
         """Wait for the requests issued so far and raise PwwHipError if a fused cross-attention hand-off of any of them timed out
-        (their outputs are NaN). The PIL-returning entry points call this after decoding; callers that take latents
-        (`return_latents=True`) call it when they synchronise."""
+        (their outputs are NaN). The PIL-returning entry points call this after decoding; the latent-returning ones
+        (`return_latents=True`) call `checked()`."""
         self._errors.poll(wait=True)
+        self.handoff_pending = False
+
+    def checked(self, latents):
+        """`latents` of the request just issued, safe to hand to a caller: if that request contained launches with an in-kernel
+        hand-off (the only launches that can fail at run time) this waits for it and raises on a time-out -- a single call never
+        hands back NaN latents silently. The default path (statistic formed in the to_q GEMM, no hand-off) has nothing to wait
+        for and stays asynchronous."""
+        if self.handoff_pending:
+            self.check_errors()
+        return latents

@@ -550,6 +550,187 @@ static void check_cfg() {
     if (rc || mism) g_fail++;
 }
 
+
+// ---- pww_qproj_stat + pww_cross_attn_fwd_parts: Q = X W^T with the score statistic's partials out of the GEMM epilogue; the attention
+// launch folds them. Checked against (1) an fp64 GEMM on sampled rows, (2) pww_qk_reduce on the Q the kernel wrote, (3) the two-step path
+// pww_qk_reduce + pww_cross_attn_fwd_stat on the same Q; timed against pww_cross_attn_fwd_fused_ex (the round-3 launch).
+struct QCase { const char *name; int dtype, B, N, Cin, H, D, M; bool shared_k; bool on_request; };
+
+static void run_qproj(const QCase &c, bool timing) {
+    const int B = c.B, N = c.N, Cin = c.Cin, H = c.H, D = c.D, M = c.M, C = H * D, Bk = c.shared_k ? 1 : B;
+    std::vector<uint16_t> x((size_t)B * N * Cin), w((size_t)C * Cin), k((size_t)Bk * M * C), v((size_t)Bk * M * C);
+    std::vector<float> xf(x.size()), wf(w.size()), kf(k.size());
+    const float ws = 1.0f / sqrtf((float)Cin);
+    for (size_t i = 0; i < x.size(); ++i) { x[i] = to_t(rng_normal(), c.dtype); xf[i] = from_t(x[i], c.dtype); }
+    for (size_t i = 0; i < w.size(); ++i) { w[i] = to_t(rng_normal() * ws, c.dtype); wf[i] = from_t(w[i], c.dtype); }
+    for (size_t i = 0; i < k.size(); ++i) { k[i] = to_t(rng_normal(), c.dtype); kf[i] = from_t(k[i], c.dtype); }
+    for (size_t i = 0; i < v.size(); ++i) v[i] = to_t(rng_normal() + 0.1f * (float)(i % 7), c.dtype);
+    pww_qproj_desc_t qd; memset(&qd, 0, sizeof(qd));
+    qd.dtype = c.dtype; qd.B = B; qd.N = N; qd.Cin = Cin; qd.H = H; qd.D = D; qd.M = M;
+    qd.x_stride[0] = (int64_t)N * Cin; qd.x_stride[1] = Cin; qd.q_stride[0] = (int64_t)N * C; qd.q_stride[1] = C;
+    qd.k_stride[0] = c.shared_k ? 0 : (int64_t)M * C; qd.k_stride[1] = C;
+    const int nparts = pww_qproj_parts(&qd);
+    if (nparts <= 0) { printf("FAIL %-30s pww_qproj_parts = %d (%s)\n", c.name, nparts, pww_last_error()); g_fail++; return; }
+    uint16_t *dx = dalloc<uint16_t>(x.size()), *dw = dalloc<uint16_t>(w.size()), *dk = dalloc<uint16_t>(k.size()), *dv = dalloc<uint16_t>(v.size());
+    uint16_t *dq = dalloc<uint16_t>((size_t)B * N * C), *o1 = dalloc<uint16_t>((size_t)B * N * C), *o2 = dalloc<uint16_t>((size_t)B * N * C);
+    double *dparts = dalloc<double>((size_t)B * nparts * 4), *dstats = dalloc<double>(4 * B), *dfold = dalloc<double>(4 * B);
+    HIPCHECK(hipMemcpy(dx, x.data(), x.size() * 2, hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(dw, w.data(), w.size() * 2, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(dk, k.data(), k.size() * 2, hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(dv, v.data(), v.size() * 2, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemset(dq, 0xff, (size_t)B * N * C * 2)); HIPCHECK(hipMemset(dparts, 0xff, (size_t)B * nparts * 32));
+    std::vector<float> gate(B, 1.f); if (B > 1) gate[B - 1] = 0.f;        // last image gated out: Q still written, no partials
+    float *dgate = dalloc<float>(B); HIPCHECK(hipMemcpy(dgate, gate.data(), B * 4, hipMemcpyHostToDevice));
+    int rc = pww_qproj_stat(dx, dw, dq, dk, dgate, &qd, PWW_STAT_ALL, dparts, (size_t)B * nparts * 32, nullptr);
+    HIPCHECK(hipDeviceSynchronize());
+    if (rc) { printf("FAIL %-30s pww_qproj_stat rc=%d err=%s\n", c.name, rc, pww_last_error()); g_fail++; return; }
+    std::vector<uint16_t> q((size_t)B * N * C); std::vector<double> parts((size_t)B * nparts * 4);
+    HIPCHECK(hipMemcpy(q.data(), dq, q.size() * 2, hipMemcpyDeviceToHost)); HIPCHECK(hipMemcpy(parts.data(), dparts, parts.size() * 8, hipMemcpyDeviceToHost));
+    // (1) Q vs fp64 GEMM: sampled rows, every channel; one rounding of the result to T (2^-9 bf16 / 2^-12 f16 relative) + fp32 accumulation
+    double qerr = 0, qmax = 0; long bad = 0, nq = 0;
+    const double ulp = c.dtype == PWW_DTYPE_F16 ? 1.0 / 2048 : 1.0 / 256;
+    const int rstep = std::max(1, N / 61);
+    for (int b = 0; b < B; ++b) for (int n = 0; n < N; ++n) {
+        if (n % rstep && n != N - 1) continue;
+        const float *xr = &xf[((size_t)b * N + n) * Cin];
+        for (int ch = 0; ch < C; ++ch) {
+            const float *wr = &wf[(size_t)ch * Cin];
+            double s = 0; for (int i = 0; i < Cin; ++i) s += (double)xr[i] * wr[i];
+            const double g = from_t(q[((size_t)b * N + n) * C + ch], c.dtype);
+            const double e = fabs(g - s);
+            qerr = std::max(qerr, e); qmax = std::max(qmax, fabs(s)); ++nq;
+            if (!(e <= ulp * fabs(s) + 2e-5)) ++bad;
+        }
+    }
+    // (2) folded partials vs pww_qk_reduce on the Q the kernel wrote
+    pww_attn_desc_t d; memset(&d, 0, sizeof(d));
+    d.dtype = c.dtype; d.B = B; d.H = H; d.N = N; d.M = M; d.D = D;
+    d.q_stride[0] = (int64_t)N * C; d.q_stride[1] = D; d.q_stride[2] = C;
+    d.k_stride[0] = c.shared_k ? 0 : (int64_t)M * C; d.k_stride[1] = D; d.k_stride[2] = C;
+    d.v_stride[0] = d.k_stride[0]; d.v_stride[1] = D; d.v_stride[2] = C;
+    d.o_stride[0] = (int64_t)N * C; d.o_stride[1] = D; d.o_stride[2] = C;
+    d.scale = 1.0f / sqrtf((float)D);
+    d.bias_stride[0] = 0; d.bias_stride[1] = 0; d.bias_stride[2] = M; d.bias_stride[3] = 1;
+    const size_t ws_bytes = pww_workspace_bytes(&d); void *dws = dalloc<char>(ws_bytes + 8);
+    rc = pww_qk_reduce(dq, dk, &d, dstats, dws, ws_bytes, nullptr);
+    HIPCHECK(hipDeviceSynchronize());
+    std::vector<double> stats(4 * B);
+    HIPCHECK(hipMemcpy(stats.data(), dstats, stats.size() * 8, hipMemcpyDeviceToHost));
+    double serr = 0; bool untouched = true;
+    const double cnt = (double)H * N * M;
+    for (int b = 0; b < B; ++b) {
+        const double *pp = &parts[(size_t)b * nparts * 4];
+        if (gate[b] == 0.f) { for (int i = 0; i < nparts * 4; ++i) { uint64_t u; memcpy(&u, &pp[i], 8); untouched = untouched && u == ~0ull; } continue; }
+        double f[4] = {-1e300, 1e300, 0, 0};
+        for (int i = 0; i < nparts; ++i) { f[0] = std::max(f[0], pp[i * 4]); f[1] = std::min(f[1], pp[i * 4 + 1]); f[2] += pp[i * 4 + 2]; f[3] += pp[i * 4 + 3]; }
+        const double *g = &stats[4 * b];
+        const double mag = std::max(fabs(g[0]), fabs(g[1])) + 1e-9;
+        serr = std::max(serr, std::max(fabs(f[0] - g[0]), fabs(f[1] - g[1])) / mag);
+        const double sd = sqrt(std::max((g[3] - g[2] * g[2] / cnt) / (cnt - 1), 0.0)) + 1e-9;
+        serr = std::max(serr, fabs(f[2] - g[2]) / cnt / sd);                        // the means, in units of the std
+        serr = std::max(serr, fabs(f[3] - g[3]) / fabs(g[3]));
+    }
+    const bool ok_q = rc == 0 && bad == 0, ok_s = serr <= 1e-6 && untouched;
+    printf("%s %-30s dtype=%s B=%d N=%d Cin=%d H=%d D=%d M=%d parts/image=%d | Q max_err=%.3e (max|Q|=%.2f, %ld of %ld beyond 1 rounding) | folded partials vs pww_qk_reduce rel_err=%.2e %s%s\n",
+           ok_q && ok_s ? "PASS" : "FAIL", c.name, c.dtype == PWW_DTYPE_F16 ? "f16" : "bf16", B, N, Cin, H, D, M, nparts, qerr, qmax, bad, nq, serr, ok_s ? "ok" : "BAD",
+           untouched ? "" : " (partials of a gated-out image were written)");
+    if (!(ok_q && ok_s)) g_fail++;
+    // (3) attention from the partials vs pww_cross_attn_fwd_stat from pww_qk_reduce's statistics, same Q
+    std::vector<float> bias((size_t)N * M);
+    for (auto &bv : bias) bv = (rng_uniform() < 0.3f) ? rng_uniform() * 1.5f : 0.f;
+    for (int n = 0; n < N; ++n) for (int m = 32; m < M; ++m) bias[(size_t)n * M + m] = 0.f;
+    float *dbias = dalloc<float>(bias.size()); HIPCHECK(hipMemcpy(dbias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+    pww_cross_opts_t op; memset(&op, 0, sizeof(op)); op.size = sizeof(op); op.bias_cols = 32; op.gated_images = B > 1 ? B - 1 : 0;
+    for (int kind : {PWW_STAT_MAX, PWW_STAT_STD, PWW_STAT_ABSMAX, PWW_STAT_MEAN, PWW_STAT_MIN}) {
+        HIPCHECK(hipMemset(o1, 0xff, (size_t)B * N * C * 2)); HIPCHECK(hipMemset(o2, 0xee, (size_t)B * N * C * 2)); HIPCHECK(hipMemset(dfold, 0, 4 * B * 8));
+        int r1 = pww_cross_attn_fwd_stat(dq, dk, dv, o1, dbias, dstats, kind, cnt, 0.37f, dgate, &d, nullptr);
+        int r2 = pww_cross_attn_fwd_parts(dq, dk, dv, o2, dbias, kind, 0.37f, dgate, &d, dparts, nparts, dfold, &op, nullptr);
+        HIPCHECK(hipDeviceSynchronize());
+        std::vector<uint16_t> h1((size_t)B * N * C), h2(h1.size());
+        HIPCHECK(hipMemcpy(h1.data(), o1, h1.size() * 2, hipMemcpyDeviceToHost)); HIPCHECK(hipMemcpy(h2.data(), o2, h2.size() * 2, hipMemcpyDeviceToHost));
+        double dmax = 0, omax = 0; long ndiff = 0, nan = 0;
+        for (size_t i = 0; i < h1.size(); ++i) {
+            const double a = from_t(h1[i], c.dtype), bq = from_t(h2[i], c.dtype);
+            if (!(bq == bq)) ++nan;
+            dmax = std::max(dmax, fabs(a - bq)); omax = std::max(omax, fabs(a)); ndiff += h1[i] != h2[i];
+        }
+        const bool ok = r1 == 0 && r2 == 0 && nan == 0 && dmax <= 4 * ulp * omax;
+        printf("%s %-30s parts-attention kind=%d: max diff %.3e vs two-step path (max|O| %.2f, %ld of %zu elements differ, nan=%ld, rc %d %d%s%s)\n", ok ? "PASS" : "FAIL",
+               c.name, kind, dmax, omax, ndiff, h1.size(), nan, r1, r2, r2 ? " " : "", r2 ? pww_last_error() : "");
+        if (!ok) g_fail++;
+    }
+    if (timing) {
+        hipEvent_t e0, e1; HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+        const int iters = 50;
+        std::vector<float> g2(B, 1.f); if (B > 1) for (int b = B / 2; b < B; ++b) g2[b] = 0.f;       // a CFG-folded batch
+        HIPCHECK(hipMemcpy(dgate, g2.data(), B * 4, hipMemcpyHostToDevice));
+        op.gated_images = B > 1 ? B / 2 : 0;
+        const size_t fws_bytes = pww_cross_fused_workspace_bytes(&d), sync_bytes = pww_cross_fused_state_bytes(&d);
+        void *fws = dalloc<char>(fws_bytes + 8); unsigned *dsync = dalloc<unsigned>(sync_bytes / 4 + 1);
+        HIPCHECK(hipMemset(dsync, 0, sync_bytes));
+        float ms[4] = {0, 0, 0, 0};
+        for (int pass = 0; pass < 4; ++pass) {
+            for (int i = 0; i < 5 + iters; ++i) {
+                if (i == 5) HIPCHECK(hipEventRecord(e0, nullptr));
+                if (pass == 0) pww_qproj_stat(dx, dw, dq, dk, dgate, &qd, PWW_STAT_MAX, dparts, (size_t)B * nparts * 32, nullptr);
+                else if (pass == 1) pww_cross_attn_fwd_parts(dq, dk, dv, o2, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, dparts, nparts, nullptr, &op, nullptr);
+                else if (pass == 2) pww_cross_attn_fwd_fused_ex(dq, dk, dv, o1, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, nullptr, dsync, sync_bytes, fws, fws_bytes, &op, nullptr);
+                else { pww_qproj_stat(dx, dw, dq, dk, dgate, &qd, PWW_STAT_MAX, dparts, (size_t)B * nparts * 32, nullptr);
+                       pww_cross_attn_fwd_parts(dq, dk, dv, o2, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, dparts, nparts, nullptr, &op, nullptr); }
+            }
+            HIPCHECK(hipEventRecord(e1, nullptr)); HIPCHECK(hipEventSynchronize(e1));
+            HIPCHECK(hipEventElapsedTime(&ms[pass], e0, e1));
+        }
+        float kq = -1.f, ka = -1.f;
+        int slot = pww_profile_arm();
+        pww_qproj_stat(dx, dw, dq, dk, dgate, &qd, PWW_STAT_MAX, dparts, (size_t)B * nparts * 32, nullptr);
+        if (slot >= 0) pww_profile_elapsed_us(slot, &kq);
+        slot = pww_profile_arm();
+        pww_cross_attn_fwd_parts(dq, dk, dv, o2, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, dparts, nparts, nullptr, &op, nullptr);
+        if (slot >= 0) pww_profile_elapsed_us(slot, &ka);
+        pww_profile_reset();
+        const double gemm_flops = 2.0 * B * N * (double)C * Cin, bytes = 2.0 * ((double)B * N * Cin + (double)B * N * C + (double)C * Cin);
+        printf("TIME %-30s qproj_stat %.2f us (kernel-only %.2f; %.1f TFLOP/s, %.0f GB/s algorithmic) | parts-attention %.2f us (kernel-only %.2f) | both back to back %.2f us | "
+               "round-3 fused launch alone (needs its own to_q GEMM before it) %.2f us\n", c.name, ms[0] * 1e3 / iters, kq, gemm_flops / (ms[0] * 1e3 / iters) * 1e-6,
+               bytes / (ms[0] * 1e3 / iters) * 1e-3, ms[1] * 1e3 / iters, ka, ms[3] * 1e3 / iters, ms[2] * 1e3 / iters);
+        (void)hipFree(fws); (void)hipFree(dsync);
+    }
+    for (void *ptr : {(void *)dx, (void *)dw, (void *)dk, (void *)dv, (void *)dq, (void *)o1, (void *)o2, (void *)dparts, (void *)dstats, (void *)dfold, (void *)dgate, (void *)dws, (void *)dbias})
+        (void)hipFree(ptr);
+}
+
+static void check_qproj(const char *only, const char *match, bool quick) {
+    const QCase cases[] = {
+        // the 16 cross-attention layers of SD1.5 at 512 x 512: 2 folded rows (config 2) and 16 (configs 3 / 4)
+        {"qproj_sd15_n4096_b2", PWW_DTYPE_BF16, 2, 4096, 320, 8, 40, 77, false, false},
+        {"qproj_sd15_n1024_b2", PWW_DTYPE_BF16, 2, 1024, 640, 8, 80, 77, false, false},
+        {"qproj_sd15_n256_b2", PWW_DTYPE_BF16, 2, 256, 1280, 8, 160, 77, false, false},
+        {"qproj_sd15_n64_b2", PWW_DTYPE_BF16, 2, 64, 1280, 8, 160, 77, false, false},
+        {"qproj_sd15_n4096_b16_f16", PWW_DTYPE_F16, 16, 4096, 320, 8, 40, 77, false, false},
+        {"qproj_sd15_n4096_b16", PWW_DTYPE_BF16, 16, 4096, 320, 8, 40, 77, false, false},
+        {"qproj_sd15_n1024_b16", PWW_DTYPE_BF16, 16, 1024, 640, 8, 80, 77, false, false},
+        {"qproj_sd15_n256_b16", PWW_DTYPE_F16, 16, 256, 1280, 8, 160, 77, false, false},
+        {"qproj_sd15_n64_b16", PWW_DTYPE_BF16, 16, 64, 1280, 8, 160, 77, false, false},
+        // SD2.1 at 768 x 768 (head dim 64: TN = 320 = 5 heads), 8 folded rows
+        {"qproj_sd21_n9216_b8", PWW_DTYPE_BF16, 8, 9216, 320, 5, 64, 77, false, false},
+        {"qproj_sd21_n2304_b8", PWW_DTYPE_BF16, 8, 2304, 640, 10, 64, 77, false, false},
+        {"qproj_sd21_n576_b8", PWW_DTYPE_BF16, 8, 576, 1280, 20, 64, 77, false, false},
+        {"qproj_sd21_n144_b8", PWW_DTYPE_F16, 8, 144, 1280, 20, 64, 77, false, false},
+        // ragged and odd shapes: rows past N, one shared prompt, other key counts, every tile shape
+        {"qproj_n3990_b3_shared_k", PWW_DTYPE_F16, 3, 3990, 320, 8, 40, 77, true, false},
+        {"qproj_n100_m40_d80", PWW_DTYPE_BF16, 2, 100, 640, 8, 80, 40, false, false},
+        {"qproj_n333_m128_d160", PWW_DTYPE_BF16, 1, 333, 1280, 8, 160, 128, false, false},
+        {"qproj_n50_m1_d32", PWW_DTYPE_F16, 5, 50, 160, 5, 32, 1, true, false},
+        {"qproj_n700_m33_d16_c160", PWW_DTYPE_BF16, 7, 700, 80, 10, 16, 33, false, false},
+        {"qproj_n2000_b40_d40", PWW_DTYPE_BF16, 40, 2000, 320, 8, 40, 77, false, false},
+    };
+    for (const QCase &c : cases) {
+        const bool big = (long)c.B * c.N >= 32768;
+        if (quick && big) continue;
+        if (only && strcmp(only, c.name)) continue;
+        if (match && !strstr(c.name, match)) continue;
+        run_qproj(c, true);
+    }
+}
+
 static void check_errors() {
     pww_attn_desc_t d; memset(&d, 0, sizeof(d));
     d.dtype = PWW_DTYPE_F16; d.B = 1; d.H = 1; d.N = 32; d.M = 32; d.D = 36; d.scale = 1.f;
@@ -672,6 +853,7 @@ int main(int argc, char **argv) {
         if (match && !strstr(c.name, match)) continue;
         run_case(c, big || c.bias_mode == 1);
     }
+    check_qproj(only, match, quick);
     if (!only && !match) {
         check_mask();
         check_cfg();

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol(built_lib):
     raw = ctypes.CDLL(built_lib)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.pww_version() == 121
+    assert lib.pww_version() == 122
     assert lib.pww_last_error() == b"" or isinstance(lib.pww_last_error(), bytes)
     assert lib.pww_workspace_bytes(None) == 0
 
@@ -526,3 +526,48 @@ def test_kernel_invariants_static():
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([_sys.executable, os.path.join(repo, "tools", "check_kernel_invariants.py")], capture_output=True, text=True, timeout=1800)
     assert out.returncode == 0, out.stdout[-3000:]
+
+
+# ---- round 4 ------------------------------------------------------------------------------------------------------------------
+
+def test_pww_context_builds_the_orig_map_on_first_access():
+    """conditioning.PwWContext: the reference's dict protocol (:370-386) with CROSS_ATTENTION_WEIGHT_ORIG built when somebody
+    indexes it (only inj_forward's KeyError path does, :95-101)."""
+    from pww_hip.conditioning import PwWContext
+    built = []
+    ctx = PwWContext({"CONTEXT_TENSOR": 1, "CROSS_ATTENTION_WEIGHT_4096": 2}).set_lazy("CROSS_ATTENTION_WEIGHT_ORIG", lambda: built.append(1) or "MAP")
+    assert "CROSS_ATTENTION_WEIGHT_ORIG" in ctx and ctx.pending("CROSS_ATTENTION_WEIGHT_ORIG") and not built
+    assert "CROSS_ATTENTION_WEIGHT_ORIG" not in dict(ctx) and len(ctx) == 2
+    with pytest.raises(KeyError):
+        ctx["CROSS_ATTENTION_WEIGHT_1024"]                     # the reference's try / except KeyError still works (:92-95)
+    twin = ctx.copy()
+    assert isinstance(twin, PwWContext) and twin.pending("CROSS_ATTENTION_WEIGHT_ORIG")
+    assert ctx["CROSS_ATTENTION_WEIGHT_ORIG"] == "MAP" and built == [1] and not ctx.pending("CROSS_ATTENTION_WEIGHT_ORIG")
+    assert ctx["CROSS_ATTENTION_WEIGHT_ORIG"] == "MAP" and built == [1]          # built once
+    assert dict(ctx)["CROSS_ATTENTION_WEIGHT_ORIG"] == "MAP"
+    assert twin.get("CROSS_ATTENTION_WEIGHT_ORIG") == "MAP" and built == [1, 1]   # the copy made before builds its own
+    assert twin.get("nope", 7) == 7
+    ctx.update({"SIGMA": 3.0})
+    assert ctx["SIGMA"] == 3.0
+
+
+def test_weight_function_results_are_classified_for_graph_replay():
+    """attention.CoeffSlots.classify: what a captured hipGraph holds per cross-attention call site -- a bias kernel with a
+    statistic selector, or NO bias kernel -- so that a change of class between requests / steps forces a re-capture."""
+    import math
+    import torch
+    from pww_hip.attention import CoeffSlots, ScaledW, _ProbeProxy
+    from pww_hip import ops
+    w = torch.zeros(16, 77)
+
+    def run(f, sigma=5.0):
+        return CoeffSlots.classify(f(ScaledW(w), sigma, _ProbeProxy((8, 16, 77), torch.float16, "cpu")))
+    assert run(lambda w, s, qk: 0.4 * w * math.log(1 + s) * qk.max()) == (ops.STAT_MAX, pytest.approx(0.4 * math.log(6.0)))
+    assert run(lambda w, s, qk: 0.4 * w * math.log(1 + s ** 2) * qk.std())[0] == ops.STAT_STD
+    assert run(lambda w, s, qk: 0.1 * w)[0] == ops.STAT_NONE
+    assert run(lambda w, s, qk: 0)[0] == CoeffSlots.NO_BIAS and run(lambda w, s, qk: 0.0)[0] == CoeffSlots.NO_BIAS
+    assert run(lambda w, s, qk: torch.tensor(0.0))[0] == CoeffSlots.NO_BIAS
+    assert run(lambda w, s, qk: 2.0 * qk.max())[0] == CoeffSlots.NO_BIAS         # a bare statistic: constant per row, cancels in softmax
+    thresholded = lambda w, s, qk: 0.4 * w * qk.max() if s > 3 else 0               # noqa: E731
+    assert run(thresholded, 5.0)[0] == ops.STAT_MAX and run(thresholded, 1.0)[0] == CoeffSlots.NO_BIAS
+    assert run(lambda w, s, qk: w + 1.0) is None                                    # a tensor-valued bias: not representable by a device word

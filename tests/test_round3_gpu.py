@@ -199,7 +199,7 @@ def test_config3_lms50_fp16_final_latent(gpu_device):
     for j in (0, 5):
         d, d0 = rel_l2(lat[j:j + 1], g[f"latents_{j}"]), rel_l2(base[j], g[f"latents_{j}"])
         print(f"config 3 fp16 LMS-50 graph batch 8, image {j}: rel-L2 vs reference {d:.3e}; unfused torch ops on this GPU {d0:.3e}")
-        assert d <= 5e-2 and d <= 1.5 * d0 + 2e-3
+        assert d <= 1e-2 and d <= 1.5 * d0 + 2e-3          # fp16 final latent <= 1e-2 (measured 1.1e-3)
 
 
 # ---- 1c: magnitude guard of the folded-reference kernel ------------------------------------------------------------------
@@ -266,11 +266,14 @@ print("state clean:", not m.__dict__["_pww_fused_scratch"].error())
     assert "nan outputs: True" in out.stdout and "raised: a fused cross-attention launch timed out" in out.stdout and "state clean: True" in out.stdout
 
 
-def test_sampler_raises_on_a_set_error_word(gpu_device):
-    """PwWSampler posts the error words of every attention layer after the loop (one device -> host copy behind an event) and
-    raises when they are looked at: in the PIL-returning entry points right after the decode, for `return_latents=True` callers at
-    the start of the next request or in sampler.check_errors() -- never by stalling the host between requests."""
+def test_sampler_raises_on_a_set_error_word(gpu_device, monkeypatch):
+    """The round-3 launch (statistic + hand-off inside the attention kernel; since round 4 only behind PWW_QPROJ_STAT=0 or for shapes
+    the to_q GEMM does not cover) can fail at run time. PwWSampler posts the error words of every attention layer after the loop (one
+    device -> host copy behind an event) and raises when they are looked at: in the PIL-returning entry points right after the
+    decode, and -- round 4 -- BEFORE `return_latents=True` hands the latents back (a single call must not return NaN
+    latents silently). The default path has no hand-off, creates no state buffers and never waits."""
     import paint_with_words as pw
+    import pww_hip.attention as A
     from pww_hip._lib import PwwHipError
     tools = cases.build_tools("tiny", dtype=torch.float16, device=gpu_device)
     kw = dict(color_map_image=Image.fromarray(cases.load_example_rgb()), input_prompt=cases.RUNNER_PROMPT, num_inference_steps=2,
@@ -279,13 +282,15 @@ def test_sampler_raises_on_a_set_error_word(gpu_device):
         with _mode("folded"):
             pw.paint_with_words(color_context=dict(cases.RUNNER_CONTEXT), return_latents=True, **kw)
             sampler = tools[1]._pww_samplers[(id(tools[4]), "folded")]
-            sampler.check_errors()
+            assert not sampler.handoff_pending        # default path: nothing to wait for
+            assert not [m for m in tools[1].modules() if "_pww_fused_scratch" in m.__dict__]
+            monkeypatch.setattr(A, "QPROJ_STAT", False)
+            pw.paint_with_words(color_context=dict(cases.RUNNER_CONTEXT), return_latents=True, **kw)
             scr = [m.__dict__["_pww_fused_scratch"] for m in tools[1].modules() if "_pww_fused_scratch" in m.__dict__]
             assert len(scr) >= 3
             scr[1].state.view(torch.int32)[scr[1]._err_index] = 1
-            pw.paint_with_words(color_context=dict(cases.RUNNER_CONTEXT), return_latents=True, **kw)      # latents: nobody waited yet
-            with pytest.raises(PwwHipError):
-                sampler.check_errors()
+            with pytest.raises(PwwHipError):                                                                # latents: checked before they are returned
+                pw.paint_with_words(color_context=dict(cases.RUNNER_CONTEXT), return_latents=True, **kw)
             assert not any(s.error() for s in scr)
             scr[2].state.view(torch.int32)[scr[2]._err_index] = 1
             with pytest.raises(PwwHipError):                                                                # PIL result: checked after the decode
