@@ -19,7 +19,18 @@ def unfused_inj_forward(module, hidden_states, context=None, mask=None):
     scores = torch.matmul(q, k.transpose(-1, -2))
     bias = 0.0
     if is_dict:
-        w = context.get(f"CROSS_ATTENTION_WEIGHT_{scores.shape[-2]}", 0)
+        n = scores.shape[-2]
+        try:
+            w = context[f"CROSS_ATTENTION_WEIGHT_{n}"]
+        except KeyError:        # the reference's fallback (:95-101): resize CROSS_ATTENTION_WEIGHT_ORIG to n tokens, plain torch ops
+            w = context["CROSS_ATTENTION_WEIGHT_ORIG"]
+            if torch.is_tensor(w):
+                ratio = (w.shape[0] * w.shape[1] / n) ** 0.5
+                nc = w.shape[2]
+                small = torch.nn.functional.interpolate(w.permute(2, 0, 1)[None].float(), scale_factor=1 / ratio, mode="bilinear", align_corners=True)
+                w = torch.nn.functional.interpolate(small.reshape(1, nc, -1), size=n, mode="nearest")[0].t()       # [n, nc]
+            else:
+                w = 0
         bias = context["WEIGHT_FUNCTION"](w, context["SIGMA"], scores)
     probs = ((scores.float() + bias) * module.scale).softmax(dim=-1)
     out = O.merge_heads(torch.matmul(probs.to(v.dtype), v), module.heads)

@@ -137,7 +137,7 @@ def test_stale_graph_is_not_replayed_for_a_function_that_wants_the_bias(gpu_devi
     kw = dict(color_map_image=Image.fromarray(cases.load_example_rgb()), input_prompt=cases.RUNNER_PROMPT, num_inference_steps=5,
               guidance_scale=7.5, seed=2, device=str(gpu_device), preloaded_utils=tools, return_latents=True)
     zero = lambda w, sigma, qk: 0                                                                    # noqa: E731
-    thresholded = lambda w, sigma, qk: 0.4 * w * math.log(1 + sigma) * qk.max() if sigma > 3 else 0     # noqa: E731
+    thresholded = lambda w, sigma, qk: 0.4 * w * math.log(1 + sigma) * qk.max() if sigma > 3 else 0     # noqa: E731  (5 LMS steps: sigma = 14.6, 4.7, 1.9, 0.7, 0.03)
     try:
         with _mode("graph"):
             z = pw.paint_with_words(color_context=dict(cases.RUNNER_CONTEXT), weight_function=zero, **kw)
@@ -149,7 +149,9 @@ def test_stale_graph_is_not_replayed_for_a_function_that_wants_the_bias(gpu_devi
             assert sampler._graphed.captures == n0 + 1
             z2 = pw.paint_with_words(color_context=dict(cases.RUNNER_CONTEXT), weight_function=zero, **kw)      # and back
             assert sampler._graphed.captures == n0 + 2
+            n1 = sampler._graphed.captures
             t = pw.paint_with_words(color_context=dict(cases.RUNNER_CONTEXT), weight_function=thresholded, **kw)
+            assert sampler._graphed.captures >= n1 + 2       # zero -> biased at the first step, biased -> bias-free at the third
         with _mode("folded"):
             z_ref = pw.paint_with_words(color_context=dict(cases.RUNNER_CONTEXT), weight_function=zero, **kw)
             r_ref = pw.paint_with_words(color_context=dict(cases.RUNNER_CONTEXT), weight_function=cases.weight_fn_runner, **kw)
@@ -161,7 +163,8 @@ def test_stale_graph_is_not_replayed_for_a_function_that_wants_the_bias(gpu_devi
     assert gap > 5e-2
     for got, ref in ((z, z_ref), (r, r_ref), (z2, z_ref), (t, t_ref)):
         assert rel_l2(got, ref) <= 2e-2
-    assert rel_l2(t_ref, r_ref) > 1e-2 and rel_l2(t_ref, z_ref) > 1e-2       # the thresholded function is neither of the two
+    print(f"thresholded vs runner {rel_l2(t_ref, r_ref):.2e}, vs zero {rel_l2(t_ref, z_ref):.2e}")
+    assert rel_l2(t_ref, z_ref) > 5e-2                                       # its first two steps carry the bias
 
 
 def test_orig_map_is_lazy_and_survives_graph_requests(gpu_device):
@@ -192,8 +195,8 @@ def test_orig_map_is_lazy_and_survives_graph_requests(gpu_device):
             with _mode(mode):
                 for tag, rgb in (("a", ex), ("b", np.ascontiguousarray(ex[:, ::-1]))):
                     outs[mode, tag] = pipe(color_map_image=Image.fromarray(rgb), **kw).images
-        sampler = unet._pww_samplers[(id(sch), "graph")]
-        assert not sampler._static_folded.pending("CROSS_ATTENTION_WEIGHT_ORIG") and sampler._graphed.captures >= 1
+        sampler = unet._pww_samplers[(id(pipe.scheduler), "graph")]        # (the class replaces the scheduler it is given, :533-538)
+        assert not sampler._static_folded.pending("CROSS_ATTENTION_WEIGHT_ORIG") and sampler._graphed.captures == 1
     finally:
         uninstall_all()
     for tag in ("a", "b"):
