@@ -224,7 +224,7 @@ int pww_cross_attn_fwd_stat_ex(const void *q, const void *k, const void *v, void
  *   gate      fp32 [B] or NULL: images with gate[b] == 0 (unconditional rows of a CFG-folded batch) get Q but no partials
  *   stat_kind PWW_STAT_*: only the fields that statistic is made of are formed (PWW_STAT_ALL: all four, PWW_STAT_NONE: none)
  *   partials  double [B][pww_qproj_parts(desc)][4], 16-byte aligned; rows of gated-out images are left untouched
- * Supported: H*D a multiple of 320 (or 160) that holds whole heads, Cin a multiple of 80, D a multiple of 8; anything else
+ * Supported: H*D a multiple of 320 (or 160) that holds whole heads, Cin a multiple of 64, D a multiple of 8; anything else
  * returns PWW_ENOTSUP and pww_qproj_parts() returns 0 (the caller keeps its own projection and pww_cross_attn_fwd_fused).
  * Statistics are those of the ROUNDED Q (what the attention kernel reads), accumulated in fp32 per 48-score lane slice and in fp64
  * from there: within 1e-6 (relative to the largest score) of pww_qk_reduce on the same Q.

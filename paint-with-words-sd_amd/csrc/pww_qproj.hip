@@ -38,30 +38,43 @@ struct QprojParams {
     int fields;               // which of the four fields anybody will read: bit 0 max, 1 min, 2 sum, 3 sum of squares
 };
 
-constexpr int QP_RING = 5;            // k-steps (16 channels of the contraction) in flight per wave
 constexpr int QP_MAX_KEYS = 128;
+constexpr int QP_KC = 64;             // contraction elements per staged chunk: 128 bytes = one full cache line per operand row
+constexpr int QP_SROW = QP_KC * 2 + 16;     // LDS row of a staged chunk: +16 bytes => 16 rows read at one column hit 16 different 4-bank groups
 
-template <typename T, int NB, int TW, int KW>
+// Tile shape <NB, TW, CW, KW>: the workgroup's 4 waves are TW token waves x CW channel waves x KW contraction waves.
+//   tile = (32 TW) tokens x (32 NB) channels; a wave accumulates 32 tokens x (32 NB / CW) channels over 1 / KW of the contraction.
+// Operands are STAGED THROUGH LDS with coalesced loads: 8 consecutive threads move the 128 contiguous bytes a chunk holds of one
+// operand row (round 4's first version streamed both operands global -> registers in MFMA layout: every wave-load touched 32 cache
+// lines for 32 bytes each and the same lines were requested by 4 consecutive k-steps -- 24 us for the B = 2 layers against 8.5 us of
+// the stock GEMM, profiles/r04_qproj_v1_register_direct.md). Chunk c + 1 is requested into registers before chunk c is computed and
+// parked after it (one staging buffer, two barriers per chunk): the K tile, the staging buffer and the Q tile share 160 KB.
+template <typename T, int NB, int TW, int CW, int KW>
 __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p) {
     typedef typename Vec<T>::v8 V8;
-    static_assert(TW * KW == 4, "four waves per workgroup");
-    constexpr int TN = NB * 32, TM = TW * 32, P = QP_RING;
-    constexpr int ROWB = TN * 2 + 16;                 // LDS row of TN channels: +16 bytes makes 16 rows read at one column hit 16 different 4-bank groups
-    constexpr int CPR = TN / 8;                       // 16-byte chunks per row
-    constexpr int RED_BYTES = NB * 16 * 64 * 4;       // one wave's fp32 accumulators
-    constexpr int NRED = KW == 1 ? 0 : (KW == 2 ? TW : 2);
+    static_assert(TW * CW * KW == 4 && NB % CW == 0, "four waves per workgroup");
+    constexpr int TN = NB * 32, TM = TW * 32, NBW = NB / CW;
+    constexpr int ROWB = TN * 2 + 16;                 // LDS row of TN channels (K tile, Q tile): same bank argument as QP_SROW
+    constexpr int CPR = TN / 8;                       // 16-byte chunks per such row
+    constexpr int RED_BYTES = NBW * 16 * 64 * 4;      // one wave's fp32 accumulators
+    constexpr int NRED = KW == 1 ? 0 : (KW == 2 ? TW * CW : 2);
     constexpr int KCH = (QP_MAX_KEYS * CPR + 255) / 256;
+    constexpr int PLANE = (TN + TM) * QP_SROW;        // one contraction wave's staged chunk: TN rows of W, then TM rows of X
+    constexpr int WSL = TN / 32, XSL = TW;            // 32-row slabs per plane (one slab = one 16-byte piece per thread)
+    constexpr int WPT = KW * WSL, XPT = KW * XSL;     // pieces per thread and chunk
+    constexpr int STAGE_BYTES = KW * PLANE;
+    constexpr int WORK_A = STAGE_BYTES > NRED * RED_BYTES ? STAGE_BYTES : NRED * RED_BYTES;
+    constexpr int WORK_BYTES = WORK_A > TM * ROWB ? WORK_A : TM * ROWB;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // [K tile: M rows][work: reduction buffers / Q tile][red: 4 x 4 f64]
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [K tile: M rows][work: staged chunk / reduction buffers / Q tile][red: 4 x 4 f64]
     const int kt_bytes = (p.M * ROWB + 15) & ~15;
     char *Kt = smem;
     char *work = smem + kt_bytes;
-    constexpr int WORK_BYTES = NRED * RED_BYTES > TM * ROWB ? NRED * RED_BYTES : TM * ROWB;
     double *red = reinterpret_cast<double *>(work + WORK_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
-    const int tw = wave % TW, kw = wave / TW;
+    const int tw = wave % TW, cw = (wave / TW) % CW, kw = wave / (TW * CW);
 
     // workgroup -> (image, token tile, channel group): XCD x (= blockIdx & 7) always works on channel group x % ncg, so an XCD's L2
     // holds ONE slice of W_q (<= 820 KB) for the whole launch
@@ -84,14 +97,13 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
     T *Qb = reinterpret_cast<T *>(p.q) + b * p.q_sb + cg * TN;
     const float gate = p.gate ? p.gate[b] : 1.f;          // (requested early, looked at in the epilogue)
 
-    // X and W: every address the loop forms is valid memory (token rows past N are CLAMPED to the last row: their Q rows are never stored
-    // and their scores are masked), so these two descriptors span the whole 2 GiB window and nothing depends on how the range check
-    // treats the scalar offset that carries the k-step
-    const auto srd_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Xb), 0, 0x80000000u, 0x00020000);
-    const auto srd_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Wg), 0, 0x80000000u, 0x00020000);
+    // exact descriptors, every variable part of an address in the VECTOR offset: anything past the end (token rows >= N, the chunk
+    // after the last one) is out of range by the vector offset alone and returns zeros without touching memory
+    const auto srd_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Xb), 0, (unsigned)((((long)p.N - 1) * p.x_sn + p.Cin) * 2), 0x00020000);
+    const auto srd_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Wg), 0, (unsigned)((long)TN * p.Cin * 2), 0x00020000);
     const auto srd_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Kb), 0, (unsigned)((((long)p.M - 1) * p.k_sm + TN) * 2), 0x00020000);
 
-    // ---- K of the tile's heads: requested FIRST (its data returns first: vmcnt retires in order), parked in LDS while the operand ring fills
+    // ---- K of the tile's heads: requested FIRST (its data returns first: vmcnt retires in order), parked in LDS while chunk 0 arrives
     u32x4 kreg[KCH];
     const int nkchunk = p.M * CPR;
 #pragma unroll
@@ -100,60 +112,97 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
         kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_k, c < nkchunk ? (unsigned)((row * p.k_sm + ch * 8) * 2) : OOB_OFF, 0, 0);
     }
 
-    // ---- main loop: acc[nb] (32 channels x 32 tokens) += W[channels][16 k] X[tokens][16 k]^T over this wave's share of the contraction
-    const int S = p.Cin / (16 * KW);                       // k-steps of this wave (a multiple of P: the host checks)
-    const int nrow = row0 + tw * 32 + l31;
-    const unsigned kbase = (unsigned)(kw * S * 32);        // byte offset of the wave's first k-step within a row
-    const unsigned voff_x = (unsigned)((long)(nrow < p.N ? nrow : p.N - 1) * p.x_sn * 2) + (unsigned)(hi * 16) + kbase;
-    const unsigned voff_w = (unsigned)(swap23(l31) * p.Cin * 2 + hi * 16) + kbase;
-    const unsigned wblk = (unsigned)(32 * p.Cin * 2);      // bytes between two 32-channel blocks of W
-    V8 xr[P], wr[P][NB];
-    auto issue = [&](int slot, int ks) {
-        xr[slot] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(srd_x, voff_x, (unsigned)(ks * 32), 0));
+    // ---- staging plan of this thread: piece = 16 bytes; slab s of a plane = rows 32 s .. 32 s + 31, thread -> (row tid >> 3, piece tid & 7)
+    const int nch = p.Cin / (QP_KC * KW);                       // chunks per contraction wave (the host checks divisibility)
+    const unsigned kspan = (unsigned)(p.Cin / KW) * 2u;         // bytes of a row one contraction wave covers
+    const int prow = tid >> 3, pcol = (tid & 7) * 16;
+    const unsigned wv0 = (unsigned)(prow * p.Cin * 2 + pcol), wslab = (unsigned)(32 * p.Cin * 2);
+    unsigned xv[XSL];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-            wr[slot][nb] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(srd_w, voff_w, (unsigned)(ks * 32) + (unsigned)nb * wblk, 0));
+    for (int j = 0; j < XSL; ++j) {
+        const int n = row0 + j * 32 + prow;
+        xv[j] = n < p.N ? (unsigned)((long)n * p.x_sn * 2) + (unsigned)pcol : OOB_OFF;
+    }
+    char *park_base = work + prow * QP_SROW + pcol;
+    u32x4 wreg[WPT], xreg[XPT];
+    auto request = [&](int c) {      // chunk c of every contraction wave -> registers (c == nch: out of range, zeros)
+        const unsigned koff = c < nch ? (unsigned)c * (QP_KC * 2) : OOB_OFF;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_w, wv0 + (unsigned)(i % WSL) * wslab + (unsigned)(i / WSL) * kspan + koff, 0, 0);
+#pragma unroll
+        for (int j = 0; j < XPT; ++j)
+            xreg[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_x, (xv[j % XSL] == OOB_OFF || koff == OOB_OFF) ? OOB_OFF : xv[j % XSL] + (unsigned)(j / XSL) * kspan + koff, 0, 0);
     };
+    auto park = [&]() {
 #pragma unroll
-    for (int j = 0; j < P; ++j) issue(j, j);
-
-    {   // park K (waits for the K loads only: the ring's loads were issued after them)
+        for (int i = 0; i < WPT; ++i) *reinterpret_cast<u32x4 *>(park_base + (i / WSL) * PLANE + (i % WSL) * 32 * QP_SROW) = wreg[i];
+#pragma unroll
+        for (int j = 0; j < XPT; ++j) *reinterpret_cast<u32x4 *>(park_base + (j / XSL) * PLANE + (TN + (j % XSL) * 32) * QP_SROW) = xreg[j];
+    };
+    request(0);
+    {   // park K (waits for the K loads only: chunk 0's loads were issued after them)
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
             const int c = tid + i * 256;
             if (c < nkchunk) { const int row = c / CPR, ch = c - row * CPR; *reinterpret_cast<u32x4 *>(Kt + row * ROWB + ch * 16) = kreg[i]; }
         }
     }
+    park();
+    __syncthreads();
 
-    f32x16 acc[NB];
+    // ---- main loop: acc[nb] (32 channels x 32 tokens) += W[channels][64 k] X[tokens][64 k]^T per chunk, operands read from LDS in MFMA layout
+    f32x16 acc[NBW];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-    for (int ks0 = 0; ks0 + P < S; ks0 += P) {
+    const char *a_base = work + kw * PLANE + (cw * NBW * 32 + swap23(l31)) * QP_SROW + hi * 16;
+    const char *b_base = work + kw * PLANE + (TN + tw * 32 + l31) * QP_SROW + hi * 16;
+    for (int c = 0; c < nch; ++c) {
+        request(c + 1);
+        // the requests go out BEFORE this chunk's MFMAs (hipcc sinks them down to the park otherwise: an exposed load latency per
+        // chunk): nothing crosses this point
+        __builtin_amdgcn_sched_barrier(0);
+        // operand fragments one k-step ahead of the MFMAs that use them
+        V8 af[2][NBW], xf[2];
+        auto frags = [&](int ks) {
+            xf[ks & 1] = *reinterpret_cast<const V8 *>(b_base + ks * 32);
 #pragma unroll
-        for (int j = 0; j < P; ++j) {
+            for (int nb = 0; nb < NBW; ++nb) af[ks & 1][nb] = *reinterpret_cast<const V8 *>(a_base + nb * 32 * QP_SROW + ks * 32);
+        };
+        frags(0);
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma32(wr[j][nb], xr[j], acc[nb]);
-            issue(j, ks0 + P + j);
+        for (int ks = 0; ks < QP_KC / 16; ++ks) {
+            if (ks + 1 < QP_KC / 16) frags(ks + 1);
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) acc[nb] = mfma32(af[ks & 1][nb], xf[ks & 1], acc[nb]);
         }
+        // issue order of the chunk (hipcc's own choice behind a scheduling barrier is read -> wait -> MFMA, one LDS latency per
+        // MFMA): the first k-step's NBW + 1 fragment reads, then one read of the NEXT k-step behind every MFMA, then the last MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, NBW + 1, 0);
+#pragma unroll
+        for (int i = 0; i < 3 * (NBW + 1); ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NBW - 3, 0);
+        __syncthreads();              // every wave is done with the staged chunk
+        if (c + 1 < nch) park();
+        __syncthreads();
     }
-#pragma unroll
-    for (int j = 0; j < P; ++j)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = mfma32(wr[j][nb], xr[j], acc[nb]);
 
     // ---- the contraction split over KW waves: partial accumulators meet in LDS (fp32, lane-contiguous 16-byte pieces: conflict-free)
     auto red_store = [&](char *buf) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4)
                 *reinterpret_cast<f32x4 *>(buf + ((nb * 4 + r4) * 64 + lane) * 16) = f32x4{acc[nb][r4 * 4], acc[nb][r4 * 4 + 1], acc[nb][r4 * 4 + 2], acc[nb][r4 * 4 + 3]};
     };
     auto red_add = [&](const char *buf) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(buf + ((nb * 4 + r4) * 64 + lane) * 16);
@@ -162,9 +211,10 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
             }
     };
     if constexpr (KW == 2) {
-        if (kw == 1) red_store(work + tw * RED_BYTES);
+        const int rid = cw * TW + tw;
+        if (kw == 1) red_store(work + rid * RED_BYTES);
         __syncthreads();
-        if (kw == 0) red_add(work + tw * RED_BYTES);
+        if (kw == 0) red_add(work + rid * RED_BYTES);
         __syncthreads();                     // (the Q tile below aliases the reduction buffers)
     } else if constexpr (KW == 4) {
         if (kw >= 2) red_store(work + (kw - 2) * RED_BYTES);
@@ -180,9 +230,9 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
     // ---- Q tile, rounded to T, into LDS: row = token, 16-byte piece (nb, half, hi) = channels 32 nb + 16 half + 8 hi .. + 7
     char *Qt = work;
     if (kw == 0) {
-        char *qrow = Qt + (tw * 32 + l31) * ROWB + hi * 16;
+        char *qrow = Qt + (tw * 32 + l31) * ROWB + cw * NBW * 64 + hi * 16;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 V8 v;
@@ -264,20 +314,21 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------
 
-struct QprojPlan { int nb, tw, kw; };
+struct QprojPlan { int nb, tw, cw, kw; };
 
-// Tile shape for a problem: the widest tile that still gives the chip ~200 workgroups, else the one with the most workgroups.
-// TN = 320 channels needs C % 320 == 0 and whole heads per tile (320 % D == 0); TN = 160 likewise with 160.
+// Tile shape for a problem: the largest tile that still gives the chip ~180 workgroups, else the one with the most workgroups.
+// TN = 32 nb channels needs C % TN == 0 and whole heads per tile (TN % D == 0); the contraction must split into 64-element chunks
+// per contraction wave (Cin % (64 kw) == 0).
 static bool qproj_plan(const pww_qproj_desc_t *d, QprojPlan *out) {
     const int C = d->H * d->D;
-    const QprojPlan cand[] = {{10, 4, 1}, {10, 2, 2}, {10, 1, 4}, {5, 4, 1}, {5, 2, 2}, {5, 1, 4}};
+    const QprojPlan cand[] = {{10, 4, 1, 1}, {10, 2, 2, 1}, {10, 1, 2, 2}, {5, 4, 1, 1}, {5, 1, 1, 4}};
     long best_wg = 0;
     bool found = false;
     for (const QprojPlan &c : cand) {
         const int tn = c.nb * 32, tm = c.tw * 32;
-        if (C % tn || tn % d->D || d->Cin % (16 * c.kw * QP_RING)) continue;
+        if (C % tn || tn % d->D || d->Cin % (QP_KC * c.kw)) continue;
         const long wgs = (long)d->B * ((d->N + tm - 1) / tm) * (C / tn);
-        if (wgs >= 200) { *out = c; return true; }
+        if (wgs >= 180) { *out = c; return true; }
         if (wgs > best_wg) { best_wg = wgs; *out = c; found = true; }
     }
     return found;
@@ -285,17 +336,20 @@ static bool qproj_plan(const pww_qproj_desc_t *d, QprojPlan *out) {
 
 int qproj_parts(const pww_qproj_desc_t *d) {
     QprojPlan pl;
-    if (!d || d->B <= 0 || d->N <= 0 || d->H <= 0 || d->D <= 0 || !qproj_plan(d, &pl)) return 0;
+    if (!d || d->B <= 0 || d->N <= 0 || d->H <= 0 || d->D <= 0 || d->Cin <= 0 || d->D % 8 || d->M <= 0 || d->M > QP_MAX_KEYS || !qproj_plan(d, &pl)) return 0;
     return ((d->N + pl.tw * 32 - 1) / (pl.tw * 32)) * (d->H * d->D / (pl.nb * 32));
 }
 
-template <typename T, int NB, int TW, int KW>
+template <typename T, int NB, int TW, int CW, int KW>
 static int launch_qproj(const QprojParams &p, hipStream_t stream) {
-    constexpr int TN = NB * 32, TM = TW * 32, ROWB = TN * 2 + 16, RED_BYTES = NB * 16 * 64 * 4;
-    constexpr int NRED = KW == 1 ? 0 : (KW == 2 ? TW : 2);
-    constexpr size_t work = (size_t)NRED * RED_BYTES > (size_t)TM * ROWB ? (size_t)NRED * RED_BYTES : (size_t)TM * ROWB;
+    constexpr int TN = NB * 32, TM = TW * 32, ROWB = TN * 2 + 16, RED_BYTES = (NB / CW) * 16 * 64 * 4;
+    constexpr int NRED = KW == 1 ? 0 : (KW == 2 ? TW * CW : 2);
+    constexpr size_t stage = (size_t)KW * (TN + TM) * QP_SROW;
+    constexpr size_t work_a = stage > (size_t)NRED * RED_BYTES ? stage : (size_t)NRED * RED_BYTES;
+    constexpr size_t work = work_a > (size_t)TM * ROWB ? work_a : (size_t)TM * ROWB;
     const size_t lds = (((size_t)p.M * ROWB + 15) & ~(size_t)15) + work + 16 * sizeof(double);
-    auto kern = qproj_stat_kernel<T, NB, TW, KW>;
+    if (lds > 160 * 1024 - 512) { set_error("qproj_stat: internal error: %zu bytes of LDS", lds); return PWW_EINVAL; }
+    auto kern = qproj_stat_kernel<T, NB, TW, CW, KW>;
     static thread_local size_t lds_attr[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // per device (hipFuncSetAttribute is per device)
     int dev = 0;
     if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return PWW_EHIP;
@@ -321,7 +375,7 @@ int qproj_stat(const void *x, const void *w, void *q, const void *k, const float
     if (d->D % 8 || d->M > QP_MAX_KEYS) { set_error("qproj_stat: head dim %d must be a multiple of 8 and M = %d at most %d", d->D, d->M, QP_MAX_KEYS); return PWW_ENOTSUP; }
     QprojPlan pl;
     if (!qproj_plan(d, &pl)) {
-        set_error("qproj_stat: no tile shape for C = %d (a multiple of 160 or 320 holding whole heads of %d) and Cin = %d (a multiple of 80)", d->H * d->D, d->D, d->Cin);
+        set_error("qproj_stat: no tile shape for C = %d (a multiple of 160 or 320 holding whole heads of %d) and Cin = %d (a multiple of 64)", d->H * d->D, d->D, d->Cin);
         return PWW_ENOTSUP;
     }
     const auto mis = [](const void *ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) != 0; };
@@ -357,13 +411,12 @@ int qproj_stat(const void *x, const void *w, void *q, const void *k, const float
             return PWW_EINVAL;
         }
     }
-#define PWW_QP(T)                                                                      \
-    if (pl.nb == 10 && pl.tw == 4) return launch_qproj<T, 10, 4, 1>(p, stream);        \
-    if (pl.nb == 10 && pl.tw == 2) return launch_qproj<T, 10, 2, 2>(p, stream);        \
-    if (pl.nb == 10 && pl.tw == 1) return launch_qproj<T, 10, 1, 4>(p, stream);        \
-    if (pl.nb == 5 && pl.tw == 4) return launch_qproj<T, 5, 4, 1>(p, stream);          \
-    if (pl.nb == 5 && pl.tw == 2) return launch_qproj<T, 5, 2, 2>(p, stream);          \
-    return launch_qproj<T, 5, 1, 4>(p, stream);
+#define PWW_QP(T)                                                                         \
+    if (pl.nb == 10 && pl.tw == 4) return launch_qproj<T, 10, 4, 1, 1>(p, stream);        \
+    if (pl.nb == 10 && pl.tw == 2) return launch_qproj<T, 10, 2, 2, 1>(p, stream);        \
+    if (pl.nb == 10 && pl.tw == 1) return launch_qproj<T, 10, 1, 2, 2>(p, stream);        \
+    if (pl.nb == 5 && pl.tw == 4) return launch_qproj<T, 5, 4, 1, 1>(p, stream);          \
+    return launch_qproj<T, 5, 1, 1, 4>(p, stream);
     if (d->dtype == PWW_DTYPE_F16) { PWW_QP(f16) }
     PWW_QP(bf16)
 #undef PWW_QP

@@ -579,6 +579,30 @@ static void run_qproj(const QCase &c, bool timing) {
     HIPCHECK(hipMemset(dq, 0xff, (size_t)B * N * C * 2)); HIPCHECK(hipMemset(dparts, 0xff, (size_t)B * nparts * 32));
     std::vector<float> gate(B, 1.f); if (B > 1) gate[B - 1] = 0.f;        // last image gated out: Q still written, no partials
     float *dgate = dalloc<float>(B); HIPCHECK(hipMemcpy(dgate, gate.data(), B * 4, hipMemcpyHostToDevice));
+    if (g_product_only) {        // --product-only: ONLY the two launches the product issues per cross-attention layer (for PMC passes)
+        std::vector<float> g2(B, 1.f); if (B > 1) for (int b = B / 2; b < B; ++b) g2[b] = 0.f;
+        HIPCHECK(hipMemcpy(dgate, g2.data(), B * 4, hipMemcpyHostToDevice));
+        std::vector<float> bias((size_t)N * M, 0.f);
+        for (int n = 0; n < N; ++n) for (int m = 0; m < 32 && m < M; ++m) bias[(size_t)n * M + m] = (rng_uniform() < 0.3f) ? rng_uniform() * 1.5f : 0.f;
+        float *dbias = dalloc<float>(bias.size()); HIPCHECK(hipMemcpy(dbias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+        pww_attn_desc_t d; memset(&d, 0, sizeof(d));
+        d.dtype = c.dtype; d.B = B; d.H = H; d.N = N; d.M = M; d.D = D;
+        d.q_stride[0] = (int64_t)N * C; d.q_stride[1] = D; d.q_stride[2] = C;
+        d.k_stride[0] = c.shared_k ? 0 : (int64_t)M * C; d.k_stride[1] = D; d.k_stride[2] = C;
+        d.v_stride[0] = d.k_stride[0]; d.v_stride[1] = D; d.v_stride[2] = C;
+        d.o_stride[0] = (int64_t)N * C; d.o_stride[1] = D; d.o_stride[2] = C;
+        d.scale = 1.0f / sqrtf((float)D); d.bias_stride[2] = M; d.bias_stride[3] = 1;
+        pww_cross_opts_t op; memset(&op, 0, sizeof(op)); op.size = sizeof(op); op.bias_cols = 32; op.gated_images = B > 1 ? B / 2 : 0;
+        int r = 0;
+        for (int i = 0; i < 20 && !r; ++i) {
+            r = pww_qproj_stat(dx, dw, dq, dk, dgate, &qd, PWW_STAT_MAX, dparts, (size_t)B * nparts * 32, nullptr);
+            if (!r) r = pww_cross_attn_fwd_parts(dq, dk, dv, o2, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, dparts, nparts, nullptr, &op, nullptr);
+        }
+        HIPCHECK(hipDeviceSynchronize());
+        printf("%s %-30s product-only: 20 x (qproj_stat, cross_attn_fwd_parts) rc=%d %s\n", r ? "FAIL" : "PASS", c.name, r, r ? pww_last_error() : "");
+        if (r) g_fail++;
+        return;
+    }
     int rc = pww_qproj_stat(dx, dw, dq, dk, dgate, &qd, PWW_STAT_ALL, dparts, (size_t)B * nparts * 32, nullptr);
     HIPCHECK(hipDeviceSynchronize());
     if (rc) { printf("FAIL %-30s pww_qproj_stat rc=%d err=%s\n", c.name, rc, pww_last_error()); g_fail++; return; }
@@ -718,8 +742,8 @@ static void check_qproj(const char *only, const char *match, bool quick) {
         {"qproj_n3990_b3_shared_k", PWW_DTYPE_F16, 3, 3990, 320, 8, 40, 77, true, false},
         {"qproj_n100_m40_d80", PWW_DTYPE_BF16, 2, 100, 640, 8, 80, 40, false, false},
         {"qproj_n333_m128_d160", PWW_DTYPE_BF16, 1, 333, 1280, 8, 160, 128, false, false},
-        {"qproj_n50_m1_d32", PWW_DTYPE_F16, 5, 50, 160, 5, 32, 1, true, false},
-        {"qproj_n700_m33_d16_c160", PWW_DTYPE_BF16, 7, 700, 80, 10, 16, 33, false, false},
+        {"qproj_n50_m1_d32", PWW_DTYPE_F16, 5, 50, 192, 5, 32, 1, true, false},
+        {"qproj_n700_m33_d16_c160", PWW_DTYPE_BF16, 7, 700, 128, 10, 16, 33, false, false},
         {"qproj_n2000_b40_d40", PWW_DTYPE_BF16, 40, 2000, 320, 8, 40, 77, false, false},
     };
     for (const QCase &c : cases) {

@@ -90,7 +90,7 @@ def test_qproj_stat_matches_gemm_and_qk_reduce(gpu_device, dtype, name, B, N, Ci
 def test_qproj_unsupported_shapes_say_so(gpu_device):
     from pww_hip import ops
     from pww_hip._lib import PwwHipError
-    x = torch.randn(1, 64, 96, device=gpu_device, dtype=torch.float16)        # Cin = 96: not a multiple of 80
+    x = torch.randn(1, 64, 96, device=gpu_device, dtype=torch.float16)        # Cin = 96: not a multiple of 64
     w = torch.randn(320, 96, device=gpu_device, dtype=torch.float16)
     k = torch.randn(1, 77, 320, device=gpu_device, dtype=torch.float16)
     assert ops.qproj_parts(x, w, k, 8) == 0
