@@ -23,6 +23,7 @@
 //     head) units are dealt to the 4 waves: score blocks S^T = K_h Q^T on the MFMA, masked (rows >= N, keys >= M), reduced per lane,
 //     per wave, per workgroup -> ONE fp64 partial per workgroup. Statistics are those of the ROUNDED Q the attention kernel reads.
 #include <string.h>
+#include <type_traits>
 #include "pww_attn_core.h"
 
 namespace pww {
@@ -36,7 +37,13 @@ struct QprojParams {
     long x_sb, x_sn, q_sb, q_sn, k_sb, k_sm;     // elements
     int ntile, ncg, nparts;   // token tiles per image, channel groups, partials per image (= ntile * ncg)
     int fields;               // which of the four fields anybody will read: bit 0 max, 1 min, 2 sum, 3 sum of squares
+    unsigned long long *timeline;     // debug: per-workgroup phase time stamps (pww_debug_timeline), normally null
+    unsigned timeline_wgs;
 };
+
+__device__ __forceinline__ void qp_stamp(const QprojParams &p, int slot) {
+    if (p.timeline && threadIdx.x == 0 && blockIdx.x < p.timeline_wgs) p.timeline[(long)blockIdx.x * TL_SLOTS + slot] = wall_clock64();
+}
 
 constexpr int QP_MAX_KEYS = 128;
 constexpr int QP_KC = 64;             // contraction elements per staged chunk: 128 bytes = one full cache line per operand row
@@ -75,6 +82,8 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
     const int tw = wave % TW, cw = (wave / TW) % CW, kw = wave / (TW * CW);
+    qp_stamp(p, 0);
+    const unsigned long long tl_c0 = p.timeline ? clock64() : 0ull;
 
     // workgroup -> (image, token tile, channel group): XCD x (= blockIdx & 7) always works on channel group x % ncg, so an XCD's L2
     // holds ONE slice of W_q (<= 820 KB) for the whole launch
@@ -124,32 +133,41 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
         xv[j] = n < p.N ? (unsigned)((long)n * p.x_sn * 2) + (unsigned)pcol : OOB_OFF;
     }
     char *park_base = work + prow * QP_SROW + pcol;
-    u32x4 wreg[WPT], xreg[XPT];
-    auto request = [&](int c) {      // chunk c of every contraction wave -> registers (c == nch: out of range, zeros)
+    // TWO register sets: chunk c + 1 sits in one while chunk c + 2 is in flight into the other (one chunk of look-ahead left every
+    // chunk's load latency exposed: 20 - 40 MFMAs per wave and chunk are 0.3 - 0.6 us, an L2 round trip under load is 1 us)
+    u32x4 wreg[2][WPT], xreg[2][XPT];
+    auto request = [&](auto set, int c) {      // chunk c of every contraction wave -> register set (c >= nch: out of range, zeros, no traffic)
+        constexpr int S = decltype(set)::value;
         const unsigned koff = c < nch ? (unsigned)c * (QP_KC * 2) : OOB_OFF;
 #pragma unroll
         for (int i = 0; i < WPT; ++i)
-            wreg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_w, wv0 + (unsigned)(i % WSL) * wslab + (unsigned)(i / WSL) * kspan + koff, 0, 0);
+            wreg[S][i] = __builtin_amdgcn_raw_buffer_load_b128(srd_w, wv0 + (unsigned)(i % WSL) * wslab + (unsigned)(i / WSL) * kspan + koff, 0, 0);
 #pragma unroll
         for (int j = 0; j < XPT; ++j)
-            xreg[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_x, (xv[j % XSL] == OOB_OFF || koff == OOB_OFF) ? OOB_OFF : xv[j % XSL] + (unsigned)(j / XSL) * kspan + koff, 0, 0);
+            xreg[S][j] = __builtin_amdgcn_raw_buffer_load_b128(srd_x, (xv[j % XSL] == OOB_OFF || koff == OOB_OFF) ? OOB_OFF : xv[j % XSL] + (unsigned)(j / XSL) * kspan + koff, 0, 0);
     };
-    auto park = [&]() {
+    auto park = [&](auto set) {
+        constexpr int S = decltype(set)::value;
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) *reinterpret_cast<u32x4 *>(park_base + (i / WSL) * PLANE + (i % WSL) * 32 * QP_SROW) = wreg[i];
+        for (int i = 0; i < WPT; ++i) *reinterpret_cast<u32x4 *>(park_base + (i / WSL) * PLANE + (i % WSL) * 32 * QP_SROW) = wreg[S][i];
 #pragma unroll
-        for (int j = 0; j < XPT; ++j) *reinterpret_cast<u32x4 *>(park_base + (j / XSL) * PLANE + (TN + (j % XSL) * 32) * QP_SROW) = xreg[j];
+        for (int j = 0; j < XPT; ++j) *reinterpret_cast<u32x4 *>(park_base + (j / XSL) * PLANE + (TN + (j % XSL) * 32) * QP_SROW) = xreg[S][j];
     };
-    request(0);
-    {   // park K (waits for the K loads only: chunk 0's loads were issued after them)
+    typedef std::integral_constant<int, 0> Set0;
+    typedef std::integral_constant<int, 1> Set1;
+    request(Set0{}, 0);
+    {   // park K (waits for the K loads only: chunk 0's loads were issued after them); its registers are free before the second set fills
 #pragma unroll
         for (int i = 0; i < KCH; ++i) {
             const int c = tid + i * 256;
             if (c < nkchunk) { const int row = c / CPR, ch = c - row * CPR; *reinterpret_cast<u32x4 *>(Kt + row * ROWB + ch * 16) = kreg[i]; }
         }
     }
-    park();
+    request(Set1{}, 1);
+    park(Set0{});
+    request(Set0{}, 2);
     __syncthreads();
+    qp_stamp(p, 1);
 
     // ---- main loop: acc[nb] (32 channels x 32 tokens) += W[channels][64 k] X[tokens][64 k]^T per chunk, operands read from LDS in MFMA layout
     f32x16 acc[NBW];
@@ -159,10 +177,7 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
     const char *a_base = work + kw * PLANE + (cw * NBW * 32 + swap23(l31)) * QP_SROW + hi * 16;
     const char *b_base = work + kw * PLANE + (TN + tw * 32 + l31) * QP_SROW + hi * 16;
-    for (int c = 0; c < nch; ++c) {
-        request(c + 1);
-        // the requests go out BEFORE this chunk's MFMAs (hipcc sinks them down to the park otherwise: an exposed load latency per
-        // chunk): nothing crosses this point
+    auto chunk_step = [&](auto next_set, int c) {      // compute chunk c (staged), park chunk c + 1 (in `next_set`), request chunk c + 3 into that set
         __builtin_amdgcn_sched_barrier(0);
         // operand fragments one k-step ahead of the MFMAs that use them
         V8 af[2][NBW], xf[2];
@@ -188,9 +203,17 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
         }
         __builtin_amdgcn_sched_group_barrier(0x008, NBW - 3, 0);
         __syncthreads();              // every wave is done with the staged chunk
-        if (c + 1 < nch) park();
+        if (c + 1 < nch) {
+            park(next_set);
+            request(next_set, c + 3);
+        }
         __syncthreads();
+    };
+    for (int c = 0; c < nch; c += 2) {
+        chunk_step(Set1{}, c);
+        if (c + 1 < nch) chunk_step(Set0{}, c + 1);
     }
+    qp_stamp(p, 2);
 
     // ---- the contraction split over KW waves: partial accumulators meet in LDS (fp32, lane-contiguous 16-byte pieces: conflict-free)
     auto red_store = [&](char *buf) {
@@ -242,6 +265,7 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
             }
     }
     __syncthreads();
+    qp_stamp(p, 3);
 
     // ---- (a) the workgroup writes its tile: 16-byte pieces, consecutive threads = consecutive pieces of a row
     for (int c = tid; c < TM * CPR; c += 256) {
@@ -250,8 +274,12 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
             *reinterpret_cast<u32x4 *>(Qb + (long)(row0 + row) * p.q_sn + ch * 8) = *reinterpret_cast<const u32x4 *>(Qt + row * ROWB + ch * 16);
     }
 
+    qp_stamp(p, 4);
     // ---- (b) statistic partial of the tile
-    if (p.fields == 0 || gate == 0.f) return;            // workgroup-uniform
+    if (p.fields == 0 || gate == 0.f) {                   // workgroup-uniform
+        if (p.timeline && threadIdx.x == 0 && blockIdx.x < p.timeline_wgs) p.timeline[(long)blockIdx.x * TL_SLOTS + 7] = clock64() - tl_c0;
+        return;
+    }
     const int HT = TN / p.D;                              // heads in the tile
     const int nkb = (p.M + 31) >> 5;
     const bool ragged_heads = (p.D & 15) != 0;            // head boundaries inside a 16-channel slice (d = 40): the foreign half is masked
@@ -270,12 +298,27 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
         const char *qp = Qt + (tu * 32 + l31) * ROWB + hi * 16;
         const char *kp = Kt + krow * ROWB + hi * 16;
+        // fragments of slice ks + 1 are requested before the MFMAs of slice ks (the last iteration re-reads its own slice)
+        auto q_frag = [&](int ks) {
+            V8 f = *reinterpret_cast<const V8 *>(qp + ks * 32);
+            if (ragged_heads && (ks * 16 + hi * 8) / p.D != hh) f = zero8<V8>();
+            return f;
+        };
+        V8 qf = q_frag(ks_lo), kf[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) kf[kb] = *reinterpret_cast<const V8 *>(kp + (kb < nkb ? kb : 0) * 32 * ROWB + ks_lo * 32);      // (rows past M: whatever LDS holds -- those scores are masked below)
         for (int ks = ks_lo; ks <= ks_hi; ++ks) {
-            V8 qf = *reinterpret_cast<const V8 *>(qp + ks * 32);
-            if (ragged_heads && (ks * 16 + hi * 8) / p.D != hh) qf = zero8<V8>();
+            const int kn = ks < ks_hi ? ks + 1 : ks;
+            const V8 qn = q_frag(kn);
+            V8 kfn[4];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) kfn[kb] = *reinterpret_cast<const V8 *>(kp + (kb < nkb ? kb : 0) * 32 * ROWB + kn * 32);
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb)
-                if (kb < nkb) s[kb] = mfma32(*reinterpret_cast<const V8 *>(kp + kb * 32 * ROWB + ks * 32), qf, s[kb]);       // (rows past M: whatever LDS holds -- those scores are masked below)
+                if (kb < nkb) s[kb] = mfma32(kf[kb], qf, s[kb]);
+            qf = qn;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) kf[kb] = kfn[kb];
         }
         float usum = 0.f, usq = 0.f;
 #pragma unroll
@@ -310,6 +353,8 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
         double *out = p.partials + ((long)b * p.nparts + (long)tile * p.ncg + cg) * 4;
         out[0] = m; out[1] = n; out[2] = a; out[3] = q2;
     }
+    qp_stamp(p, 5);
+    if (p.timeline && threadIdx.x == 0 && blockIdx.x < p.timeline_wgs) p.timeline[(long)blockIdx.x * TL_SLOTS + 7] = clock64() - tl_c0;
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------
@@ -321,7 +366,10 @@ struct QprojPlan { int nb, tw, cw, kw; };
 // per contraction wave (Cin % (64 kw) == 0).
 static bool qproj_plan(const pww_qproj_desc_t *d, QprojPlan *out) {
     const int C = d->H * d->D;
-    const QprojPlan cand[] = {{10, 4, 1, 1}, {10, 2, 2, 1}, {10, 1, 2, 2}, {5, 4, 1, 1}, {5, 1, 1, 4}};
+    // 160-channel tiles where the heads allow it (d = 40 / 80 / 160: 69 - 90 KB of LDS, two workgroups per CU hide each other's
+    // latencies), 320-channel tiles otherwise (d = 64); within a family: the largest tile that fills the chip
+    // (a 128 x 320 tile -- <10, 4, 1, 1> -- needs more than 512 registers with two operand sets in flight: not instantiated)
+    const QprojPlan cand[] = {{5, 4, 1, 1}, {5, 2, 1, 2}, {5, 1, 1, 4}, {10, 2, 2, 1}, {10, 1, 2, 2}};
     long best_wg = 0;
     bool found = false;
     for (const QprojPlan &c : cand) {
@@ -392,6 +440,8 @@ int qproj_stat(const void *x, const void *w, void *q, const void *k, const float
     p.B = d->B; p.N = d->N; p.Cin = d->Cin; p.C = C; p.D = d->D; p.M = d->M;
     p.x_sb = d->x_stride[0]; p.x_sn = d->x_stride[1]; p.q_sb = d->q_stride[0]; p.q_sn = d->q_stride[1];
     p.k_sb = d->k_stride[0]; p.k_sm = d->k_stride[1];
+    p.timeline = debug_timeline();
+    p.timeline_wgs = (unsigned)(debug_timeline_bytes() / (TL_SLOTS * sizeof(unsigned long long)));
     p.ntile = (d->N + pl.tw * 32 - 1) / (pl.tw * 32);
     p.ncg = C / (pl.nb * 32);
     p.nparts = p.ntile * p.ncg;
@@ -412,10 +462,10 @@ int qproj_stat(const void *x, const void *w, void *q, const void *k, const float
         }
     }
 #define PWW_QP(T)                                                                         \
-    if (pl.nb == 10 && pl.tw == 4) return launch_qproj<T, 10, 4, 1, 1>(p, stream);        \
     if (pl.nb == 10 && pl.tw == 2) return launch_qproj<T, 10, 2, 2, 1>(p, stream);        \
     if (pl.nb == 10 && pl.tw == 1) return launch_qproj<T, 10, 1, 2, 2>(p, stream);        \
     if (pl.nb == 5 && pl.tw == 4) return launch_qproj<T, 5, 4, 1, 1>(p, stream);          \
+    if (pl.nb == 5 && pl.tw == 2) return launch_qproj<T, 5, 2, 1, 2>(p, stream);          \
     return launch_qproj<T, 5, 1, 1, 4>(p, stream);
     if (d->dtype == PWW_DTYPE_F16) { PWW_QP(f16) }
     PWW_QP(bf16)
