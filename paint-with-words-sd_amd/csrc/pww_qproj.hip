@@ -49,6 +49,81 @@ constexpr int QP_MAX_KEYS = 128;
 constexpr int QP_KC = 64;             // contraction elements per staged chunk: 128 bytes = one full cache line per operand row
 constexpr int QP_SROW = QP_KC * 2 + 16;     // LDS row of a staged chunk: +16 bytes => 16 rows read at one column hit 16 different 4-bank groups
 
+// One (32 tokens x one head) unit of the statistic: score blocks S^T[32 keys][32 tokens] = K_h Q^T for NKB key blocks on the MFMA (Q
+// fragments from the LDS tile, K rows from the K tile: the operands of pww_tile.h's score_tile), masked and reduced into the lane's
+// running extremes and fp64 sums. Fragments of slice ks + 1 are requested before the MFMAs of slice ks. Rows of the K tile past M hold
+// whatever LDS holds: their scores are masked.
+template <typename T, int NKB, int ROWB>
+__device__ __forceinline__ void qp_stat_unit(const char *qp, const char *kp, int hh, int D, const float (&neg)[16], int hi, bool rvalid, int fields,
+                                             float &vmax, float &vmin, double &dsum, double &dsq) {
+    typedef typename Vec<T>::v8 V8;
+    const int ks_lo = (hh * D) >> 4, ks_hi = ((hh + 1) * D - 1) >> 4;
+    const bool ragged = (D & 15) != 0;         // head boundaries inside a 16-channel slice (d = 40): the foreign half of a boundary slice is zeroed
+    const int c_lo = hh * D, c_hi = c_lo + D;  // the head's channels within the tile
+    auto q_frag = [&](int ks) {
+        V8 f = *reinterpret_cast<const V8 *>(qp + ks * 32);
+        const int c0 = ks * 16 + hi * 8;
+        if (ragged && (c0 < c_lo || c0 >= c_hi)) f = zero8<V8>();
+        return f;
+    };
+    f32x16 s[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+    V8 qf = q_frag(ks_lo), kf[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) kf[kb] = *reinterpret_cast<const V8 *>(kp + kb * 32 * ROWB + ks_lo * 32);
+    for (int ks = ks_lo; ks <= ks_hi; ++ks) {
+        const int kn = ks < ks_hi ? ks + 1 : ks;
+        const V8 qn = q_frag(kn);
+        V8 kfn[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) kfn[kb] = *reinterpret_cast<const V8 *>(kp + kb * 32 * ROWB + kn * 32);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) s[kb] = mfma32(kf[kb], qf, s[kb]);
+        qf = qn;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) kf[kb] = kfn[kb];
+    }
+    // one pass per field that anybody will read, each behind a wave-uniform branch (the shipped weight functions read ONE: max).
+    // Rows of the K tile past M are ZERO (the kernel fills them): their scores are exactly 0 and leave the sums alone; for the
+    // extremes the lane adds neg[r] (0 for a live key of the last block, -inf for a padding key) -- no compares, no lane masks here
+    float usum = 0.f, usq = 0.f, umax = -INFINITY, umin = INFINITY;
+    if (fields & 1) {
+#pragma unroll
+        for (int kb = 0; kb < NKB - 1; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) umax = fmaxf(umax, fmaxf(fmaxf(s[kb][r], s[kb][r + 1]), fmaxf(s[kb][r + 2], s[kb][r + 3])));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) umax = fmaxf(umax, s[NKB - 1][r] + neg[r]);
+    }
+    if (fields & 2) {
+#pragma unroll
+        for (int kb = 0; kb < NKB - 1; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) umin = fminf(umin, fminf(fminf(s[kb][r], s[kb][r + 1]), fminf(s[kb][r + 2], s[kb][r + 3])));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) umin = fminf(umin, s[NKB - 1][r] - neg[r]);
+    }
+    if (fields & 4) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) usum += s[kb][r];
+    }
+    if (fields & 8) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) usq = fmaf(s[kb][r], s[kb][r], usq);
+    }
+    if (rvalid) {       // (a token row past N contributes nothing)
+        vmax = fmaxf(vmax, umax); vmin = fminf(vmin, umin);
+        dsum += (double)usum; dsq += (double)usq;
+    }
+}
+
 // Tile shape <NB, TW, CW, KW>: the workgroup's 4 waves are TW token waves x CW channel waves x KW contraction waves.
 //   tile = (32 TW) tokens x (32 NB) channels; a wave accumulates 32 tokens x (32 NB / CW) channels over 1 / KW of the contraction.
 // Operands are STAGED THROUGH LDS with coalesced loads: 8 consecutive threads move the 128 contiguous bytes a chunk holds of one
@@ -74,12 +149,14 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
     constexpr int WORK_BYTES = WORK_A > TM * ROWB ? WORK_A : TM * ROWB;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [K tile: M rows][work: staged chunk / reduction buffers / Q tile][red: 4 x 4 f64]
-    const int kt_bytes = (p.M * ROWB + 15) & ~15;
+    const int kt_rows = ((p.M + 31) >> 5) << 5;       // whole 32-key blocks: the rows past M are zero-filled (scores of exactly 0)
+    const int kt_bytes = kt_rows * ROWB;
     char *Kt = smem;
     char *work = smem + kt_bytes;
     double *red = reinterpret_cast<double *>(work + WORK_BYTES);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (a scalar: everything derived from it -- tile roles, loop bounds of the statistic -- stays in SGPRs)
     const int hi = lane >> 5, l31 = lane & 31;
     const int tw = wave % TW, cw = (wave / TW) % CW, kw = wave / (TW * CW);
     qp_stamp(p, 0);
@@ -162,6 +239,10 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
             const int c = tid + i * 256;
             if (c < nkchunk) { const int row = c / CPR, ch = c - row * CPR; *reinterpret_cast<u32x4 *>(Kt + row * ROWB + ch * 16) = kreg[i]; }
         }
+    }
+    for (int c = tid; c < (kt_rows - p.M) * CPR; c += 256) {
+        const int row = p.M + c / CPR, ch = c % CPR;
+        *reinterpret_cast<u32x4 *>(Kt + row * ROWB + ch * 16) = u32x4{0u, 0u, 0u, 0u};
     }
     request(Set1{}, 1);
     park(Set0{});
@@ -282,61 +363,23 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
     }
     const int HT = TN / p.D;                              // heads in the tile
     const int nkb = (p.M + 31) >> 5;
-    const bool ragged_heads = (p.D & 15) != 0;            // head boundaries inside a 16-channel slice (d = 40): the foreign half is masked
-    const bool f_max = p.fields & 1, f_min = p.fields & 2, f_sum = p.fields & 4, f_sq = p.fields & 8;
     float vmax = -INFINITY, vmin = INFINITY;
     double dsum = 0.0, dsq = 0.0;
     const int krow = swap23(l31);
+    float neg[16];            // last key block: 0 for the lane's live keys, -inf for its padding keys (register r = key 16 (r >> 3) + 8 hi + (r & 7))
+#pragma unroll
+    for (int r = 0; r < 16; ++r) neg[r] = key_of(nkb - 1, r, hi) < p.M ? 0.f : -INFINITY;
     for (int u = wave; u < TW * HT; u += 4) {
         const int tu = u % TW, hh = u / TW;
         const bool rvalid = row0 + tu * 32 + l31 < p.N;
-        const int ks_lo = (hh * p.D) >> 4, ks_hi = ((hh + 1) * p.D - 1) >> 4;
-        f32x16 s[4];
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
         const char *qp = Qt + (tu * 32 + l31) * ROWB + hi * 16;
         const char *kp = Kt + krow * ROWB + hi * 16;
-        // fragments of slice ks + 1 are requested before the MFMAs of slice ks (the last iteration re-reads its own slice)
-        auto q_frag = [&](int ks) {
-            V8 f = *reinterpret_cast<const V8 *>(qp + ks * 32);
-            if (ragged_heads && (ks * 16 + hi * 8) / p.D != hh) f = zero8<V8>();
-            return f;
-        };
-        V8 qf = q_frag(ks_lo), kf[4];
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) kf[kb] = *reinterpret_cast<const V8 *>(kp + (kb < nkb ? kb : 0) * 32 * ROWB + ks_lo * 32);      // (rows past M: whatever LDS holds -- those scores are masked below)
-        for (int ks = ks_lo; ks <= ks_hi; ++ks) {
-            const int kn = ks < ks_hi ? ks + 1 : ks;
-            const V8 qn = q_frag(kn);
-            V8 kfn[4];
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) kfn[kb] = *reinterpret_cast<const V8 *>(kp + (kb < nkb ? kb : 0) * 32 * ROWB + kn * 32);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-                if (kb < nkb) s[kb] = mfma32(kf[kb], qf, s[kb]);
-            qf = qn;
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) kf[kb] = kfn[kb];
+        switch (nkb) {      // (the key-block count is a compile-time constant inside: straight-line MFMAs, accumulators that stay put)
+            case 1: qp_stat_unit<T, 1, ROWB>(qp, kp, hh, p.D, neg, hi, rvalid, p.fields, vmax, vmin, dsum, dsq); break;
+            case 2: qp_stat_unit<T, 2, ROWB>(qp, kp, hh, p.D, neg, hi, rvalid, p.fields, vmax, vmin, dsum, dsq); break;
+            case 3: qp_stat_unit<T, 3, ROWB>(qp, kp, hh, p.D, neg, hi, rvalid, p.fields, vmax, vmin, dsum, dsq); break;
+            default: qp_stat_unit<T, 4, ROWB>(qp, kp, hh, p.D, neg, hi, rvalid, p.fields, vmax, vmin, dsum, dsq); break;
         }
-        float usum = 0.f, usq = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            if (kb < nkb) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const bool live = rvalid && key_of(kb, r, hi) < p.M;
-                    const float x = s[kb][r];
-                    if (f_max) vmax = fmaxf(vmax, live ? x : -INFINITY);
-                    if (f_min) vmin = fminf(vmin, live ? x : INFINITY);
-                    if (f_sum) usum += live ? x : 0.f;
-                    if (f_sq) usq += live ? x * x : 0.f;
-                }
-            }
-        }
-        dsum += (double)usum;
-        dsq += (double)usq;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -360,6 +403,16 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
 // ---- host side ----------------------------------------------------------------------------------------------------------------
 
 struct QprojPlan { int nb, tw, cw, kw; };
+constexpr size_t QP_LDS_LIMIT = 160 * 1024 - 1024;
+
+static size_t qproj_lds(const QprojPlan &c, int M) {
+    const size_t tn = c.nb * 32, tm = c.tw * 32, rowb = tn * 2 + 16, red = (size_t)(c.nb / c.cw) * 16 * 64 * 4;
+    const size_t nred = c.kw == 1 ? 0 : (c.kw == 2 ? c.tw * c.cw : 2);
+    size_t work = (size_t)c.kw * (tn + tm) * QP_SROW;
+    if (nred * red > work) work = nred * red;
+    if (tm * rowb > work) work = tm * rowb;
+    return (size_t)(((M + 31) >> 5) << 5) * rowb + work + 16 * sizeof(double);
+}
 
 // Tile shape for a problem: the largest tile that still gives the chip ~180 workgroups, else the one with the most workgroups.
 // TN = 32 nb channels needs C % TN == 0 and whole heads per tile (TN % D == 0); the contraction must split into 64-element chunks
@@ -374,7 +427,7 @@ static bool qproj_plan(const pww_qproj_desc_t *d, QprojPlan *out) {
     bool found = false;
     for (const QprojPlan &c : cand) {
         const int tn = c.nb * 32, tm = c.tw * 32;
-        if (C % tn || tn % d->D || d->Cin % (QP_KC * c.kw)) continue;
+        if (C % tn || tn % d->D || d->Cin % (QP_KC * c.kw) || qproj_lds(c, d->M) > QP_LDS_LIMIT) continue;
         const long wgs = (long)d->B * ((d->N + tm - 1) / tm) * (C / tn);
         if (wgs >= 180) { *out = c; return true; }
         if (wgs > best_wg) { best_wg = wgs; *out = c; found = true; }
@@ -395,8 +448,8 @@ static int launch_qproj(const QprojParams &p, hipStream_t stream) {
     constexpr size_t stage = (size_t)KW * (TN + TM) * QP_SROW;
     constexpr size_t work_a = stage > (size_t)NRED * RED_BYTES ? stage : (size_t)NRED * RED_BYTES;
     constexpr size_t work = work_a > (size_t)TM * ROWB ? work_a : (size_t)TM * ROWB;
-    const size_t lds = (((size_t)p.M * ROWB + 15) & ~(size_t)15) + work + 16 * sizeof(double);
-    if (lds > 160 * 1024 - 512) { set_error("qproj_stat: internal error: %zu bytes of LDS", lds); return PWW_EINVAL; }
+    const size_t lds = (size_t)(((p.M + 31) >> 5) << 5) * ROWB + work + 16 * sizeof(double);
+    if (lds > QP_LDS_LIMIT) { set_error("qproj_stat: internal error: %zu bytes of LDS", lds); return PWW_EINVAL; }
     auto kern = qproj_stat_kernel<T, NB, TW, CW, KW>;
     static thread_local size_t lds_attr[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // per device (hipFuncSetAttribute is per device)
     int dev = 0;
