@@ -21,7 +21,8 @@
 //   * both operands stream global -> registers (buffer loads, a ring of P k-steps in flight; rows past N read the image's last row); K of the tile's heads sits in LDS (requested first, parked while the ring fills).
 //   * epilogue: accumulators -> T -> LDS tile; the workgroup stores the tile with coalesced 16-byte row pieces, and the (token wave,
 //     head) units are dealt to the 4 waves: score blocks S^T = K_h Q^T on the MFMA, masked (rows >= N, keys >= M), reduced per lane,
-//     per wave, per workgroup -> ONE fp64 partial per workgroup. Statistics are those of the ROUNDED Q the attention kernel reads.
+//     per wave -> ONE fp64 partial per WAVE, written before the tile's stores go out (no barrier, nothing in the kernel waits for a
+//     store). Statistics are those of the ROUNDED Q the attention kernel reads.
 #include <string.h>
 #include <type_traits>
 #include "pww_attn_core.h"
@@ -35,7 +36,7 @@ struct QprojParams {
     double *partials;         // [B][nparts][4] = { max, min, sum, sum of squares }; rows of gated-out images are not written
     int B, N, Cin, C, D, M;
     long x_sb, x_sn, q_sb, q_sn, k_sb, k_sm;     // elements
-    int ntile, ncg, nparts;   // token tiles per image, channel groups, partials per image (= ntile * ncg)
+    int ntile, ncg, nparts;   // token tiles per image, channel groups, partials per image (= 4 ntile ncg: one per wave)
     int fields;               // which of the four fields anybody will read: bit 0 max, 1 min, 2 sum, 3 sum of squares
     unsigned long long *timeline;     // debug: per-workgroup phase time stamps (pww_debug_timeline), normally null
     unsigned timeline_wgs;
@@ -148,12 +149,11 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
     constexpr int WORK_A = STAGE_BYTES > NRED * RED_BYTES ? STAGE_BYTES : NRED * RED_BYTES;
     constexpr int WORK_BYTES = WORK_A > TM * ROWB ? WORK_A : TM * ROWB;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // [K tile: M rows][work: staged chunk / reduction buffers / Q tile][red: 4 x 4 f64]
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [K tile: whole 32-key blocks][work: staged chunk / reduction buffers / Q tile]
     const int kt_rows = ((p.M + 31) >> 5) << 5;       // whole 32-key blocks: the rows past M are zero-filled (scores of exactly 0)
     const int kt_bytes = kt_rows * ROWB;
     char *Kt = smem;
     char *work = smem + kt_bytes;
-    double *red = reinterpret_cast<double *>(work + WORK_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // (a scalar: everything derived from it -- tile roles, loop bounds of the statistic -- stays in SGPRs)
@@ -348,54 +348,50 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
     __syncthreads();
     qp_stamp(p, 3);
 
-    // ---- (a) the workgroup writes its tile: 16-byte pieces, consecutive threads = consecutive pieces of a row
+    // ---- (a) statistic partial of the tile: ONE partial PER WAVE (no barrier, no fold across the waves: the attention kernel folds
+    // all partials of the image anyway), written before the tile's stores go out -- nothing in this kernel ever waits for a store
+    if (p.fields != 0 && gate != 0.f) {                   // workgroup-uniform
+        const int HT = TN / p.D;                          // heads in the tile
+        const int nkb = (p.M + 31) >> 5;
+        float vmax = -INFINITY, vmin = INFINITY;
+        double dsum = 0.0, dsq = 0.0;
+        const int krow = swap23(l31);
+        float neg[16];            // last key block: 0 for the lane's live keys, -inf for its padding keys (register r = key 16 (r >> 3) + 8 hi + (r & 7))
+#pragma unroll
+        for (int r = 0; r < 16; ++r) neg[r] = key_of(nkb - 1, r, hi) < p.M ? 0.f : -INFINITY;
+        for (int u = wave; u < TW * HT; u += 4) {
+            const int tu = u % TW, hh = u / TW;
+            const bool rvalid = row0 + tu * 32 + l31 < p.N;
+            const char *qp = Qt + (tu * 32 + l31) * ROWB + hi * 16;
+            const char *kp = Kt + krow * ROWB + hi * 16;
+            switch (nkb) {      // (the key-block count is a compile-time constant inside: straight-line MFMAs, accumulators that stay put)
+                case 1: qp_stat_unit<T, 1, ROWB>(qp, kp, hh, p.D, neg, hi, rvalid, p.fields, vmax, vmin, dsum, dsq); break;
+                case 2: qp_stat_unit<T, 2, ROWB>(qp, kp, hh, p.D, neg, hi, rvalid, p.fields, vmax, vmin, dsum, dsq); break;
+                case 3: qp_stat_unit<T, 3, ROWB>(qp, kp, hh, p.D, neg, hi, rvalid, p.fields, vmax, vmin, dsum, dsq); break;
+                default: qp_stat_unit<T, 4, ROWB>(qp, kp, hh, p.D, neg, hi, rvalid, p.fields, vmax, vmin, dsum, dsq); break;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+            vmin = fminf(vmin, __shfl_xor(vmin, off));
+            dsum += __shfl_xor(dsum, off);
+            dsq += __shfl_xor(dsq, off);
+        }
+        if (lane == 0) {      // (a wave without a unit writes the neutral element)
+            double *out = p.partials + ((long)b * p.nparts + ((long)tile * p.ncg + cg) * 4 + wave) * 4;
+            out[0] = (double)vmax; out[1] = (double)vmin; out[2] = dsum; out[3] = dsq;
+        }
+    }
+    qp_stamp(p, 4);
+
+    // ---- (b) the workgroup writes its tile: 16-byte pieces, consecutive threads = consecutive pieces of a row
     for (int c = tid; c < TM * CPR; c += 256) {
         const int row = c / CPR, ch = c - row * CPR;
         if (row0 + row < p.N)
             *reinterpret_cast<u32x4 *>(Qb + (long)(row0 + row) * p.q_sn + ch * 8) = *reinterpret_cast<const u32x4 *>(Qt + row * ROWB + ch * 16);
     }
 
-    qp_stamp(p, 4);
-    // ---- (b) statistic partial of the tile
-    if (p.fields == 0 || gate == 0.f) {                   // workgroup-uniform
-        if (p.timeline && threadIdx.x == 0 && blockIdx.x < p.timeline_wgs) p.timeline[(long)blockIdx.x * TL_SLOTS + 7] = clock64() - tl_c0;
-        return;
-    }
-    const int HT = TN / p.D;                              // heads in the tile
-    const int nkb = (p.M + 31) >> 5;
-    float vmax = -INFINITY, vmin = INFINITY;
-    double dsum = 0.0, dsq = 0.0;
-    const int krow = swap23(l31);
-    float neg[16];            // last key block: 0 for the lane's live keys, -inf for its padding keys (register r = key 16 (r >> 3) + 8 hi + (r & 7))
-#pragma unroll
-    for (int r = 0; r < 16; ++r) neg[r] = key_of(nkb - 1, r, hi) < p.M ? 0.f : -INFINITY;
-    for (int u = wave; u < TW * HT; u += 4) {
-        const int tu = u % TW, hh = u / TW;
-        const bool rvalid = row0 + tu * 32 + l31 < p.N;
-        const char *qp = Qt + (tu * 32 + l31) * ROWB + hi * 16;
-        const char *kp = Kt + krow * ROWB + hi * 16;
-        switch (nkb) {      // (the key-block count is a compile-time constant inside: straight-line MFMAs, accumulators that stay put)
-            case 1: qp_stat_unit<T, 1, ROWB>(qp, kp, hh, p.D, neg, hi, rvalid, p.fields, vmax, vmin, dsum, dsq); break;
-            case 2: qp_stat_unit<T, 2, ROWB>(qp, kp, hh, p.D, neg, hi, rvalid, p.fields, vmax, vmin, dsum, dsq); break;
-            case 3: qp_stat_unit<T, 3, ROWB>(qp, kp, hh, p.D, neg, hi, rvalid, p.fields, vmax, vmin, dsum, dsq); break;
-            default: qp_stat_unit<T, 4, ROWB>(qp, kp, hh, p.D, neg, hi, rvalid, p.fields, vmax, vmin, dsum, dsq); break;
-        }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        vmax = fmaxf(vmax, __shfl_xor(vmax, off));
-        vmin = fminf(vmin, __shfl_xor(vmin, off));
-        dsum += __shfl_xor(dsum, off);
-        dsq += __shfl_xor(dsq, off);
-    }
-    if (lane == 0) { red[wave * 4 + 0] = (double)vmax; red[wave * 4 + 1] = (double)vmin; red[wave * 4 + 2] = dsum; red[wave * 4 + 3] = dsq; }
-    __syncthreads();
-    if (tid == 0) {
-        double m = red[0], n = red[1], a = red[2], q2 = red[3];
-        for (int w = 1; w < 4; ++w) { m = fmax(m, red[w * 4]); n = fmin(n, red[w * 4 + 1]); a += red[w * 4 + 2]; q2 += red[w * 4 + 3]; }
-        double *out = p.partials + ((long)b * p.nparts + (long)tile * p.ncg + cg) * 4;
-        out[0] = m; out[1] = n; out[2] = a; out[3] = q2;
-    }
     qp_stamp(p, 5);
     if (p.timeline && threadIdx.x == 0 && blockIdx.x < p.timeline_wgs) p.timeline[(long)blockIdx.x * TL_SLOTS + 7] = clock64() - tl_c0;
 }
@@ -438,7 +434,7 @@ static bool qproj_plan(const pww_qproj_desc_t *d, QprojPlan *out) {
 int qproj_parts(const pww_qproj_desc_t *d) {
     QprojPlan pl;
     if (!d || d->B <= 0 || d->N <= 0 || d->H <= 0 || d->D <= 0 || d->Cin <= 0 || d->D % 8 || d->M <= 0 || d->M > QP_MAX_KEYS || !qproj_plan(d, &pl)) return 0;
-    return ((d->N + pl.tw * 32 - 1) / (pl.tw * 32)) * (d->H * d->D / (pl.nb * 32));
+    return ((d->N + pl.tw * 32 - 1) / (pl.tw * 32)) * (d->H * d->D / (pl.nb * 32)) * 4;      // one partial per wave of every tile
 }
 
 template <typename T, int NB, int TW, int CW, int KW>
@@ -497,7 +493,7 @@ int qproj_stat(const void *x, const void *w, void *q, const void *k, const float
     p.timeline_wgs = (unsigned)(debug_timeline_bytes() / (TL_SLOTS * sizeof(unsigned long long)));
     p.ntile = (d->N + pl.tw * 32 - 1) / (pl.tw * 32);
     p.ncg = C / (pl.nb * 32);
-    p.nparts = p.ntile * p.ncg;
+    p.nparts = p.ntile * p.ncg * 4;
     switch (stat_kind) {
         case PWW_STAT_NONE: p.fields = 0; break;
         case PWW_STAT_MAX: p.fields = 1; break;

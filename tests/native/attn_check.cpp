@@ -684,7 +684,7 @@ static void run_qproj(const QCase &c, bool timing) {
     if (timing && g_timeline) {
         std::vector<float> g2(B, 1.f); if (B > 1) for (int b = B / 2; b < B; ++b) g2[b] = 0.f;
         HIPCHECK(hipMemcpy(dgate, g2.data(), B * 4, hipMemcpyHostToDevice));
-        timeline_report(c.name, "qproj_stat (stamps: 0 entry, 1 K tile + chunk 0 staged, 2 contraction done, 3 Q tile in LDS, 4 tile stored, 5 partial written)", [&]() {
+        timeline_report(c.name, "qproj_stat (stamps: 0 entry, 1 K tile + chunk 0 staged, 2 contraction done, 3 Q tile in LDS, 4 statistic partials written, 5 tile stores issued)", [&]() {
             pww_qproj_stat(dx, dw, dq, dk, dgate, &qd, PWW_STAT_MAX, dparts, (size_t)B * nparts * 32, nullptr); });
         op.gated_images = B > 1 ? B / 2 : 0;
         timeline_report(c.name, "cross_attn_fwd_parts (stamps: 0 entry, 1 K/V staged, 3 partials folded, 4 outputs stored, 5 exit)", [&]() {
