@@ -50,11 +50,17 @@ constexpr int QP_MAX_KEYS = 128;
 constexpr int QP_KC = 64;             // contraction elements per staged chunk: 128 bytes = one full cache line per operand row
 constexpr int QP_SROW = QP_KC * 2 + 16;     // LDS row of a staged chunk: +16 bytes => 16 rows read at one column hit 16 different 4-bank groups
 
+template <int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
+
 // One (32 tokens x one head) unit of the statistic: score blocks S^T[32 keys][32 tokens] = K_h Q^T for NKB key blocks on the MFMA (Q
 // fragments from the LDS tile, K rows from the K tile: the operands of pww_tile.h's score_tile), masked and reduced into the lane's
 // running extremes and fp64 sums. Fragments of slice ks + 1 are requested before the MFMAs of slice ks. Rows of the K tile past M hold
 // whatever LDS holds: their scores are masked.
-template <typename T, int NKB, int ROWB>
+// KSC > 0: the head spans exactly KSC 16-channel slices (a compile-time constant: d = 40 -> 3, 64 -> 4, 80 -> 5, 160 -> 10): every
+// fragment read of the unit is issued before its first MFMA (one LDS latency per unit instead of one per slice); KSC == 0: run-time loop.
+template <typename T, int NKB, int ROWB, int KSC>
 __device__ __forceinline__ void qp_stat_unit(const char *qp, const char *kp, int hh, int D, const float (&neg)[16], int hi, bool rvalid, int fields,
                                              float &vmax, float &vmin, double &dsum, double &dsq) {
     typedef typename Vec<T>::v8 V8;
@@ -72,6 +78,19 @@ __device__ __forceinline__ void qp_stat_unit(const char *qp, const char *kp, int
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+    if constexpr (KSC > 0) {
+        V8 qa[KSC], ka[KSC][NKB];
+#pragma unroll
+        for (int i = 0; i < KSC; ++i) {
+            qa[i] = q_frag(ks_lo + i);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) ka[i][kb] = *reinterpret_cast<const V8 *>(kp + kb * 32 * ROWB + (ks_lo + i) * 32);
+        }
+#pragma unroll
+        for (int i = 0; i < KSC; ++i)
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) s[kb] = mfma32(ka[i][kb], qa[i], s[kb]);
+    } else {
     V8 qf = q_frag(ks_lo), kf[NKB];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) kf[kb] = *reinterpret_cast<const V8 *>(kp + kb * 32 * ROWB + ks_lo * 32);
@@ -86,6 +105,7 @@ __device__ __forceinline__ void qp_stat_unit(const char *qp, const char *kp, int
         qf = qn;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) kf[kb] = kfn[kb];
+    }
     }
     // one pass per field that anybody will read, each behind a wave-uniform branch (the shipped weight functions read ONE: max).
     // Rows of the K tile past M are ZERO (the kernel fills them): their scores are exactly 0 and leave the sums alone; for the
@@ -132,7 +152,7 @@ __device__ __forceinline__ void qp_stat_unit(const char *qp, const char *kp, int
 // lines for 32 bytes each and the same lines were requested by 4 consecutive k-steps -- 24 us for the B = 2 layers against 8.5 us of
 // the stock GEMM, profiles/r04_qproj_v1_register_direct.md). Chunk c + 1 is requested into registers before chunk c is computed and
 // parked after it (one staging buffer, two barriers per chunk): the K tile, the staging buffer and the Q tile share 160 KB.
-template <typename T, int NB, int TW, int CW, int KW>
+template <typename T, int NB, int TW, int CW, int KW, int NSETS>
 __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p) {
     typedef typename Vec<T>::v8 V8;
     static_assert(TW * CW * KW == 4 && NB % CW == 0, "four waves per workgroup");
@@ -147,7 +167,6 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
     constexpr int WPT = KW * WSL, XPT = KW * XSL;     // pieces per thread and chunk
     constexpr int STAGE_BYTES = KW * PLANE;
     constexpr int WORK_A = STAGE_BYTES > NRED * RED_BYTES ? STAGE_BYTES : NRED * RED_BYTES;
-    constexpr int WORK_BYTES = WORK_A > TM * ROWB ? WORK_A : TM * ROWB;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [K tile: whole 32-key blocks][work: staged chunk / reduction buffers / Q tile]
     const int kt_rows = ((p.M + 31) >> 5) << 5;       // whole 32-key blocks: the rows past M are zero-filled (scores of exactly 0)
@@ -210,9 +229,9 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
         xv[j] = n < p.N ? (unsigned)((long)n * p.x_sn * 2) + (unsigned)pcol : OOB_OFF;
     }
     char *park_base = work + prow * QP_SROW + pcol;
-    // TWO register sets: chunk c + 1 sits in one while chunk c + 2 is in flight into the other (one chunk of look-ahead left every
-    // chunk's load latency exposed: 20 - 40 MFMAs per wave and chunk are 0.3 - 0.6 us, an L2 round trip under load is 1 us)
-    u32x4 wreg[2][WPT], xreg[2][XPT];
+    // A RING of NSETS register sets: chunks c + 1 ... c + NSETS are in flight while chunk c is computed (one chunk of look-ahead left
+    // every chunk's load latency exposed: 20 MFMAs per wave and chunk are 0.3 us, the X rows come from HBM: 1.5 - 2 us under load)
+    u32x4 wreg[NSETS][WPT], xreg[NSETS][XPT];
     auto request = [&](auto set, int c) {      // chunk c of every contraction wave -> register set (c >= nch: out of range, zeros, no traffic)
         constexpr int S = decltype(set)::value;
         const unsigned koff = c < nch ? (unsigned)c * (QP_KC * 2) : OOB_OFF;
@@ -231,7 +250,6 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
         for (int j = 0; j < XPT; ++j) *reinterpret_cast<u32x4 *>(park_base + (j / XSL) * PLANE + (TN + (j % XSL) * 32) * QP_SROW) = xreg[S][j];
     };
     typedef std::integral_constant<int, 0> Set0;
-    typedef std::integral_constant<int, 1> Set1;
     request(Set0{}, 0);
     {   // park K (waits for the K loads only: chunk 0's loads were issued after them); its registers are free before the second set fills
 #pragma unroll
@@ -244,9 +262,9 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
         const int row = p.M + c / CPR, ch = c % CPR;
         *reinterpret_cast<u32x4 *>(Kt + row * ROWB + ch * 16) = u32x4{0u, 0u, 0u, 0u};
     }
-    request(Set1{}, 1);
+    static_for<NSETS - 1>([&](auto i) { request(std::integral_constant<int, decltype(i)::value + 1>{}, decltype(i)::value + 1); });
     park(Set0{});
-    request(Set0{}, 2);
+    request(Set0{}, NSETS);
     __syncthreads();
     qp_stamp(p, 1);
 
@@ -258,7 +276,7 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
     const char *a_base = work + kw * PLANE + (cw * NBW * 32 + swap23(l31)) * QP_SROW + hi * 16;
     const char *b_base = work + kw * PLANE + (TN + tw * 32 + l31) * QP_SROW + hi * 16;
-    auto chunk_step = [&](auto next_set, int c) {      // compute chunk c (staged), park chunk c + 1 (in `next_set`), request chunk c + 3 into that set
+    auto chunk_step = [&](auto next_set, int c) {      // compute chunk c (staged), park chunk c + 1 (in `next_set`), request chunk c + 1 + NSETS into that set
         __builtin_amdgcn_sched_barrier(0);
         // operand fragments one k-step ahead of the MFMAs that use them
         V8 af[2][NBW], xf[2];
@@ -286,14 +304,15 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
         __syncthreads();              // every wave is done with the staged chunk
         if (c + 1 < nch) {
             park(next_set);
-            request(next_set, c + 3);
+            request(next_set, c + 1 + NSETS);
         }
         __syncthreads();
     };
-    for (int c = 0; c < nch; c += 2) {
-        chunk_step(Set1{}, c);
-        if (c + 1 < nch) chunk_step(Set0{}, c + 1);
-    }
+    for (int c0 = 0; c0 < nch; c0 += NSETS)
+        static_for<NSETS>([&](auto i) {
+            constexpr int I = decltype(i)::value;
+            if (c0 + I < nch) chunk_step(std::integral_constant<int, (I + 1) % NSETS>{}, c0 + I);       // (workgroup-uniform)
+        });
     qp_stamp(p, 2);
 
     // ---- the contraction split over KW waves: partial accumulators meet in LDS (fp32, lane-contiguous 16-byte pieces: conflict-free)
@@ -364,12 +383,18 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
             const bool rvalid = row0 + tu * 32 + l31 < p.N;
             const char *qp = Qt + (tu * 32 + l31) * ROWB + hi * 16;
             const char *kp = Kt + krow * ROWB + hi * 16;
-            switch (nkb) {      // (the key-block count is a compile-time constant inside: straight-line MFMAs, accumulators that stay put)
-                case 1: qp_stat_unit<T, 1, ROWB>(qp, kp, hh, p.D, neg, hi, rvalid, p.fields, vmax, vmin, dsum, dsq); break;
-                case 2: qp_stat_unit<T, 2, ROWB>(qp, kp, hh, p.D, neg, hi, rvalid, p.fields, vmax, vmin, dsum, dsq); break;
-                case 3: qp_stat_unit<T, 3, ROWB>(qp, kp, hh, p.D, neg, hi, rvalid, p.fields, vmax, vmin, dsum, dsq); break;
-                default: qp_stat_unit<T, 4, ROWB>(qp, kp, hh, p.D, neg, hi, rvalid, p.fields, vmax, vmin, dsum, dsq); break;
-            }
+            // (key-block count and, for the 77-token prompt, the slice count are compile-time constants inside: straight-line MFMAs)
+            const int nks = (((hh + 1) * p.D - 1) >> 4) - ((hh * p.D) >> 4) + 1;
+#define PWW_STAT_UNIT(NKB, KSC) qp_stat_unit<T, NKB, ROWB, KSC>(qp, kp, hh, p.D, neg, hi, rvalid, p.fields, vmax, vmin, dsum, dsq)
+            if (nkb == 3 && nks == 3) PWW_STAT_UNIT(3, 3);
+            else if (nkb == 3 && nks == 4) PWW_STAT_UNIT(3, 4);
+            else if (nkb == 3 && nks == 5) PWW_STAT_UNIT(3, 5);
+            else if (nkb == 3 && nks == 10) PWW_STAT_UNIT(3, 10);
+            else if (nkb == 1) PWW_STAT_UNIT(1, 0);
+            else if (nkb == 2) PWW_STAT_UNIT(2, 0);
+            else if (nkb == 3) PWW_STAT_UNIT(3, 0);
+            else PWW_STAT_UNIT(4, 0);
+#undef PWW_STAT_UNIT
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
@@ -437,7 +462,7 @@ int qproj_parts(const pww_qproj_desc_t *d) {
     return ((d->N + pl.tw * 32 - 1) / (pl.tw * 32)) * (d->H * d->D / (pl.nb * 32)) * 4;      // one partial per wave of every tile
 }
 
-template <typename T, int NB, int TW, int CW, int KW>
+template <typename T, int NB, int TW, int CW, int KW, int NSETS>
 static int launch_qproj(const QprojParams &p, hipStream_t stream) {
     constexpr int TN = NB * 32, TM = TW * 32, ROWB = TN * 2 + 16, RED_BYTES = (NB / CW) * 16 * 64 * 4;
     constexpr int NRED = KW == 1 ? 0 : (KW == 2 ? TW * CW : 2);
@@ -446,7 +471,7 @@ static int launch_qproj(const QprojParams &p, hipStream_t stream) {
     constexpr size_t work = work_a > (size_t)TM * ROWB ? work_a : (size_t)TM * ROWB;
     const size_t lds = (size_t)(((p.M + 31) >> 5) << 5) * ROWB + work + 16 * sizeof(double);
     if (lds > QP_LDS_LIMIT) { set_error("qproj_stat: internal error: %zu bytes of LDS", lds); return PWW_EINVAL; }
-    auto kern = qproj_stat_kernel<T, NB, TW, CW, KW>;
+    auto kern = qproj_stat_kernel<T, NB, TW, CW, KW, NSETS>;
     static thread_local size_t lds_attr[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // per device (hipFuncSetAttribute is per device)
     int dev = 0;
     if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return PWW_EHIP;
@@ -510,12 +535,15 @@ int qproj_stat(const void *x, const void *w, void *q, const void *k, const float
             return PWW_EINVAL;
         }
     }
-#define PWW_QP(T)                                                                         \
-    if (pl.nb == 10 && pl.tw == 2) return launch_qproj<T, 10, 2, 2, 1>(p, stream);        \
-    if (pl.nb == 10 && pl.tw == 1) return launch_qproj<T, 10, 1, 2, 2>(p, stream);        \
-    if (pl.nb == 5 && pl.tw == 4) return launch_qproj<T, 5, 4, 1, 1>(p, stream);          \
-    if (pl.nb == 5 && pl.tw == 2) return launch_qproj<T, 5, 2, 1, 2>(p, stream);          \
-    return launch_qproj<T, 5, 1, 1, 4>(p, stream);
+    // operand register sets in flight: as many as the register file holds beside the accumulators; the 128 x 160 tile keeps two when the
+    // launch has several workgroups per CU anyway (two sets = 2 waves per SIMD = two resident workgroups hiding each other's latencies)
+    const bool many = (long)p.B * p.ntile * p.ncg >= 512;
+#define PWW_QP(T)                                                                                            \
+    if (pl.nb == 10 && pl.tw == 2) return launch_qproj<T, 10, 2, 2, 1, 3>(p, stream);                        \
+    if (pl.nb == 10 && pl.tw == 1) return launch_qproj<T, 10, 1, 2, 2, 2>(p, stream);                        \
+    if (pl.nb == 5 && pl.tw == 4) return many ? launch_qproj<T, 5, 4, 1, 1, 2>(p, stream) : launch_qproj<T, 5, 4, 1, 1, 4>(p, stream);   \
+    if (pl.nb == 5 && pl.tw == 2) return launch_qproj<T, 5, 2, 1, 2, 3>(p, stream);                          \
+    return launch_qproj<T, 5, 1, 1, 4, 2>(p, stream);
     if (d->dtype == PWW_DTYPE_F16) { PWW_QP(f16) }
     PWW_QP(bf16)
 #undef PWW_QP
