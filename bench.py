@@ -287,7 +287,7 @@ def measured_traffic(n_tok, d, b_rows, dtype, live=False):
     passes now over the same launch through the native harness. None if the shape is not covered."""
     if live:
         return live_traffic(n_tok, d, b_rows, dtype)
-    for name in ("r03_traffic.json", "r02_attn_traffic.json"):
+    for name in ("r04_pmc.json", "r03_traffic.json", "r02_attn_traffic.json"):
         path = os.path.join(REPO, "profiles", name)
         if not os.path.isfile(path):
             continue
@@ -297,6 +297,26 @@ def measured_traffic(n_tok, d, b_rows, dtype, live=False):
             if (rec.get("N"), rec.get("D"), rec.get("B"), rec.get("dtype")) == (n_tok, d, b_rows, dtype) and rec.get("kind", "self") == "self":
                 return int(rec["hbm_bytes_per_launch"])
     return None
+
+
+def measured_mfma_busy(n_tok, d, b_rows, dtype):
+    """Matrix-pipe busy fraction of the dominant kernel from the committed PMC passes (profiles/r04_pmc.json: SQ_VALU_MFMA_BUSY_CYCLES over
+    kernel cycles x 1024 SIMDs, the shipped kernel on this shape), or None."""
+    path = os.path.join(REPO, "profiles", "r04_pmc.json")
+    if os.path.isfile(path):
+        for rec in json.load(open(path)).get("records", []):
+            if (rec.get("N"), rec.get("D"), rec.get("B"), rec.get("dtype")) == (n_tok, d, b_rows, dtype) and rec.get("kind") == "self":
+                return rec.get("mfma_busy")
+    return None
+
+
+# Issue-bound ceiling of the d = 40 / d = 64 self-attention loops (DESIGN section 4, K3): per 64-key tile and wave the loop issues 448
+# matrix-pipe cycles (14 MFMAs x 32) and ~500 VALU issue cycles (32 v_exp_f32 at 8.5 cycles, 16 v_cvt_pk, the fma / max chains:
+# profiles/r01_valu_ubench.md), and on one SIMD the two ADD UP (profiles/r02_attn_pingpong.md: t(no exp) + t(no MFMA) = t(full)):
+# the matrix pipe can be busy at most 448 / (448 + 500) = 0.47 of the time, of which 40 / 64 (d = 40 padded to 48 + 64 MFMA rows: 0.71
+# averaged over the score and PV MFMAs) is algorithmic work: 0.47 x 0.71 = 0.34 of the dense peak at the nominal clock. d = 64 has no
+# padding: 0.47.
+ATTAINABLE = {40: 0.34, 64: 0.47}
 
 
 HARNESS_CASES = {(4096, 40, 2, "bf16"): "sd15_self_n4096_d40_bf16_b2", (4096, 40, 2, "fp16"): "sd15_self_n4096_d40_f16_b2",
@@ -639,8 +659,13 @@ def main():
             result["kernels"].append(hot_logit_row(device, dtype, b_rows, n_dom, d, heads))
             result["roofline"] = {"bound": "mfma", "kernel": "self-attention N=%d d=%d (%s, B=%d rows folded)" % (n_dom, d, cfg["dtype"], b_rows),
                                   "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                                  "attainable": ATTAINABLE.get(d), "attainable_model": "issue-bound: MFMA and VALU issue cycles of a SIMD add up (448 vs ~500 per "
+                                  "64-key tile and wave), times the algorithmic share of the padded MFMA rows; see DESIGN section 4",
+                                  "mfma_busy": measured_mfma_busy(n_dom, d, b_rows, cfg["dtype"]), "mfma_busy_source": "committed PMC pass (profiles/r04_pmc.json): "
+                                  "SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), back-to-back launches of this shape",
                                   "traffic": measured_traffic(n_dom, d, b_rows, cfg["dtype"], live=args.live_traffic),
-                                  "traffic_source": "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes" if args.live_traffic else "committed PMC pass of the shipped kernel (profiles/)",
+                                  "traffic_source": "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes" if args.live_traffic else "CONSTANT from the committed PMC pass of the shipped kernel "
+                                  "(profiles/r04_pmc.json), not measured in this run; --live-traffic measures it now",
                                   "algorithmic_bytes": 2 * (2 * b_rows * n_dom * heads * d) * 2,
                                   "avg_us": round(us, 2), "avg_us_method": "kernel-only HIP event timestamps (hipExtLaunchKernelGGL start/stop events) of every launch of this "
                                   "class in an eager pass of the same workload, on the launch stream",

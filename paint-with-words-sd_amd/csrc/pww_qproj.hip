@@ -79,17 +79,24 @@ __device__ __forceinline__ void qp_stat_unit(const char *qp, const char *kp, int
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
     if constexpr (KSC > 0) {
-        V8 qa[KSC], ka[KSC][NKB];
+        // groups of at most 5 slices (80 fragment registers: a head of 160 channels takes two groups) -- the statistic must not be what
+        // sets the kernel's register count (two waves per SIMD for the 128 x 160 tile)
+        constexpr int GRP = KSC <= 5 ? KSC : 5;
+        static_assert(KSC % GRP == 0, "slice groups");
 #pragma unroll
-        for (int i = 0; i < KSC; ++i) {
-            qa[i] = q_frag(ks_lo + i);
+        for (int g0 = 0; g0 < KSC; g0 += GRP) {
+            V8 qa[GRP], ka[GRP][NKB];
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb) ka[i][kb] = *reinterpret_cast<const V8 *>(kp + kb * 32 * ROWB + (ks_lo + i) * 32);
+            for (int i = 0; i < GRP; ++i) {
+                qa[i] = q_frag(ks_lo + g0 + i);
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) ka[i][kb] = *reinterpret_cast<const V8 *>(kp + kb * 32 * ROWB + (ks_lo + g0 + i) * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < GRP; ++i)
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) s[kb] = mfma32(ka[i][kb], qa[i], s[kb]);
         }
-#pragma unroll
-        for (int i = 0; i < KSC; ++i)
-#pragma unroll
-            for (int kb = 0; kb < NKB; ++kb) s[kb] = mfma32(ka[i][kb], qa[i], s[kb]);
     } else {
     V8 qf = q_frag(ks_lo), kf[NKB];
 #pragma unroll
