@@ -1,4 +1,5 @@
 // extern "C" surface of libpww_hip.so (declared in include/pww_hip.h) + error plumbing.
+#include <stdlib.h>
 #include <string.h>
 #include <mutex>
 #include <vector>
@@ -19,6 +20,33 @@ int check_hip(hipError_t e, const char *what) {
     if (e == hipSuccess) return PWW_OK;
     set_error("%s: %s (%s)", what, hipGetErrorString(e), hipGetErrorName(e));
     return PWW_EHIP;
+}
+
+const DebugKnobs &debug_knobs() {
+    static const DebugKnobs knobs = [] {
+        DebugKnobs k;
+        const char *e = getenv("PWW_DEBUG");
+        if (!e) return k;
+        const struct { const char *name; int *value; } table[] = {
+            {"attn_rf", &k.attn_rf}, {"attn_ksplit", &k.attn_ksplit}, {"attn_fold", &k.attn_fold}, {"attn_nw8", &k.attn_nw8},
+            {"attn_pair_major", &k.attn_pair_major}, {"attn_wide_store", &k.attn_wide_store}, {"cross_wg_per_cu", &k.cross_wg_per_cu},
+            {"cross_assume_resident", &k.cross_assume_resident}, {"cross_gate_weight", &k.cross_gate_weight},
+            {"cross_tile_nbuf", &k.cross_tile_nbuf}, {"cross_bias_lds", &k.cross_bias_lds}};
+        const char *p = e;
+        while (*p) {
+            const char *eq = strchr(p, '='), *end = strchr(p, ',');
+            if (!end) end = p + strlen(p);
+            if (eq && eq < end) {
+                bool known = false;
+                for (const auto &t : table)
+                    if (strlen(t.name) == (size_t)(eq - p) && !strncmp(t.name, p, eq - p)) { *t.value = atoi(eq + 1); known = true; }
+                if (!known) fprintf(stderr, "libpww_hip: PWW_DEBUG: unknown knob '%.*s'\n", (int)(eq - p), p);
+            }
+            p = *end ? end + 1 : end;
+        }
+        return k;
+    }();
+    return knobs;
 }
 
 static int query_arch(char *buf, size_t n) {

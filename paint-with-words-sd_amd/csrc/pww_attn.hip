@@ -675,9 +675,9 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
 
 // ---- host dispatch ---------------------------------------------------------------------------
 
-static int rf_mode() {   // PWW_ATTN_RF=0: bf16 self-attention with the running-maximum softmax instead of the range-free one (A/B testing)
+static int rf_mode() {   // PWW_DEBUG=attn_rf=0: bf16 self-attention with the running-maximum softmax instead of the range-free one (A/B testing)
     static int mode = -2;
-    if (mode == -2) { const char *e = getenv("PWW_ATTN_RF"); mode = e ? atoi(e) : 1; }
+    if (mode == -2) { mode = debug_knobs().attn_rf; }
     return mode;
 }
 
@@ -727,15 +727,15 @@ static int launch_attn_ksplit(const AttnParams &p, hipStream_t stream) {
     return check_hip(hipGetLastError(), "attn_fwd_kernel<key-split> launch");
 }
 
-static int ksplit_mode() {   // PWW_ATTN_KSPLIT=0/1 (A/B testing); default on
+static int ksplit_mode() {   // PWW_DEBUG=attn_ksplit=0|1 (A/B testing); default on
     static int mode = -2;
-    if (mode == -2) { const char *e = getenv("PWW_ATTN_KSPLIT"); mode = e ? atoi(e) : 1; }
+    if (mode == -2) { mode = debug_knobs().attn_ksplit; }
     return mode;
 }
 
-static int fold_mode() {   // PWW_ATTN_FOLD (A/B testing only -- accuracy is guarded in the kernel): 0 = never, 1 = bf16 and f16 (default), 2 = bf16 only
+static int fold_mode() {   // PWW_DEBUG=attn_fold=n (A/B testing only -- accuracy is guarded in the kernel): 0 = never, 1 = bf16 and f16 (default), 2 = bf16 only
     static int mode = -2;
-    if (mode == -2) { const char *e = getenv("PWW_ATTN_FOLD"); mode = e ? atoi(e) : 1; }
+    if (mode == -2) { mode = debug_knobs().attn_fold; }
     return mode;
 }
 
@@ -824,20 +824,20 @@ template <typename T> static int dispatch_nw(const AttnParams &p, hipStream_t s)
     if (p.bias) return wide ? dispatch_d<T, 4, true>(p, s) : dispatch_d<T, 2, true>(p, s);
     // 8-wave workgroups (256 query rows per K/V stage) once they still give every CU a workgroup
     static int nw8 = -1;
-    if (nw8 < 0) { const char *e = getenv("PWW_ATTN_NW8"); nw8 = e ? atoi(e) : 1; }
+    if (nw8 < 0) { nw8 = debug_knobs().attn_nw8; }
     if (nw8 && rows32 >= 8 * 256 && p.N >= 256 && p.D <= 64) return dispatch_d<T, 8, false>(p, s);
     return wide ? dispatch_d<T, 4, false>(p, s) : dispatch_d<T, 2, false>(p, s);
 }
 
-static int pair_major_min() {   // PWW_ATTN_PAIR_MAJOR=n: pair-major workgroup order for launches with at least n (image, head) pairs (0 = never; default 16)
+static int pair_major_min() {   // PWW_DEBUG=attn_pair_major=n: pair-major workgroup order for launches with at least n (image, head) pairs (0 = never; default 16)
     static int n = -2;
-    if (n == -2) { const char *e = getenv("PWW_ATTN_PAIR_MAJOR"); n = e ? atoi(e) : 16; if (n <= 0) n = 0x7fffffff; }
+    if (n == -2) { n = debug_knobs().attn_pair_major; if (n <= 0) n = 0x7fffffff; }
     return n;
 }
 
-static int wide_store_mode() {   // PWW_ATTN_WIDE_STORE=0: 8-byte epilogue stores as in round 2 (A/B testing)
+static int wide_store_mode() {   // PWW_DEBUG=attn_wide_store=0: 8-byte epilogue stores as in round 2 (A/B testing)
     static int mode = -2;
-    if (mode == -2) { const char *e = getenv("PWW_ATTN_WIDE_STORE"); mode = e ? atoi(e) : 1; }
+    if (mode == -2) { mode = debug_knobs().attn_wide_store; }
     return mode;
 }
 

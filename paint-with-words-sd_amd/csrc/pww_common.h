@@ -45,6 +45,23 @@ template <typename V8> __device__ __forceinline__ V8 zero8() {
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
 // ---- host side -------------------------------------------------------------------------------
+// A/B knobs of experiments DESIGN.md declares closed (each measured, the default is the winner): ONE environment variable,
+// PWW_DEBUG="name=value,name=value", parsed once per process. Nothing in here changes results beyond rounding; the product never sets it.
+struct DebugKnobs {
+    int attn_rf = 1;               // 0: running-maximum softmax instead of the range-free one
+    int attn_ksplit = 1;           // 0: no key-split workgroups for under-filled launches
+    int attn_fold = 1;             // folded-reference d = 40 kernel: 0 never / 1 bf16 and fp16 / 2 bf16 only
+    int attn_nw8 = 1;              // 0: no 8-wave workgroups
+    int attn_pair_major = 16;      // pair-major workgroup order from this many (image, head) pairs on (0: never)
+    int attn_wide_store = 1;       // 0: 8-byte instead of 16-byte epilogue stores
+    int cross_wg_per_cu = 4;       // upper bound on the resident workgroups per CU the hand-off launch counts on
+    int cross_assume_resident = 0; // TEST HOOK: count on n workgroups per CU whatever the occupancy query says (drives the time-out path)
+    int cross_gate_weight = 2;     // cost of a gated-in image's query block in units of a gated-out one's (1: ignore the hint)
+    int cross_tile_nbuf = 2;       // 1: never double-buffer the bias tile
+    int cross_bias_lds = 2;        // bias rows: 0 per lane from global memory / 1 LDS tile in single-block launches only / 2 LDS tile everywhere
+};
+const DebugKnobs &debug_knobs();
+
 void set_error(const char *fmt, ...);
 int check_hip(hipError_t e, const char *what);
 bool arch_ok();

@@ -726,26 +726,26 @@ static int device_cus() {      // per device (a thread may drive several GPUs)
     return cus;
 }
 
-static int fused_wg_cap() {   // PWW_CROSS_WG_PER_CU: upper bound on the resident workgroups per CU the fused launch counts on (A/B testing)
+static int fused_wg_cap() {   // PWW_DEBUG=cross_wg_per_cu=n: upper bound on the resident workgroups per CU the fused launch counts on (A/B testing)
     static int cap = -1;
-    if (cap < 0) { const char *e = getenv("PWW_CROSS_WG_PER_CU"); cap = e ? atoi(e) : 4; if (cap < 1) cap = 1; }
+    if (cap < 0) { cap = debug_knobs().cross_wg_per_cu; if (cap < 1) cap = 1; }
     return cap;
 }
-static int fused_assume_resident() {   // PWW_CROSS_ASSUME_RESIDENT=n: TEST HOOK -- count on n workgroups per CU whatever the occupancy query says
+static int fused_assume_resident() {   // PWW_DEBUG=cross_assume_resident=n: TEST HOOK -- count on n workgroups per CU whatever the occupancy query says
     static int n = -1;                 // (tests/test_round3_gpu.py drives the hand-off's time-out / error-word path with it)
-    if (n < 0) { const char *e = getenv("PWW_CROSS_ASSUME_RESIDENT"); n = e ? atoi(e) : 0; if (n < 0) n = 0; }
+    if (n < 0) { n = debug_knobs().cross_assume_resident; if (n < 0) n = 0; }
     return n;
 }
 
 static int bias_tile_mode();
-static int gate_balance_weight() {   // PWW_CROSS_GATE_WEIGHT: cost of a gated-in image's query block in units of a gated-out one's (default 2 -- measured best of 2 / 3 / 4; 1 = ignore the hint)
+static int gate_balance_weight() {   // PWW_DEBUG=cross_gate_weight=n: cost of a gated-in image's query block in units of a gated-out one's (default 2 -- measured best of 2 / 3 / 4; 1 = ignore the hint)
     static int w = -1;
-    if (w < 0) { const char *e = getenv("PWW_CROSS_GATE_WEIGHT"); w = e ? atoi(e) : 2; if (w < 1) w = 1; }
+    if (w < 0) { w = debug_knobs().cross_gate_weight; if (w < 1) w = 1; }
     return w;
 }
-static int tile_nbuf_mode() {   // PWW_CROSS_TILE_NBUF=1: never double-buffer the bias tile (A/B testing); default 2: when it costs no residency
+static int tile_nbuf_mode() {   // PWW_DEBUG=cross_tile_nbuf=1: never double-buffer the bias tile (A/B testing); default 2: when it costs no residency
     static int mode = -1;
-    if (mode < 0) { const char *e = getenv("PWW_CROSS_TILE_NBUF"); mode = e ? atoi(e) : 2; if (mode != 1) mode = 2; }
+    if (mode < 0) { mode = debug_knobs().cross_tile_nbuf; if (mode != 1) mode = 2; }
     return mode;
 }
 
@@ -877,12 +877,12 @@ size_t cross_fused_state_bytes(const pww_attn_desc_t *d) {
     return state_sync_bytes(d) + (size_t)d->B * ((d->N + 63) / 64) * d->H * 4 * sizeof(unsigned long long);
 }
 
-// PWW_CROSS_BIAS_LDS (A/B testing): 0 = per-lane global bias loads as in round 2; 1 = LDS tile only in launches with one query block per
+// PWW_DEBUG=cross_bias_lds=n (A/B testing): 0 = per-lane global bias loads as in round 2; 1 = LDS tile only in launches with one query block per
 // workgroup (register-staged), several blocks per workgroup keep the per-lane loads; 2 (default) = LDS tile everywhere (several blocks
 // per workgroup: LDS-direct copies)
 static int bias_tile_mode() {
     static int mode = -2;
-    if (mode == -2) { const char *e = getenv("PWW_CROSS_BIAS_LDS"); mode = e ? atoi(e) : 2; }
+    if (mode == -2) { mode = debug_knobs().cross_bias_lds; }
     return mode;
 }
 
@@ -940,7 +940,7 @@ int cross_attn_fused(const void *q, const void *k, const void *v, void *o, const
     // The LDS tile needs unit key stride (dense form) or the compact form, and it pays when the map is NARROW: measured (MI355X,
     // N = 4096, d = 40) 16 folded rows 73.6 us with a 32-column tile vs 81.8 us with per-lane loads, but 126 us with all 80 columns
     // staged (82 KB of LDS: one workgroup per CU, two slabs fetched without prefetch) -- so a dense map without a column bound of
-    // at most 48 keeps the per-lane loads (wider tiles would cost a resident workgroup per CU). PWW_CROSS_BIAS_LDS=0: per-lane loads (A/B).
+    // at most 48 keeps the per-lane loads (wider tiles would cost a resident workgroup per CU). PWW_DEBUG=cross_bias_lds=0: per-lane loads (A/B).
     const bool tile_ok = compact || (d->bias_stride[3] == 1 && bias_tile_mode() != 0 && bias_cols <= 48);
     int tile_stride = 16;
     while (tile_stride < bias_cols) tile_stride *= 2;

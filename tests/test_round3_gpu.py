@@ -233,7 +233,7 @@ def test_magnitude_guard(gpu_device, dtype, target_max):
 
 def test_fused_handoff_timeout_raises(gpu_device):
     """If the workgroups of a fused cross-attention launch are not all resident (here: forced with the library's test hook
-    PWW_CROSS_ASSUME_RESIDENT -- in the field: another process or stream holding compute units), the hand-off times out after
+    PWW_DEBUG=cross_assume_resident=n -- in the field: another process or stream holding compute units), the hand-off times out after
     1 s, the outputs are NaN and an error word is set. The product reads that
     word once per request (PwWSampler.sample -> ops.check_fused_errors) and raises PwwHipError; the state is re-zeroed so the
     next request is clean. Run in a subprocess: the residency bound is read once per process."""
@@ -259,7 +259,7 @@ except PwwHipError as e:
     print("raised:", str(e)[:60])
 print("state clean:", not m.__dict__["_pww_fused_scratch"].error())
 ''' % (os.path.join(cases.REPO, "paint-with-words-sd_amd"), cases.REPO)
-    env = dict(os.environ, PWW_CROSS_ASSUME_RESIDENT="8")
+    env = dict(os.environ, PWW_DEBUG="cross_assume_resident=8")
     out = subprocess.run(["timeout", "240", sys.executable, "-c", code], capture_output=True, text=True, env=env)
     print(out.stdout[-600:], out.stderr[-600:])
     assert out.returncode == 0, out.stderr[-2000:]
