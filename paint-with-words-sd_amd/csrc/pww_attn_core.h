@@ -302,24 +302,32 @@ __device__ __forceinline__ void bias_ref_tile(BiasRef &b, const char *tile, int 
     b.lds_cols = cols;
 }
 
-template <typename T, int KS, int DT, int HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
+template <typename T, int KS, int DT, int HAS_BIAS, bool MASKED, bool ROWSUM_MFMA, int STEP = 0>
 __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[DT], float &m_run, float &l_run, const char *Vs,
                                                 int key0, int M, int l31, int hi, const BiasRef &bias,
                                                 float coeff, float c1);
 
-template <typename T, int KS, int DT, int HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
+template <typename T, int KS, int DT, int HAS_BIAS, bool MASKED, bool ROWSUM_MFMA, int STEP = 0>
 __device__ __forceinline__ void attn_tile(f32x16 (&oacc)[DT], float &m_run, float &l_run,
                                           const typename Vec<T>::v8 (&qf)[KS], const char *Ks, const char *Vs,
                                           int key0, int M, int l31, int hi, const BiasRef &bias,
                                           float coeff, float c1) {
     f32x16 s[2];
     score_tile<T, KS>(s, qf, Ks, key0, MASKED ? M : 0x7fffffff, l31, hi);
-    attn_tile_sm_pv<T, KS, DT, HAS_BIAS, MASKED, ROWSUM_MFMA>(s, oacc, m_run, l_run, Vs, key0, M, l31, hi, bias, coeff, c1);
+    attn_tile_sm_pv<T, KS, DT, HAS_BIAS, MASKED, ROWSUM_MFMA, STEP>(s, oacc, m_run, l_run, Vs, key0, M, l31, hi, bias, coeff, c1);
 }
+
+// Headroom of the lazy step (STEP 2), in exp2 units: a later tile keeps the row's running reference while no score of it exceeds the
+// reference by more than this -- P <= 2^8 is exact in f16 and bf16 alike, and O^T / the row sum accumulate in fp32.
+constexpr float LAZY_HEADROOM = 8.f;
 
 // scores (already in `s`) -> (bias) -> online softmax -> PV against the V tile at Vs
 // HAS_BIAS: 0 none, 1 bias rows read from global memory (per-lane buffer loads), 2 bias rows read from the LDS tile
-template <typename T, int KS, int DT, int HAS_BIAS, bool MASKED, bool ROWSUM_MFMA>
+// STEP: 0 the general online step; 1 the FIRST tile of a row (m_run = -inf, l_run = 0, O^T = 0 on entry: nothing to rescale, and the
+//       first MFMA of every channel tile starts from a zero constant -- the caller need not clear O^T); 2 a LATER tile with a lazy
+//       reference: the running maximum is only raised (and O^T rescaled) when some row of the wave would otherwise produce a P above
+//       2^LAZY_HEADROOM -- any reference gives the same softmax, it only has to keep P inside the storage type's range.
+template <typename T, int KS, int DT, int HAS_BIAS, bool MASKED, bool ROWSUM_MFMA, int STEP>
 __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[DT], float &m_run, float &l_run, const char *Vs,
                                                 int key0, int M, int l31, int hi, const BiasRef &bias,
                                                 float coeff, float c1) {
@@ -394,6 +402,10 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
             }
         }
     } else {
+    unsigned key_stride = HAS_BIAS ? bias.key_stride : 0u;
+    // (opaque to the optimiser: otherwise the 32 products key * stride of this rarely taken form are hoisted out of the caller's block
+    // loop and live -- or spill -- across the hot forms)
+    if (HAS_BIAS) asm volatile("" : "+s"(key_stride));
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
         if (kb == 0 ? live0 : live1) {
@@ -402,7 +414,7 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
             const int key = key0 + key_of(kb, r, hi);
             float x = s[kb][r];
             if (HAS_BIAS) {   // keys >= M of a ragged tile read a neighbouring (in-range) value; they are masked below
-                const unsigned off = bias.row_off + (unsigned)key * bias.key_stride;
+                const unsigned off = bias.row_off + (unsigned)key * key_stride;
                 const float bv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bias.srd, off, 0, 0));
                 x = fmaf(bv, coeff, x);
             }
@@ -414,15 +426,24 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
     }
     }
     tmax = xhalf_max(tmax);
-    const float m_new = fmaxf(m_run, tmax);   // finite: key0 < M, so at least one key of the tile is live
-    if (!__all(m_new == m_run)) {             // exact skip: alpha == 1 for every row of the wave
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c1);
-        if (!ROWSUM_MFMA) l_run *= alpha;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+    float m_new;
+    if (STEP == 1) {
+        m_new = tmax;                         // finite: key 0 of the row is live
         m_run = m_new;
+    } else {
+        m_new = fmaxf(m_run, tmax);           // finite: key0 < M, so at least one key of the tile is live
+        const bool keep = STEP == 2 ? __all((tmax - m_run) * c1 <= LAZY_HEADROOM) : __all(m_new == m_run);
+        if (!keep) {                          // (STEP 0: an exact skip -- alpha == 1 for every row of the wave)
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c1);
+            if (!ROWSUM_MFMA) l_run *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            m_run = m_new;
+        } else if (STEP == 2) {
+            m_new = m_run;
+        }
     }
     const float mc = -m_new * c1;
     float psum = 0.f;
@@ -438,7 +459,7 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
             }
         }
     }
-    if (!ROWSUM_MFMA) l_run += psum;
+    if (!ROWSUM_MFMA) l_run = STEP == 1 ? psum : l_run + psum;
 
     // O^T[d][row] += V^T[d][key] * P^T[key][row]   (V^T fragments come out of the transpose read)
 #pragma unroll
@@ -449,7 +470,14 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     const V8 vf = load_vfrag<T, DT>(vl, kb, k2, dt);
-                    oacc[dt] = mfma32(vf, pf[kb][k2], oacc[dt]);
+                    if (STEP == 1 && kb == 0 && k2 == 0) {      // (block 0 of the first tile is always live)
+                        f32x16 zero;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+                        oacc[dt] = mfma32(vf, pf[kb][k2], zero);
+                    } else {
+                        oacc[dt] = mfma32(vf, pf[kb][k2], oacc[dt]);
+                    }
                 }
             }
         }

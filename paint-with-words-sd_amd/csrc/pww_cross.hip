@@ -216,6 +216,9 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     typedef KTile<KS> KT;
     typedef VTile<DT> VT;
     constexpr int NSUB = 2;
+    // the head dim (in (16 (KS - 1), 16 KS], a multiple of 8) leaves padding channels in the V tile (d = 40 -> 64, 80 -> 96): channel D is
+    // a column of ones and the row sums come out of the PV MFMAs (no per-score adds; the sum of the ROUNDED P, as in pww_attn.hip)
+    constexpr bool RSM = KS * 16 < DT * 32;
     constexpr int NT = NW * 64;
     constexpr int SUB_BYTES = KT::BYTES + VT::BYTES;
     constexpr int STAGE_BYTES = NSUB * SUB_BYTES;
@@ -336,6 +339,11 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
         tl_stamp(p, 6);
         __syncthreads();                      // the zero fill is complete
         stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
+        if (RSM) {      // column D of every V row is one: the PV MFMA accumulates the softmax denominator in row D of O^T
+            const T one = (T)1.0f;
+            for (int i = tid; i < NSUB * KVBLK; i += NT)
+                *reinterpret_cast<T *>(smem + (i >> 6) * SUB_BYTES + KT::BYTES + (i & 63) * VT::STRIDE + p.D * 2) = one;
+        }
         if (SINGLE && use_tile) tile_park<NT>(treg, use_compact, tile, cp.tile_stride, cidx, bias.srd, (long)chunk * NW * 32, p.N, p.b_sn, cp.R, p.bias_cols, tid);
     }
     __syncthreads();
@@ -622,11 +630,10 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
             if (biased && use_compact) tile_request<NT>(treg, true, cbase, bias.srd, (long)qb * NW * 32, p.N, cp.c_sn, p.b_sn, cp.R, p.bias_cols, tid);
         }
         if (biased && !use_tile) bias.row_off = qvalid ? (unsigned)((long)qrow * p.b_sn * 4) : OOB_OFF;
+        // one key stage (M <= 128): the FIRST 64-key tile sets the row's reference, starts O^T from a zero constant and has nothing to
+        // rescale (STEP 1); the second one (13 live keys of the 77 prompt tokens) keeps that reference unless a score of it exceeds it by
+        // 2^8 (STEP 2: with 32 rows per wave the exact online step rescaled O^T in 997 of 1000 waves, for a handful of keys)
         f32x16 oacc[DT];
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;
         if (biased && use_tile) {
             f32x16 s0[2];
@@ -642,23 +649,30 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
                 if (use_glds) bias_ref_tile(bias, cur_tile, wave * 32 + l31, cp.tile_stride, p.bias_cols, hi);
             }
             // (with the 77 prompt tokens the first 64 keys are all live: no per-score key compare there)
-            if (p.M >= KVBLK) attn_tile_sm_pv<T, KS, DT, 2, false, false>(s0, oacc, m_run, l_run, smem + KT::BYTES, 0, p.M, l31, hi, bias, coeff, c1);
-            else attn_tile_sm_pv<T, KS, DT, 2, true, false>(s0, oacc, m_run, l_run, smem + KT::BYTES, 0, p.M, l31, hi, bias, coeff, c1);
+            if (p.M >= KVBLK) attn_tile_sm_pv<T, KS, DT, 2, false, RSM, 1>(s0, oacc, m_run, l_run, smem + KT::BYTES, 0, p.M, l31, hi, bias, coeff, c1);
+            else attn_tile_sm_pv<T, KS, DT, 2, true, RSM, 1>(s0, oacc, m_run, l_run, smem + KT::BYTES, 0, p.M, l31, hi, bias, coeff, c1);
             if (KVBLK < p.M)
-                attn_tile<T, KS, DT, 2, true, false>(oacc, m_run, l_run, qf, smem + SUB_BYTES, smem + SUB_BYTES + KT::BYTES, KVBLK, p.M, l31, hi, bias, coeff, c1);
+                attn_tile<T, KS, DT, 2, true, RSM, 2>(oacc, m_run, l_run, qf, smem + SUB_BYTES, smem + SUB_BYTES + KT::BYTES, KVBLK, p.M, l31, hi, bias, coeff, c1);
         } else {
+            static_assert(NSUB == 2, "one key stage of two 64-key tiles");
+            const char *Ks1 = smem + SUB_BYTES;
+            if (biased) {
+                // bias rows read per lane from global memory (maps wider than the LDS tile, or a strided key axis): the fall-back form, kept
+                // on the general online step in ONE instantiation (a second one makes hipcc hoist 32 strided offsets into scratch)
 #pragma unroll
-            for (int sub = 0; sub < NSUB; ++sub) {
-                const int key0 = sub * KVBLK;
-                if (key0 < p.M) {
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+#pragma unroll
+                for (int sub = 0; sub < NSUB; ++sub) {
                     const char *Ks = smem + sub * SUB_BYTES;
-                    if (biased)
-                        attn_tile<T, KS, DT, 1, true, false>(oacc, m_run, l_run, qf, Ks, Ks + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
-                    else if (key0 + KVBLK <= p.M)      // a full 64-key tile (the first one of the 77 prompt tokens): no key compares
-                        attn_tile<T, KS, DT, 0, false, false>(oacc, m_run, l_run, qf, Ks, Ks + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
-                    else
-                        attn_tile<T, KS, DT, 0, true, false>(oacc, m_run, l_run, qf, Ks, Ks + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
+                    if (sub * KVBLK < p.M) attn_tile<T, KS, DT, 1, true, RSM>(oacc, m_run, l_run, qf, Ks, Ks + KT::BYTES, sub * KVBLK, p.M, l31, hi, bias, coeff, c1);
                 }
+            } else {
+                // (a full first tile -- the 77 prompt tokens -- needs no key compares)
+                if (KVBLK <= p.M) attn_tile<T, KS, DT, 0, false, RSM, 1>(oacc, m_run, l_run, qf, smem, smem + KT::BYTES, 0, p.M, l31, hi, bias, coeff, c1);
+                else attn_tile<T, KS, DT, 0, true, RSM, 1>(oacc, m_run, l_run, qf, smem, smem + KT::BYTES, 0, p.M, l31, hi, bias, coeff, c1);
+                if (KVBLK < p.M) attn_tile<T, KS, DT, 0, true, RSM, 2>(oacc, m_run, l_run, qf, Ks1, Ks1 + KT::BYTES, KVBLK, p.M, l31, hi, bias, coeff, c1);
             }
         }
         if constexpr (!SINGLE) {
@@ -668,7 +682,20 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
         }
-        const float l_tot = l_run + __shfl_xor(l_run, 32);
+        float l_tot;
+        if (RSM) {      // row D of O^T: tile D / 32, register (D % 32) / 2 (D is a multiple of 8 below 32 DT), held by the hi == 0 half
+            const int rl = p.D & 31, tl = p.D >> 5;
+            float lv = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const float c = rl == 0 ? oacc[dt][0] : rl == 8 ? oacc[dt][4] : rl == 16 ? oacc[dt][8] : oacc[dt][12];
+                lv = dt == tl ? c : lv;
+            }
+            const float other = __shfl_xor(lv, 32);
+            l_tot = hi ? other : lv;
+        } else {
+            l_tot = l_run + __shfl_xor(l_run, 32);
+        }
         const float inv = 1.f / l_tot;
         store_o_block<T, DT>(Op + (long)(qvalid ? qrow : 0) * p.o_sn, oacc, inv, p.D, hi, qvalid, p.o_wide != 0);
     }

@@ -219,14 +219,21 @@ static void run_case(const Case &c, bool timing) {
                 HIPCHECK(hipMemcpy(h2.data(), o2, h2.size() * 2, hipMemcpyDeviceToHost));
                 HIPCHECK(hipMemcpy(fs.data(), fstats, fs.size() * 8, hipMemcpyDeviceToHost));
                 HIPCHECK(hipMemcpy(hs.data(), dsync, sync_bytes, hipMemcpyDeviceToHost));
-                long diff = 0, sdiff = 0, dirty = 0;
-                for (size_t i = 0; i < h1.size(); ++i) diff += h1[i] != h2[i];
+                // statistics: bit for bit. Outputs: the single-stage kernel computes a row with a one-shot softmax (round 4), the general
+                // kernel with two online tiles -- same mathematics, other roundings: within two units of the storage type's last place
+                long diff = 0, sdiff = 0, dirty = 0; double dmax = 0, omax = 0;
+                for (size_t i = 0; i < h1.size(); ++i) {
+                    diff += h1[i] != h2[i];
+                    const double a = from_t(h1[i], c.dtype), bq = from_t(h2[i], c.dtype);
+                    dmax = std::max(dmax, fabs(a - bq)); omax = std::max(omax, fabs(a));
+                    if (!(bq == bq)) dmax = 1e30;
+                }
                 if (kind != PWW_STAT_NONE)
                     for (int b = 0; b < B; ++b) if (gate[b] != 0.f) for (int j = 0; j < 4; ++j) sdiff += memcmp(&fs[4 * b + j], &stats[4 * b + j], 8) != 0;
                 for (unsigned w : hs) dirty += w != 0;
-                const bool ok = r1 == 0 && r2 == 0 && diff == 0 && sdiff == 0 && dirty == 0;
-                printf("%s %-28s fused kind=%d gate-variant=%d: %ld differing outputs, %ld differing statistics, %ld dirty state words (rc %d %d%s%s)\n",
-                       ok ? "PASS" : "FAIL", c.name, kind, variant, diff, sdiff, dirty, r1, r2, r2 ? " " : "", r2 ? pww_last_error() : "");
+                const bool ok = r1 == 0 && r2 == 0 && dmax <= (c.dtype == PWW_DTYPE_F16 ? 1.0 / 512 : 1.0 / 64) * omax && sdiff == 0 && dirty == 0;
+                printf("%s %-28s fused kind=%d gate-variant=%d: max output diff %.2e of max|O| %.2f (%ld elements differ), %ld differing statistics, %ld dirty state words (rc %d %d%s%s)\n",
+                       ok ? "PASS" : "FAIL", c.name, kind, variant, dmax, omax, diff, sdiff, dirty, r1, r2, r2 ? " " : "", r2 ? pww_last_error() : "");
                 if (!ok) g_fail++;
             }
         }
@@ -264,16 +271,23 @@ static void run_case(const Case &c, bool timing) {
                 std::vector<uint16_t> ha(q.size()), hb(q.size()); std::vector<unsigned> hs(sync_bytes / 4);
                 HIPCHECK(hipMemcpy(ha.data(), o2, ha.size() * 2, hipMemcpyDeviceToHost)); HIPCHECK(hipMemcpy(hb.data(), o1, hb.size() * 2, hipMemcpyDeviceToHost));
                 HIPCHECK(hipMemcpy(hs.data(), dsync, sync_bytes, hipMemcpyDeviceToHost));
-                long diff = 0, dirty = 0; for (size_t i = 0; i < ha.size(); ++i) diff += ha[i] != hb[i];
+                long diff = 0, dirty = 0; double dmax = 0, omax = 0;
+                for (size_t i = 0; i < ha.size(); ++i) {
+                    diff += ha[i] != hb[i];
+                    const double a = from_t(ha[i], c.dtype), bq = from_t(hb[i], c.dtype);
+                    dmax = std::max(dmax, fabs(a - bq)); omax = std::max(omax, fabs(a));
+                    if (!(bq == bq)) dmax = 1e30;
+                }
                 for (unsigned w : hs) dirty += w != 0;
-                const bool ok = ra == 0 && rb == 0 && diff == 0 && dirty == 0;
-                printf("%s %-28s fused kind=%d without stats_out (running extremes): %ld differing outputs vs two launches, %ld dirty state words (rc %d %d)\n", ok ? "PASS" : "FAIL", c.name, kind, diff, dirty, ra, rb);
+                const bool ok = ra == 0 && rb == 0 && dmax <= (c.dtype == PWW_DTYPE_F16 ? 1.0 / 512 : 1.0 / 64) * omax && dirty == 0;
+                printf("%s %-28s fused kind=%d without stats_out (running extremes): max output diff %.2e of max|O| %.2f vs two launches (%ld elements differ), %ld dirty state words (rc %d %d)\n", ok ? "PASS" : "FAIL", c.name, kind, dmax, omax, diff, dirty, ra, rb);
                 if (!ok) g_fail++;
             }
             HIPCHECK(hipMemset(o1, 0xff, q.size() * 2));
             r1 = pww_cross_attn_fwd_fused(dq, dk, dv, o1, dbias, PWW_STAT_MAX, s0, dgate, &d, nullptr, dsync, sync_bytes, fws, fws_bytes, nullptr);
             HIPCHECK(hipDeviceSynchronize());
             HIPCHECK(hipMemcpy(h1.data(), o1, h1.size() * 2, hipMemcpyDeviceToHost));
+            std::vector<uint16_t> htile;
             for (int variant = 0; variant < 8; ++variant) {
                 pww_cross_opts_t op; memset(&op, 0, sizeof(op)); op.size = sizeof(op);
                 const float *use_bias = dbias;
@@ -293,9 +307,24 @@ static void run_case(const Case &c, bool timing) {
                 HIPCHECK(hipDeviceSynchronize());
                 if (r2 == PWW_ENOTSUP && !use_bias) { printf("SKIP %-28s fused_ex %s: not resident without the dense map (%s)\n", c.name, what, pww_last_error()); continue; }
                 HIPCHECK(hipMemcpy(h2.data(), o2, h2.size() * 2, hipMemcpyDeviceToHost));
-                long diff = 0; for (size_t i = 0; i < h1.size(); ++i) diff += h1[i] != h2[i];
-                const bool ok = r1 == 0 && r2 == 0 && diff == 0;
-                printf("%s %-28s fused_ex [%s]: %ld differing outputs vs the plain fused call (rc %d %d%s%s)\n", ok ? "PASS" : "FAIL", c.name, what, diff, r1, r2, r2 ? " " : "", r2 ? pww_last_error() : "");
+                // Forms that stage the bias rows in LDS (bias_cols / compact) run the first / lazy softmax steps, the plain call reads its
+                // bias per lane and runs the general online step: bit-identical AMONG the staged forms, equal to the last bit or two of
+                // the storage type ACROSS the two families (the same mathematics with another rounding order).
+                const bool staged = op.bias_compact || (op.bias_cols && op.bias_cols <= 48);      // (pww_cross.hip: dense rows are staged up to 48 columns)
+                long diff = 0, tdiff = 0; double dmax = 0, omax = 0;
+                for (size_t i = 0; i < h1.size(); ++i) {
+                    diff += h1[i] != h2[i];
+                    const double a = from_t(h1[i], c.dtype), bq = from_t(h2[i], c.dtype);
+                    dmax = std::max(dmax, fabs(a - bq)); omax = std::max(omax, fabs(a));
+                    if (!(bq == bq)) dmax = 1e30;
+                }
+                if (staged) {
+                    if (htile.empty()) htile = h2;
+                    else for (size_t i = 0; i < h2.size(); ++i) tdiff += htile[i] != h2[i];
+                }
+                const bool ok = r1 == 0 && r2 == 0 && (staged ? tdiff == 0 && dmax <= (c.dtype == PWW_DTYPE_F16 ? 1.0 / 512 : 1.0 / 64) * omax : diff == 0);
+                printf("%s %-28s fused_ex [%s]: %ld differing outputs vs the plain fused call (max diff %.2e of max|O| %.2f), %ld vs the first staged form (rc %d %d%s%s)\n",
+                       ok ? "PASS" : "FAIL", c.name, what, diff, dmax, omax, tdiff, r1, r2, r2 ? " " : "", r2 ? pww_last_error() : "");
                 if (!ok) g_fail++;
             }
             // pww_cross_attn_fwd_stat_ex with the device word == pww_cross_attn_fwd_stat with the value
