@@ -499,6 +499,7 @@ def main():
                     help="memory format of the UNet (a stock PyTorch setting: MIOpen's bf16/fp16 convolutions are NHWC kernels, NCHW pays a "
                          "transpose either side). auto = channels_last for the SD1.5 topologies (measured +4.6 %% at batch 1, +1..3 %% at "
                          "batch 8), NCHW for SD2.1 at 768x768 (channels_last measured -6 %% there)")
+    ap.add_argument("--no-fused-norm", action="store_true", help="A/B: the UNet blocks' GroupNorm (+ addend, + SiLU) as stock PyTorch ops instead of pww_group_norm_fwd")
     ap.add_argument("--tiny", action="store_true", help="1/8-width stand-in of the workload's topology (tests of the launcher / sharding plumbing on a GPU; the line says so)")
     ap.add_argument("--dump-latents", default=None, metavar="PREFIX", help="save this rank's final latents of the last timed step to PREFIX_rank<r>.npy")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: spawn / rendezvous (gloo) / broadcast a 1/8-width model and the request, print the line with value null")
@@ -536,6 +537,8 @@ def main():
         pww_hip.enable_miopen_find()      # MIOpen find mode for the UNet's stock convolutions (PWW_MIOPEN_FIND=0: PyTorch's default)
         pww_hip.load_library()
     pw_api.DEFAULT_MODE = args.mode
+    if args.no_fused_norm:
+        pww_hip.blocks.FUSED_NORM = False
 
     log("cpu_count", os.cpu_count(), "torch threads", torch.get_num_threads(), "rank", rank, "world", world, "config", args.config)
     tools, build_info = build_tools(device, dtype, cfg["scheduler"], cfg["model"], tiny=not on_gpu or args.tiny)
@@ -577,6 +580,7 @@ def main():
                    "baseline_config": args.config, "mode": args.mode, "images_per_step": n_global,
                    "stock_op_settings": "MIOpen find mode%s" % (", UNet in channels_last memory format" if channels_last else ""),
                    "parallelism": "image-sharded x%d, no data-path collective" % world, "backend": pdist.backend_name(),
+                   "block_norms": "pww_group_norm_fwd (GroupNorm + time-embedding addend + SiLU of the ResnetBlock2D / Transformer2DModel blocks)" if pww_hip.blocks.FUSED_NORM else "stock PyTorch ops",
                    "weight_broadcast": build_info, "weight_broadcast_s": build_info.get("weight_broadcast_s"), "request_broadcast_s": round(req_bcast_s, 4)},
     }
     if args.config != 2 or cfg["denoise_steps"] != 30:     # (an overridden step count must not carry the headline's "30 steps" label)

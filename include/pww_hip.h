@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define PWW_VERSION 122 /* 0.1.22: pww_qproj_stat / pww_qproj_parts / pww_cross_attn_fwd_parts (score statistic formed in the to_q GEMM's epilogue), pww_mask_build_f32_levels, PWW_STAT_ALL; 0.1.21: pww_cross_opts_t.gated_images (was padding); 0.1.20: + pww_cross_attn_fwd_fused_ex / pww_cross_attn_fwd_stat_ex (pww_cross_opts_t: device-side coefficient word, bias column bound,
+#define PWW_VERSION 123 /* 0.1.23: pww_group_norm_fwd / pww_group_norm_workspace_bytes (GroupNorm + addend + SiLU of the blocks that call the attention path); 0.1.22: pww_qproj_stat / pww_qproj_parts / pww_cross_attn_fwd_parts (score statistic formed in the to_q GEMM's epilogue), pww_mask_build_f32_levels, PWW_STAT_ALL; 0.1.21: pww_cross_opts_t.gated_images (was padding); 0.1.20: + pww_cross_attn_fwd_fused_ex / pww_cross_attn_fwd_stat_ex (pww_cross_opts_t: device-side coefficient word, bias column bound,
                            compact bias), pww_debug_timeline (0.1.11: pww_profile_*; 0.1.10: fused cross-attention, blur, resize, inpaint prep) */
 
 #define PWW_OK 0
@@ -250,6 +250,41 @@ int32_t pww_qproj_parts(const pww_qproj_desc_t *desc);
 int pww_cross_attn_fwd_parts(const void *q, const void *k, const void *v, void *o, const float *bias, int32_t stat_kind,
                              float coeff_scalar, const float *gate, const pww_attn_desc_t *desc, const double *partials,
                              int32_t nparts, double *stats_out, const pww_cross_opts_t *opts, void *stream);
+
+/*
+ * GroupNorm of the UNet blocks that call the attention path, fused with the elementwise neighbours those callers put around it
+ * (diffusers==0.10.0 -- requirements.txt:1 of the reference, source not under the reference tree --
+ * ResnetBlock2D.forward `conv1(silu(norm1(x)))`, `h + time_emb_proj(silu(temb))[:, :, None, None]` -> `conv2(silu(norm2(h)))`, and
+ * Transformer2DModel.forward `norm(hidden_states)` in front of proj_in and the patched CrossAttention modules):
+ *   y[b, c, p] = act( (h - mean[b, g]) * rstd[b, g] * gamma[c] + beta[c] ),   h = x[b, c, p] + add_bc[b, c],   g = c / (C / G),
+ *   mean / rstd over the C / G channels x HW positions of the group (biased variance, rstd = 1 / sqrt(var + eps)), act = identity | SiLU.
+ * Rounding points are those of the stock sequence on tensors of the storage type: h is rounded to it before it is normalised, the normalised
+ * value before the activation. Statistics accumulate in fp64.
+ *   x, y      [B, C, H, W] of `dtype` in memory format `layout`: PWW_LAYOUT_NCHW (contiguous) or PWW_LAYOUT_NHWC (torch.channels_last:
+ *             element (b, c, p) at (b * HW + p) * C + c); y has x's layout; x == y is allowed (in place)
+ *   add_bc    [B, C] of `dtype`, contiguous, or NULL
+ *   gamma, beta   [C] of `dtype`, or NULL (1 / 0)
+ *   workspace caller-owned, at least pww_group_norm_workspace_bytes(desc) bytes, 16-byte aligned. Its first 4096 bytes are arrival
+ *             counters: ZERO before the first use, left at zero by every launch (so one buffer, zeroed once, serves every norm of a
+ *             stream and hipGraph replays need no memset node); the rest is scratch.
+ * Two launches on `stream` (moments, apply). Requirements: C % G == 0, C % 8 == 0, HW % 8 == 0, B * G <= 1024, C <= 4096 for NHWC;
+ * PWW_ENOTSUP otherwise.
+ */
+#define PWW_LAYOUT_NCHW 0
+#define PWW_LAYOUT_NHWC 1
+#define PWW_ACT_NONE 0
+#define PWW_ACT_SILU 1
+typedef struct pww_gn_desc {
+    int32_t dtype;        /* PWW_DTYPE_* */
+    int32_t layout;       /* PWW_LAYOUT_* */
+    int32_t B, C, HW, G;
+    float eps;
+    int32_t act;          /* PWW_ACT_* */
+} pww_gn_desc_t;
+
+size_t pww_group_norm_workspace_bytes(const pww_gn_desc_t *desc);
+int pww_group_norm_fwd(const void *x, const void *add_bc, const void *gamma, const void *beta, void *y, const pww_gn_desc_t *desc,
+                       void *workspace, size_t workspace_bytes, void *stream);
 
 /*
  * Per-image global statistics of the raw score tensor S = Q K^T over all heads, rows and keys

@@ -181,6 +181,9 @@ int inpaint_prep(const uint8_t *rgb, const uint8_t *mask, int H, int W, int h, i
                  float *mask_lat, hipStream_t stream);
 int cfg_combine(const void *cond, const void *uncond, float g, float *out, long n, int dtype, hipStream_t stream);
 int store_f32(float *dst, const float *values, int n, hipStream_t stream);
+size_t group_norm_workspace_bytes(const pww_gn_desc_t *d);
+int group_norm_fwd(const void *x, const void *add_bc, const void *gamma, const void *beta, void *y, const pww_gn_desc_t *d, void *workspace,
+                   size_t workspace_bytes, hipStream_t stream);
 
 }  // namespace pww
 
@@ -318,5 +321,11 @@ int pww_cfg_combine(const void *cond, const void *uncond, float guidance, float 
 int pww_store_f32(float *dst, const float *values, int32_t n, void *stream) { return pww::store_f32(dst, values, n, static_cast<hipStream_t>(stream)); }
 
 size_t pww_workspace_bytes(const pww_attn_desc_t *desc) { return pww::qk_reduce_workspace_bytes(desc); }
+
+size_t pww_group_norm_workspace_bytes(const pww_gn_desc_t *desc) { return pww::group_norm_workspace_bytes(desc); }
+int pww_group_norm_fwd(const void *x, const void *add_bc, const void *gamma, const void *beta, void *y, const pww_gn_desc_t *desc,
+                       void *workspace, size_t workspace_bytes, void *stream) {
+    return pww::group_norm_fwd(x, add_bc, gamma, beta, y, desc, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
 
 }  // extern "C"

@@ -173,7 +173,6 @@ __global__ void __launch_bounds__(256, 1) qproj_stat_kernel(const QprojParams p)
     constexpr int WSL = TN / 32, XSL = TW;            // 32-row slabs per plane (one slab = one 16-byte piece per thread)
     constexpr int WPT = KW * WSL, XPT = KW * XSL;     // pieces per thread and chunk
     constexpr int STAGE_BYTES = KW * PLANE;
-    constexpr int WORK_A = STAGE_BYTES > NRED * RED_BYTES ? STAGE_BYTES : NRED * RED_BYTES;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [K tile: whole 32-key blocks][work: staged chunk / reduction buffers / Q tile]
     const int kt_rows = ((p.M + 31) >> 5) << 5;       // whole 32-key blocks: the rows past M are zero-filled (scores of exactly 0)

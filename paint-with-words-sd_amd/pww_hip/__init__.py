@@ -3,6 +3,7 @@ attention path). `import pww_hip` never touches the GPU; the shared library is l
 and a missing library raises PwwHipError (no fallback)."""
 from ._lib import PwwHipError, load as load_library, device_arch, LIB_PATH, EXPORTS
 from . import ops
+from . import blocks
 from .attention import QKProxy, ScaledW, inj_forward, install, uninstall, PwWAttnProcessor, pww_attention
 
 

@@ -11,6 +11,8 @@ LIB_PATH = os.environ.get("PWW_HIP_LIB", os.path.join(_HERE, "libpww_hip.so"))
 
 PWW_OK, PWW_EINVAL, PWW_ENOTSUP, PWW_EHIP = 0, -22, -95, -5
 DTYPE_F16, DTYPE_BF16 = 0, 1
+LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
+ACT_NONE, ACT_SILU = 0, 1
 MAX_HEAD_DIM = 160
 
 # every symbol include/pww_hip.h declares (tests check the library exports all of them)
@@ -19,7 +21,8 @@ EXPORTS = ("pww_version", "pww_last_error", "pww_device_arch", "pww_self_attn_fw
            "pww_cross_fused_workspace_bytes", "pww_cross_fused_state_bytes",
            "pww_qk_reduce", "pww_mask_build", "pww_mask_build_rgb", "pww_mask_build_f32", "pww_resize_tokens", "pww_gauss_blur", "pww_inpaint_prep", "pww_cfg_combine", "pww_store_f32",
            "pww_workspace_bytes", "pww_profile_arm", "pww_profile_elapsed_us", "pww_profile_reset", "pww_debug_timeline",
-           "pww_qproj_stat", "pww_qproj_parts", "pww_cross_attn_fwd_parts", "pww_mask_build_f32_levels")
+           "pww_qproj_stat", "pww_qproj_parts", "pww_cross_attn_fwd_parts", "pww_mask_build_f32_levels",
+           "pww_group_norm_fwd", "pww_group_norm_workspace_bytes")
 
 
 class AttnDesc(ctypes.Structure):
@@ -43,6 +46,12 @@ class QprojDesc(ctypes.Structure):
     _fields_ = [("dtype", ctypes.c_int32), ("B", ctypes.c_int32), ("N", ctypes.c_int32), ("Cin", ctypes.c_int32), ("H", ctypes.c_int32),
                 ("D", ctypes.c_int32), ("M", ctypes.c_int32), ("x_stride", ctypes.c_int64 * 2), ("q_stride", ctypes.c_int64 * 2),
                 ("k_stride", ctypes.c_int64 * 2)]
+
+
+class GnDesc(ctypes.Structure):
+    """struct pww_gn_desc (GroupNorm + addend + activation)."""
+    _fields_ = [("dtype", ctypes.c_int32), ("layout", ctypes.c_int32), ("B", ctypes.c_int32), ("C", ctypes.c_int32), ("HW", ctypes.c_int32),
+                ("G", ctypes.c_int32), ("eps", ctypes.c_float), ("act", ctypes.c_int32)]
 
 
 class Region(ctypes.Structure):
@@ -89,6 +98,10 @@ def load():
     lib.pww_cross_attn_fwd_parts.restype = ctypes.c_int
     lib.pww_mask_build_f32_levels.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.pww_mask_build_f32_levels.restype = ctypes.c_int
+    lib.pww_group_norm_workspace_bytes.argtypes = [ctypes.POINTER(GnDesc)]
+    lib.pww_group_norm_workspace_bytes.restype = ctypes.c_size_t
+    lib.pww_group_norm_fwd.argtypes = [vp, vp, vp, vp, vp, ctypes.POINTER(GnDesc), vp, ctypes.c_size_t, vp]
+    lib.pww_group_norm_fwd.restype = ctypes.c_int
     lib.pww_debug_timeline.argtypes = [vp, ctypes.c_size_t]
     lib.pww_debug_timeline.restype = None
     lib.pww_cross_fused_workspace_bytes.argtypes = [ctypes.POINTER(AttnDesc)]
@@ -117,8 +130,8 @@ def load():
                  "pww_cross_attn_fwd_stat_ex", "pww_cross_attn_fwd_fused_ex", "pww_qk_reduce", "pww_mask_build",
                  "pww_mask_build_rgb", "pww_mask_build_f32", "pww_resize_tokens", "pww_gauss_blur", "pww_inpaint_prep", "pww_cfg_combine"):
         getattr(lib, name).restype = ctypes.c_int
-    if lib.pww_version() // 100 != 1 or lib.pww_version() < 122:
-        raise PwwHipError("libpww_hip ABI version %d is not 1.x >= 1.22 (rebuild: python paint-with-words-sd_amd/build.py)" % lib.pww_version())
+    if lib.pww_version() // 100 != 1 or lib.pww_version() < 123:
+        raise PwwHipError("libpww_hip ABI version %d is not 1.x >= 1.23 (rebuild: python paint-with-words-sd_amd/build.py)" % lib.pww_version())
     _lib = lib
     return lib
 

@@ -725,10 +725,15 @@ def install(unet):
         if module.__class__.__name__ == "CrossAttention":
             module.__class__.__call__ = inj_forward
             n += 1
+    # the blocks around the attention path (row a17): GroupNorm (+ time-embedding addend, + SiLU) on the HIP kernels, per instance
+    from . import blocks
+    blocks.install_blocks(unet)
     return n
 
 
 def uninstall(unet):
+    from . import blocks
+    blocks.uninstall_blocks(unet)
     for module in unet.modules():
         cls = module.__class__
         if cls.__name__ == "CrossAttention" and cls.__dict__.get("__call__") is inj_forward:

@@ -1,0 +1,116 @@
+"""The blocks that CALL the attention path (diffusers==0.10.0 ``ResnetBlock2D`` / ``Transformer2DModel`` /
+``UNet2DConditionModel.conv_norm_out``), with their GroupNorm (+ time-embedding addend, + SiLU) on the HIP kernels of ``csrc/pww_norm.hip``.
+
+Installed per INSTANCE (``module.forward = ...``; ``nn.Module.__call__`` and its hooks stay), by class NAME like the reference's own plug
+(paint_with_words.py:193-195 selects ``__class__.__name__ == "CrossAttention"``):
+
+* ``ResnetBlock2D`` -- the 0.10.0 forward restated with the two ``norm -> nonlinearity`` pairs and the ``+ temb`` in front of ``norm2`` as ONE op
+  each::
+
+      h = conv1(silu(norm1(x)));  h = h + time_emb_proj(silu(temb))[:, :, None, None];  h = conv2(dropout(silu(norm2(h))));
+      return (conv_shortcut(x) + h) / output_scale_factor
+
+  Blocks this restatement does not cover (``upsample`` / ``downsample`` inside the block, ``time_embedding_norm != "default"``, a nonlinearity
+  other than SiLU) keep their own forward.
+* every other ``nn.GroupNorm`` of the model (``Transformer2DModel.norm``, ``conv_norm_out``) -- the same kernels without addend / activation.
+
+Inputs the kernels do not take (CPU tensors, fp32, a channel count that is not a multiple of 8 ...) go through the module's ORIGINAL forward:
+that is the stock op of the dependency, not a second implementation of this repository. On a GPU without the HIP library ``ops.group_norm``
+raises like every other op here.
+"""
+import os
+import types
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+FUSED_NORM = os.environ.get("PWW_FUSED_NORM", "1") != "0"      # A/B switch (bench.py --no-fused-norm sets it)
+
+
+def _takes(x, norm):
+    if not (FUSED_NORM and torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype in (torch.float16, torch.bfloat16)):
+        return False
+    B, C, H, W = x.shape
+    w = norm.weight
+    return (C % 8 == 0 and (H * W) % 8 == 0 and C % norm.num_groups == 0 and B * norm.num_groups <= 1024 and C <= 4096
+            and (w is None or w.dtype == x.dtype) and not torch.is_autocast_enabled()         # (autocast runs group_norm in fp32)
+            and not (torch.is_grad_enabled() and (x.requires_grad or (w is not None and w.requires_grad))))
+
+
+def fused_group_norm(norm, x, add=None, act=None):
+    """act(norm(x + add[:, :, None, None])) through the HIP kernels when they take the input, else the same thing from stock ops."""
+    if _takes(x, norm) and (add is None or add.dtype == x.dtype):
+        return ops.group_norm(x, norm.num_groups, norm.weight, norm.bias, norm.eps, add=add, act=act)
+    if add is not None:
+        x = x + add[:, :, None, None]
+    y = F.group_norm(x, norm.num_groups, norm.weight, norm.bias, norm.eps)
+    return F.silu(y) if act == "silu" else y
+
+
+def _group_norm_forward(self, x):
+    return fused_group_norm(self, x) if _takes(x, self) else self._pww_orig_forward(x)
+
+
+def _is_silu(m):
+    return m is None or isinstance(m, nn.SiLU) or m is F.silu
+
+
+def _resnet_covered(m):
+    return (isinstance(getattr(m, "norm1", None), nn.GroupNorm) and isinstance(getattr(m, "norm2", None), nn.GroupNorm)
+            and hasattr(m, "conv1") and hasattr(m, "conv2") and getattr(m, "upsample", None) is None and getattr(m, "downsample", None) is None
+            and getattr(m, "time_embedding_norm", "default") == "default" and _is_silu(getattr(m, "nonlinearity", None)))
+
+
+def _resnet_forward(self, input_tensor, temb=None):
+    """diffusers 0.10.0 ``ResnetBlock2D.forward`` (``up`` / ``down`` = False, ``time_embedding_norm == "default"``)."""
+    if not _takes(input_tensor, self.norm1):
+        return self._pww_orig_forward(input_tensor, temb)
+    h = self.conv1(fused_group_norm(self.norm1, input_tensor, act="silu"))
+    add = None
+    if temb is not None and getattr(self, "time_emb_proj", None) is not None:
+        add = self.time_emb_proj(F.silu(temb))
+        if add.dtype != h.dtype:
+            add = add.to(h.dtype)
+    h = fused_group_norm(self.norm2, h, add=add, act="silu")
+    dropout = getattr(self, "dropout", None)
+    if dropout is not None:
+        h = dropout(h)
+    h = self.conv2(h)
+    if getattr(self, "conv_shortcut", None) is not None:
+        input_tensor = self.conv_shortcut(input_tensor)
+    out = input_tensor + h
+    scale = getattr(self, "output_scale_factor", 1.0)
+    return out if scale == 1.0 else out / scale
+
+
+def install_blocks(unet):
+    """Put the fused norms under every ``ResnetBlock2D`` and every other ``nn.GroupNorm`` of `unet`. Returns (resnets, norms) patched."""
+    n_res = n_gn = 0
+    owned = set()
+    dev = next((p.device for p in unet.parameters()), None)
+    if dev is not None and dev.type == "cuda":
+        ops.group_norm_workspace(dev)            # allocated (and zeroed) now: never inside a hipGraph capture
+    for m in unet.modules():
+        if m.__class__.__name__ == "ResnetBlock2D" and _resnet_covered(m):
+            if "_pww_orig_forward" not in m.__dict__:
+                m.__dict__["_pww_orig_forward"] = m.forward
+                m.forward = types.MethodType(_resnet_forward, m)
+            owned.update((id(m.norm1), id(m.norm2)))
+            n_res += 1
+    for m in unet.modules():
+        if isinstance(m, nn.GroupNorm) and id(m) not in owned:
+            if "_pww_orig_forward" not in m.__dict__:
+                m.__dict__["_pww_orig_forward"] = m.forward
+                m.forward = types.MethodType(_group_norm_forward, m)
+            n_gn += 1
+    return n_res, n_gn
+
+
+def uninstall_blocks(unet):
+    for m in unet.modules():
+        if "_pww_orig_forward" in m.__dict__:
+            del m.__dict__["_pww_orig_forward"]
+            m.__dict__.pop("forward", None)

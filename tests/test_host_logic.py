@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol(built_lib):
     raw = ctypes.CDLL(built_lib)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.pww_version() == 122
+    assert lib.pww_version() == 123
     assert lib.pww_last_error() == b"" or isinstance(lib.pww_last_error(), bytes)
     assert lib.pww_workspace_bytes(None) == 0
 
@@ -571,3 +571,39 @@ def test_weight_function_results_are_classified_for_graph_replay():
     thresholded = lambda w, s, qk: 0.4 * w * qk.max() if s > 3 else 0               # noqa: E731
     assert run(thresholded, 5.0)[0] == ops.STAT_MAX and run(thresholded, 1.0)[0] == CoeffSlots.NO_BIAS
     assert run(lambda w, s, qk: w + 1.0) is None                                    # a tensor-valued bias: not representable by a device word
+
+
+def test_block_plug_keeps_cpu_and_fp32_inputs_on_the_modules_own_forward():
+    """pww_hip/blocks.py: the per-instance plug of ResnetBlock2D / GroupNorm (row a17) hands anything the HIP kernels do not take -- here CPU
+    fp32 tensors, how the oracle runs the stand-in -- to the module's ORIGINAL forward, bit for bit, and uninstall() removes every trace."""
+    import torch
+    import torch.nn as nn
+    from pww_hip import blocks
+    from sd_standin import unet as U
+    torch.manual_seed(0)
+    res = U.ResnetBlock2D(32, 64, 128).eval().requires_grad_(False)
+    norm = nn.GroupNorm(32, 64)
+    holder = nn.ModuleList([res, norm])
+    x, temb = torch.randn(2, 32, 8, 8), torch.randn(2, 128)
+    with torch.no_grad():
+        want, want_n = res(x, temb), norm(res(x, temb))
+        assert blocks.install_blocks(holder) == (1, 1) and blocks.install_blocks(holder) == (1, 1)      # idempotent
+        assert "forward" in res.__dict__ and "forward" in norm.__dict__ and "forward" not in res.norm1.__dict__
+        assert torch.equal(res(x, temb), want) and torch.equal(norm(want), want_n)
+        # the stock-op form of the fused helper (what a block falls back to for an input the kernels do not take) is the same arithmetic
+        add = res.time_emb_proj(torch.nn.functional.silu(temb))
+        h = res.conv1(torch.nn.functional.silu(res.norm1(x)))
+        assert torch.equal(blocks.fused_group_norm(res.norm2, h, add=add, act="silu"), torch.nn.functional.silu(res.norm2(h + add[:, :, None, None])))
+        blocks.uninstall_blocks(holder)
+        assert "forward" not in res.__dict__ and "forward" not in norm.__dict__ and "_pww_orig_forward" not in res.__dict__
+        assert torch.equal(res(x, temb), want)
+
+    class Odd(nn.Module):               # a block named ResnetBlock2D that the restated forward does not cover keeps its own forward
+        def __init__(self):
+            super().__init__()
+            self.norm1, self.norm2 = nn.GroupNorm(4, 8), nn.GroupNorm(4, 8)
+            self.conv1 = self.conv2 = nn.Identity()
+            self.time_embedding_norm = "scale_shift"
+    Odd.__name__ = "ResnetBlock2D"
+    odd = Odd()
+    assert blocks.install_blocks(odd) == (0, 2) and "forward" not in odd.__dict__
