@@ -611,11 +611,13 @@ def main():
     pdist.barrier(device)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    mono0 = time.monotonic_ns()
     for s in range(args.steps):
         lat = one_step(args.warmup + s)
     pdist.barrier(device)
     torch.cuda.synchronize()
     elapsed = pdist.max_over_ranks(time.perf_counter() - t0, device)
+    log("timed region CLOCK_MONOTONIC ns %d %d" % (mono0, time.monotonic_ns()))      # (tools/rocpd_stats.py --window: the kernels of the timed steps only)
     for smp in getattr(unet, "_pww_samplers", {}).values():
         smp.check_errors()            # fused hand-off time-outs of any timed request (raises; the requests are complete: synchronised above)
     assert torch.isfinite(lat).all(), "non-finite latents"

@@ -262,13 +262,12 @@ int pww_cross_attn_fwd_parts(const void *q, const void *k, const void *v, void *
  * value before the activation. Statistics accumulate in fp64.
  *   x, y      [B, C, H, W] of `dtype` in memory format `layout`: PWW_LAYOUT_NCHW (contiguous) or PWW_LAYOUT_NHWC (torch.channels_last:
  *             element (b, c, p) at (b * HW + p) * C + c); y has x's layout; x == y is allowed (in place)
- *   add_bc    [B, C] of `dtype`, contiguous, or NULL
+ *   add_bc    [B, C] of `dtype` (row b at add_bc + b * add_stride), or NULL
  *   gamma, beta   [C] of `dtype`, or NULL (1 / 0)
- *   workspace caller-owned, at least pww_group_norm_workspace_bytes(desc) bytes, 16-byte aligned. Its first 4096 bytes are arrival
- *             counters: ZERO before the first use, left at zero by every launch (so one buffer, zeroed once, serves every norm of a
- *             stream and hipGraph replays need no memset node); the rest is scratch.
- * Two launches on `stream` (moments, apply). Requirements: C % G == 0, C % 8 == 0, HW % 8 == 0, B * G <= 1024, C <= 4096 for NHWC;
- * PWW_ENOTSUP otherwise.
+ *   workspace caller-owned scratch, at least pww_group_norm_workspace_bytes(desc) bytes, 16-byte aligned, contents need not be
+ *             initialised (fp64 partial sums handed from the first launch to the second).
+ * One launch when a group fits one workgroup's registers (the small feature maps), else two (moments, apply) on `stream`; no atomics,
+ * results bitwise repeatable. Requirements: C % G == 0, C % 8 == 0, HW % 8 == 0, G <= 32, C <= 4096 for NHWC; PWW_ENOTSUP otherwise.
  */
 #define PWW_LAYOUT_NCHW 0
 #define PWW_LAYOUT_NHWC 1
@@ -280,6 +279,8 @@ typedef struct pww_gn_desc {
     int32_t B, C, HW, G;
     float eps;
     int32_t act;          /* PWW_ACT_* */
+    int32_t add_stride;   /* elements between two images' rows of add_bc; 0 = C (contiguous). A multiple of 8. */
+    int32_t _pad;
 } pww_gn_desc_t;
 
 size_t pww_group_norm_workspace_bytes(const pww_gn_desc_t *desc);

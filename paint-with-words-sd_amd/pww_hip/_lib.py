@@ -51,7 +51,7 @@ class QprojDesc(ctypes.Structure):
 class GnDesc(ctypes.Structure):
     """struct pww_gn_desc (GroupNorm + addend + activation)."""
     _fields_ = [("dtype", ctypes.c_int32), ("layout", ctypes.c_int32), ("B", ctypes.c_int32), ("C", ctypes.c_int32), ("HW", ctypes.c_int32),
-                ("G", ctypes.c_int32), ("eps", ctypes.c_float), ("act", ctypes.c_int32)]
+                ("G", ctypes.c_int32), ("eps", ctypes.c_float), ("act", ctypes.c_int32), ("add_stride", ctypes.c_int32), ("_pad", ctypes.c_int32)]
 
 
 class Region(ctypes.Structure):

@@ -10,6 +10,7 @@ Installed per INSTANCE (``module.forward = ...``; ``nn.Module.__call__`` and its
       h = conv1(silu(norm1(x)));  h = h + time_emb_proj(silu(temb))[:, :, None, None];  h = conv2(dropout(silu(norm2(h))));
       return (conv_shortcut(x) + h) / output_scale_factor
 
+  and ``time_emb_proj(silu(temb))`` of all blocks as one GEMM per forward (``TembProjections``).
   Blocks this restatement does not cover (``upsample`` / ``downsample`` inside the block, ``time_embedding_norm != "default"``, a nonlinearity
   other than SiLU) keep their own forward.
 * every other ``nn.GroupNorm`` of the model (``Transformer2DModel.norm``, ``conv_norm_out``) -- the same kernels without addend / activation.
@@ -28,6 +29,7 @@ import torch.nn.functional as F
 from . import ops
 
 FUSED_NORM = os.environ.get("PWW_FUSED_NORM", "1") != "0"      # A/B switch (bench.py --no-fused-norm sets it)
+BATCHED_TEMB = os.environ.get("PWW_BATCHED_TEMB", "1") != "0"  # A/B switch: one time-embedding projection GEMM per forward for all blocks
 
 
 def _takes(x, norm):
@@ -35,7 +37,7 @@ def _takes(x, norm):
         return False
     B, C, H, W = x.shape
     w = norm.weight
-    return (C % 8 == 0 and (H * W) % 8 == 0 and C % norm.num_groups == 0 and B * norm.num_groups <= 1024 and C <= 4096
+    return (C % 8 == 0 and (H * W) % 8 == 0 and C % norm.num_groups == 0 and norm.num_groups <= 32 and C <= 4096
             and (w is None or w.dtype == x.dtype) and not torch.is_autocast_enabled()         # (autocast runs group_norm in fp32)
             and not (torch.is_grad_enabled() and (x.requires_grad or (w is not None and w.requires_grad))))
 
@@ -64,6 +66,50 @@ def _resnet_covered(m):
             and getattr(m, "time_embedding_norm", "default") == "default" and _is_silu(getattr(m, "nonlinearity", None)))
 
 
+class TembProjections:
+    """``time_emb_proj(silu(temb))`` of ALL the plugged ResnetBlock2D of a model as ONE GEMM per forward (22 blocks in the SD1.5 UNet: 22
+    SiLU launches on the same [B, 1280] tensor and 22 GEMMs of 2 rows become one each). The concatenated weight is a COPY: it is rebuilt
+    when any source parameter was replaced, modified in place (tensor version counter), moved or cast. The result is cached ON the temb
+    tensor object (a fresh one every forward), block i takes its columns as a view -- `ops.group_norm` reads strided rows."""
+
+    def __init__(self):
+        self.linears = []          # (block, offset, width) in registration order
+        self.width = 0
+        self._sig = None
+        self._w = self._b = None
+
+    def register(self, block):
+        lin = block.time_emb_proj
+        slot = (self, self.width, lin.out_features)
+        self.linears.append((lin, self.width, lin.out_features))
+        self.width += (lin.out_features + 7) // 8 * 8             # (every block's columns start 16-byte aligned)
+        return slot
+
+    def _signature(self, dtype, device):
+        sig = [dtype, device]
+        for lin, _, _ in self.linears:
+            sig.append((lin.weight.data_ptr(), lin.weight._version, lin.weight.dtype))
+            sig.append(None if lin.bias is None else (lin.bias.data_ptr(), lin.bias._version))
+        return tuple(sig)
+
+    def project(self, temb):
+        hit = temb.__dict__.get("_pww_temb_proj")
+        if hit is not None and hit[0] is self:
+            return hit[1]
+        sig = self._signature(temb.dtype, temb.device)
+        if sig != self._sig:
+            w = torch.zeros(self.width, self.linears[0][0].in_features, dtype=temb.dtype, device=temb.device)
+            b = torch.zeros(self.width, dtype=temb.dtype, device=temb.device)
+            for lin, off, n in self.linears:
+                w[off:off + n] = lin.weight.detach().to(temb.dtype)
+                if lin.bias is not None:
+                    b[off:off + n] = lin.bias.detach().to(temb.dtype)
+            self._w, self._b, self._sig = w, b, sig
+        out = F.linear(F.silu(temb), self._w, self._b)
+        temb.__dict__["_pww_temb_proj"] = (self, out)
+        return out
+
+
 def _resnet_forward(self, input_tensor, temb=None):
     """diffusers 0.10.0 ``ResnetBlock2D.forward`` (``up`` / ``down`` = False, ``time_embedding_norm == "default"``)."""
     if not _takes(input_tensor, self.norm1):
@@ -71,7 +117,11 @@ def _resnet_forward(self, input_tensor, temb=None):
     h = self.conv1(fused_group_norm(self.norm1, input_tensor, act="silu"))
     add = None
     if temb is not None and getattr(self, "time_emb_proj", None) is not None:
-        add = self.time_emb_proj(F.silu(temb))
+        slot = self.__dict__.get("_pww_temb_slot")
+        if slot is not None and temb.dtype == h.dtype and temb.dim() == 2 and not torch.is_grad_enabled():
+            add = slot[0].project(temb)[:, slot[1]:slot[1] + slot[2]]
+        else:
+            add = self.time_emb_proj(F.silu(temb))
         if add.dtype != h.dtype:
             add = add.to(h.dtype)
     h = fused_group_norm(self.norm2, h, add=add, act="silu")
@@ -92,12 +142,16 @@ def install_blocks(unet):
     owned = set()
     dev = next((p.device for p in unet.parameters()), None)
     if dev is not None and dev.type == "cuda":
-        ops.group_norm_workspace(dev)            # allocated (and zeroed) now: never inside a hipGraph capture
+        ops.group_norm_workspace(dev)            # allocated now: never inside a hipGraph capture
+    plans = {}                 # time-embedding width -> one batched projection for all blocks that share it
     for m in unet.modules():
         if m.__class__.__name__ == "ResnetBlock2D" and _resnet_covered(m):
             if "_pww_orig_forward" not in m.__dict__:
                 m.__dict__["_pww_orig_forward"] = m.forward
                 m.forward = types.MethodType(_resnet_forward, m)
+                lin = getattr(m, "time_emb_proj", None)
+                if BATCHED_TEMB and isinstance(lin, nn.Linear):
+                    m.__dict__["_pww_temb_slot"] = plans.setdefault(lin.in_features, TembProjections()).register(m)
             owned.update((id(m.norm1), id(m.norm2)))
             n_res += 1
     for m in unet.modules():
@@ -114,3 +168,4 @@ def uninstall_blocks(unet):
         if "_pww_orig_forward" in m.__dict__:
             del m.__dict__["_pww_orig_forward"]
             m.__dict__.pop("forward", None)
+            m.__dict__.pop("_pww_temb_slot", None)

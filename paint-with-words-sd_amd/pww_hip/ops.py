@@ -540,12 +540,13 @@ def cfg_combine(cond, uncond, guidance_scale):
 
 
 # ---- GroupNorm (+ per-(image, channel) addend, + SiLU) of the blocks that call the attention path ------------------------------------
-_GN_WORKSPACE = {}          # device index -> zero-initialised workspace (arrival counters in front: every launch leaves them zero)
-_GN_WORKSPACE_BYTES = 8 << 20
+_GN_WORKSPACE = {}          # device index -> scratch for the partial sums (every launch writes what it reads: no initial state)
+_GN_WORKSPACE_BYTES = 4 << 20
 
 
 def group_norm_workspace(device, need=0):
-    """The device's shared group_norm workspace (created zeroed on first use; `blocks.install_blocks` creates it up front)."""
+    """The device's shared group_norm scratch (created on first use; `blocks.install_blocks` creates it up front so that a hipGraph capture
+    never allocates it)."""
     device = torch.device(device)
     index = device.index if device.index is not None else torch.cuda.current_device()
     ws = _GN_WORKSPACE.get(index)
@@ -553,17 +554,18 @@ def group_norm_workspace(device, need=0):
         if torch.cuda.is_current_stream_capturing():
             raise PwwHipError("group_norm: the workspace must exist before a hipGraph capture (call ops.group_norm_workspace(device) first)")
         with torch.cuda.device(index):
-            torch.cuda.synchronize()           # (a larger replacement: nothing may still be using the old one's counters)
-            ws = torch.zeros(max(_GN_WORKSPACE_BYTES, int(need)), dtype=torch.uint8, device=torch.device("cuda", index))
+            torch.cuda.synchronize()           # (a larger replacement: nothing may still be reading the old one)
+            ws = torch.empty(max(_GN_WORKSPACE_BYTES, int(need)), dtype=torch.uint8, device=torch.device("cuda", index))
         _GN_WORKSPACE[index] = ws
     return ws
 
 
 def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, add=None, act=None, workspace=None, out=None):
     """act(GroupNorm(x + add[:, :, None, None])) for a [B, C, H, W] float16 / bfloat16 tensor in NCHW-contiguous or channels_last memory
-    format (the output has x's format); `add` [B, C] or None; act None | "silu". SURVEY.md section 8 row a17 (diffusers 0.10.0
-    ResnetBlock2D / Transformer2DModel, the callers of the patched CrossAttention). One `workspace` per device serves every call made on
-    ONE stream (launches serialise there); a caller that runs norms on several streams at once passes its own zero-initialised uint8 buffer."""
+    format (the output has x's format); `add` [B, C] (unit stride along C; rows may be views into a wider tensor) or None; act None |
+    "silu". SURVEY.md section 8 row a17 (diffusers 0.10.0 ResnetBlock2D / Transformer2DModel, the callers of the patched CrossAttention).
+    One scratch `workspace` per device serves every call made on ONE stream (launches serialise there); a caller that runs norms on several
+    streams at once passes its own uint8 buffer."""
     _require_gpu(x)
     if x.dim() != 4 or x.dtype not in _DT:
         raise PwwHipError("group_norm needs a 4-d float16/bfloat16 tensor (got %s %s)" % (tuple(x.shape), x.dtype))
@@ -575,8 +577,6 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, add=None, act=No
     else:
         x = x.contiguous()
         layout = _lib.LAYOUT_NCHW
-    if H * W == 1 or C == 1:          # both formats describe the same bytes; is_contiguous() answered first
-        layout = _lib.LAYOUT_NCHW
     if out is None:
         out = torch.empty_like(x)     # (preserves the memory format)
     elif out.shape != x.shape or out.dtype != x.dtype or out.stride() != x.stride():
@@ -586,15 +586,19 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, add=None, act=No
             raise PwwHipError("group_norm: `%s` must be %s %s on %s (got %s %s)" % (name, x.dtype, shape, x.device, t.dtype, tuple(t.shape)))
     weight = weight.contiguous() if weight is not None else None
     bias = bias.contiguous() if bias is not None else None
-    add = add.contiguous() if add is not None else None
+    add_stride = 0
+    if add is not None:
+        if add.stride(1) != 1 or add.stride(0) % 8 != 0 or add.data_ptr() % 16 != 0:
+            add = add.contiguous()
+        add_stride = add.stride(0) if B > 1 else C
     if act not in (None, "silu"):
         raise PwwHipError("group_norm: act must be None or 'silu'")
-    d = _lib.GnDesc(_DT[x.dtype], layout, B, C, H * W, int(num_groups), float(eps), _lib.ACT_SILU if act == "silu" else _lib.ACT_NONE)
+    d = _lib.GnDesc(_DT[x.dtype], layout, B, C, H * W, int(num_groups), float(eps), _lib.ACT_SILU if act == "silu" else _lib.ACT_NONE, add_stride, 0)
     lib = _lib.load()
     need = lib.pww_group_norm_workspace_bytes(ctypes.byref(d))
     if need == 0:
         raise PwwHipError("group_norm: unsupported shape B %d C %d HW %d groups %d (C and H*W multiples of 8, C %% groups == 0, "
-                          "B * groups <= 1024, C <= 4096 in channels_last)" % (B, C, H * W, num_groups))
+                          "groups <= 32, C <= 4096 in channels_last)" % (B, C, H * W, num_groups))
     ws = workspace if workspace is not None else group_norm_workspace(x.device, need)
     with torch.cuda.device(x.device):
         _lib.check(lib.pww_group_norm_fwd(_ptr(x), _ptr(add) if add is not None else None, _ptr(weight) if weight is not None else None,

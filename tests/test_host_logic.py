@@ -607,3 +607,33 @@ def test_block_plug_keeps_cpu_and_fp32_inputs_on_the_modules_own_forward():
     Odd.__name__ = "ResnetBlock2D"
     odd = Odd()
     assert blocks.install_blocks(odd) == (0, 2) and "forward" not in odd.__dict__
+
+
+def test_batched_time_embedding_projection_tracks_its_source_weights():
+    """blocks.TembProjections: one GEMM for all blocks' time_emb_proj(silu(temb)); the concatenated copy follows in-place updates,
+    replaced parameters and casts of the source weights; the result is cached on the temb tensor object only."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from pww_hip.blocks import TembProjections
+    torch.manual_seed(1)
+    lins = [nn.Linear(16, n) for n in (8, 20, 32)]            # (20: the next block still starts on a multiple of 8 columns)
+    blocks_ = [type("B", (), {"time_emb_proj": lin})() for lin in lins]
+    plan = TembProjections()
+    slots = [plan.register(b) for b in blocks_]
+    assert [s[1] for s in slots] == [0, 8, 32] and plan.width == 64
+    temb = torch.randn(3, 16)
+    with torch.no_grad():
+        out = plan.project(temb)
+        assert plan.project(temb) is out                       # cached on this tensor object ...
+        assert plan.project(temb.clone()) is not out           # ... and nowhere else
+        for lin, (_, off, n) in zip(lins, slots):
+            assert torch.allclose(out[:, off:off + n], lin(F.silu(temb)), atol=1e-6)
+        lins[1].weight.mul_(2.0)                               # in-place update: version counter moves
+        assert torch.allclose(plan.project(temb.clone())[:, 8:28], lins[1](F.silu(temb)), atol=1e-6)
+        lins[2].weight = nn.Parameter(torch.randn(32, 16))     # replaced parameter
+        assert torch.allclose(plan.project(temb.clone())[:, 32:64], lins[2](F.silu(temb)), atol=1e-6)
+        t64 = temb.double()
+        for lin in lins:
+            lin.double()
+        assert torch.allclose(plan.project(t64)[:, 0:8], lins[0](F.silu(t64)), atol=1e-12)

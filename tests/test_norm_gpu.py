@@ -74,8 +74,10 @@ def test_group_norm_matches_the_fp32_reference(shape, channels_last, dtype):
         stock = F.silu(stock) if act == "silu" else stock
         rel2 = _close(y, stock, dtype)[1]
         assert rel2 <= 2 * ULP[dtype], ("vs stock", shape, channels_last, dtype, use_add, act, rel2)
-    torch.cuda.synchronize()
-    assert int(ops.group_norm_workspace(torch.device(DEV))[:4096].sum()) == 0          # arrival counters back at zero
+    # the addend as rows of a wider tensor (how the block plug hands over one batched time-embedding projection): no copy, same bits
+    wide = torch.zeros(B, C + 64, device=DEV, dtype=dtype)
+    wide[:, 32:32 + C] = add
+    assert torch.equal(ops.group_norm(x, 32, w, b, 1e-5, add=wide[:, 32:32 + C], act="silu"), ops.group_norm(x, 32, w, b, 1e-5, add=add, act="silu"))
 
 
 def test_group_norm_statistics_survive_a_large_mean():
@@ -101,7 +103,7 @@ def test_group_norm_in_place_graph_replay_and_errors():
     y = ops.group_norm(x, 32, w, b, 1e-5, act="silu")
     x2 = x.clone(memory_format=torch.preserve_format)
     assert ops.group_norm(x2, 32, w, b, 1e-5, act="silu", out=x2) is x2 and torch.equal(x2, y)
-    # replayed from a hipGraph: bit-identical every time, no memset node needed for the counters
+    # replayed from a hipGraph: bit-identical every time (no state between launches)
     static = x.clone(memory_format=torch.preserve_format)
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())

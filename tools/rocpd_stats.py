@@ -1,5 +1,5 @@
 """Summarise a rocprofv3 rocpd sqlite database (kernel-trace) into a per-kernel stats table (markdown).
-Usage: python tools/rocpd_stats.py <results.db> [--top N] [--grid] [--match <substring>] [--split-b2b <kernel name substring>]
+Usage: python tools/rocpd_stats.py <results.db> [--top N] [--grid] [--match <substring>] [--split-b2b <kernel name substring>] [--window <ns> <ns>]
 --split-b2b: for one kernel, average duration of the launches that directly follow another launch of the SAME kernel
 (bench.py's roofline pass: 40 launches replayed back to back) and of all others (the launches inside the UNet workload)."""
 import sqlite3
@@ -11,9 +11,17 @@ def main():
     top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 40
     cur = db.cursor()
     group = "name, grid_x, workgroup_x" if "--grid" in sys.argv else "name"
+    where = ""
+    if "--window" in sys.argv:          # only dispatches that start inside [a, b] ns (bench.py logs the timed region's CLOCK_MONOTONIC bounds)
+        a, b = int(sys.argv[sys.argv.index("--window") + 1]), int(sys.argv[sys.argv.index("--window") + 2])
+        n_in = cur.execute(f"select count(*) from kernels where start >= {a} and start <= {b}").fetchone()[0]
+        lo, hi = cur.execute("select min(start), max(end) from kernels").fetchone()
+        print("window [%d, %d] ns = %.1f ms: %d dispatches inside (trace spans [%d, %d])" % (a, b, (b - a) / 1e6, n_in, lo, hi))
+        if n_in:
+            where = f"where start >= {a} and start <= {b}"
     rows = cur.execute(
         f"select name, count(*), sum(duration), avg(duration), min(duration), max(duration), max(vgpr_count), "
-        f"max(accum_vgpr_count), max(lds_size), min(grid_x), max(grid_x), max(workgroup_x) from kernels group by {group} "
+        f"max(accum_vgpr_count), max(lds_size), min(grid_x), max(grid_x), max(workgroup_x) from kernels {where} group by {group} "
         f"order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows)
     print("total kernel time: %.3f ms over %d dispatches, %d distinct kernels" % (total / 1e6, sum(r[1] for r in rows), len(rows)))
