@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define PWW_VERSION 123 /* 0.1.23: pww_group_norm_fwd / pww_group_norm_workspace_bytes (GroupNorm + addend + SiLU of the blocks that call the attention path); 0.1.22: pww_qproj_stat / pww_qproj_parts / pww_cross_attn_fwd_parts (score statistic formed in the to_q GEMM's epilogue), pww_mask_build_f32_levels, PWW_STAT_ALL; 0.1.21: pww_cross_opts_t.gated_images (was padding); 0.1.20: + pww_cross_attn_fwd_fused_ex / pww_cross_attn_fwd_stat_ex (pww_cross_opts_t: device-side coefficient word, bias column bound,
+#define PWW_VERSION 123 /* 0.1.23: pww_group_norm_fwd / pww_group_norm_workspace_bytes, pww_add_layer_norm, pww_geglu, pww_bias_residual (norms and elementwise glue of the blocks that call the attention path); 0.1.22: pww_qproj_stat / pww_qproj_parts / pww_cross_attn_fwd_parts (score statistic formed in the to_q GEMM's epilogue), pww_mask_build_f32_levels, PWW_STAT_ALL; 0.1.21: pww_cross_opts_t.gated_images (was padding); 0.1.20: + pww_cross_attn_fwd_fused_ex / pww_cross_attn_fwd_stat_ex (pww_cross_opts_t: device-side coefficient word, bias column bound,
                            compact bias), pww_debug_timeline (0.1.11: pww_profile_*; 0.1.10: fused cross-attention, blur, resize, inpaint prep) */
 
 #define PWW_OK 0
@@ -256,12 +256,14 @@ int pww_cross_attn_fwd_parts(const void *q, const void *k, const void *v, void *
  * (diffusers==0.10.0 -- requirements.txt:1 of the reference, source not under the reference tree --
  * ResnetBlock2D.forward `conv1(silu(norm1(x)))`, `h + time_emb_proj(silu(temb))[:, :, None, None]` -> `conv2(silu(norm2(h)))`, and
  * Transformer2DModel.forward `norm(hidden_states)` in front of proj_in and the patched CrossAttention modules):
- *   y[b, c, p] = act( (h - mean[b, g]) * rstd[b, g] * gamma[c] + beta[c] ),   h = x[b, c, p] + add_bc[b, c],   g = c / (C / G),
+ *   y[b, c, p] = act( (h - mean[b, g]) * rstd[b, g] * gamma[c] + beta[c] ),   h = x[b, c, p] + pre_c[c] + add_bc[b, c],   g = c / (C / G),
  *   mean / rstd over the C / G channels x HW positions of the group (biased variance, rstd = 1 / sqrt(var + eps)), act = identity | SiLU.
  * Rounding points are those of the stock sequence on tensors of the storage type: h is rounded to it before it is normalised, the normalised
  * value before the activation. Statistics accumulate in fp64.
  *   x, y      [B, C, H, W] of `dtype` in memory format `layout`: PWW_LAYOUT_NCHW (contiguous) or PWW_LAYOUT_NHWC (torch.channels_last:
  *             element (b, c, p) at (b * HW + p) * C + c); y has x's layout; x == y is allowed (in place)
+ *   pre_c     [C] of `dtype` or NULL: a per-channel addend applied (and rounded) BEFORE add_bc -- the bias of the convolution that produced x,
+ *             handed over instead of being added by a launch of its own
  *   add_bc    [B, C] of `dtype` (row b at add_bc + b * add_stride), or NULL
  *   gamma, beta   [C] of `dtype`, or NULL (1 / 0)
  *   workspace caller-owned scratch, at least pww_group_norm_workspace_bytes(desc) bytes, 16-byte aligned, contents need not be
@@ -284,8 +286,30 @@ typedef struct pww_gn_desc {
 } pww_gn_desc_t;
 
 size_t pww_group_norm_workspace_bytes(const pww_gn_desc_t *desc);
-int pww_group_norm_fwd(const void *x, const void *add_bc, const void *gamma, const void *beta, void *y, const pww_gn_desc_t *desc,
-                       void *workspace, size_t workspace_bytes, void *stream);
+int pww_group_norm_fwd(const void *x, const void *pre_c, const void *add_bc, const void *gamma, const void *beta, void *y,
+                       const pww_gn_desc_t *desc, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Elementwise glue of the same blocks (row a17; diffusers 0.10.0 BasicTransformerBlock / FeedForward / ResnetBlock2D), each ONE launch with
+ * the stock sequence's rounding points on tensors of the storage type T:
+ *   pww_add_layer_norm   s = T(a + x);  y = T(LayerNorm_C(s) * gamma + beta)     `attn(norm(h)) + h` and the block's NEXT norm in one launch.
+ *                        a == NULL (then s == NULL): plain LayerNorm of x. Rows of C channels (a multiple of 8, <= 2048), row strides in
+ *                        elements (0 = C); statistics in fp32, two passes over the row in registers (mean, centred squares).
+ *   pww_geglu            y[m, 0..D) = T(h[m, 0..D) * T(gelu(h[m, D..2D))))        FeedForward's GEGLU after its projection (erf form of gelu)
+ *   pww_bias_residual    y = T(r + T(v + bias[c]))  over [B, C, H, W] in layout    ResnetBlock2D's `input + conv2(h)` with conv2's bias handed
+ *                        over as an operand instead of a launch of its own. y may alias r or v.
+ */
+typedef struct pww_ln_desc {
+    int32_t dtype;        /* PWW_DTYPE_* */
+    int32_t C;
+    int64_t rows;
+    int64_t a_stride, x_stride, s_stride, y_stride;
+    float eps;
+    int32_t _pad;
+} pww_ln_desc_t;
+int pww_add_layer_norm(const void *a, const void *x, const void *gamma, const void *beta, void *s, void *y, const pww_ln_desc_t *desc, void *stream);
+int pww_geglu(const void *h, void *y, int64_t rows, int32_t D, int64_t h_stride, int64_t y_stride, int32_t dtype, void *stream);
+int pww_bias_residual(const void *r, const void *v, const void *bias, void *y, int32_t B, int32_t C, int32_t HW, int32_t layout, int32_t dtype, void *stream);
 
 /*
  * Per-image global statistics of the raw score tensor S = Q K^T over all heads, rows and keys

@@ -182,8 +182,11 @@ int inpaint_prep(const uint8_t *rgb, const uint8_t *mask, int H, int W, int h, i
 int cfg_combine(const void *cond, const void *uncond, float g, float *out, long n, int dtype, hipStream_t stream);
 int store_f32(float *dst, const float *values, int n, hipStream_t stream);
 size_t group_norm_workspace_bytes(const pww_gn_desc_t *d);
-int group_norm_fwd(const void *x, const void *add_bc, const void *gamma, const void *beta, void *y, const pww_gn_desc_t *d, void *workspace,
-                   size_t workspace_bytes, hipStream_t stream);
+int group_norm_fwd(const void *x, const void *pre_c, const void *add_bc, const void *gamma, const void *beta, void *y, const pww_gn_desc_t *d,
+                   void *workspace, size_t workspace_bytes, hipStream_t stream);
+int add_layer_norm(const void *a, const void *x, const void *gamma, const void *beta, void *s, void *y, const pww_ln_desc_t *d, hipStream_t stream);
+int geglu(const void *h, void *y, int64_t rows, int32_t D, int64_t h_stride, int64_t y_stride, int32_t dtype, hipStream_t stream);
+int bias_residual(const void *r, const void *v, const void *bias, void *y, int32_t B, int32_t C, int32_t HW, int32_t layout, int32_t dtype, hipStream_t stream);
 
 }  // namespace pww
 
@@ -323,9 +326,18 @@ int pww_store_f32(float *dst, const float *values, int32_t n, void *stream) { re
 size_t pww_workspace_bytes(const pww_attn_desc_t *desc) { return pww::qk_reduce_workspace_bytes(desc); }
 
 size_t pww_group_norm_workspace_bytes(const pww_gn_desc_t *desc) { return pww::group_norm_workspace_bytes(desc); }
-int pww_group_norm_fwd(const void *x, const void *add_bc, const void *gamma, const void *beta, void *y, const pww_gn_desc_t *desc,
+int pww_group_norm_fwd(const void *x, const void *pre_c, const void *add_bc, const void *gamma, const void *beta, void *y, const pww_gn_desc_t *desc,
                        void *workspace, size_t workspace_bytes, void *stream) {
-    return pww::group_norm_fwd(x, add_bc, gamma, beta, y, desc, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    return pww::group_norm_fwd(x, pre_c, add_bc, gamma, beta, y, desc, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+int pww_add_layer_norm(const void *a, const void *x, const void *gamma, const void *beta, void *s, void *y, const pww_ln_desc_t *desc, void *stream) {
+    return pww::add_layer_norm(a, x, gamma, beta, s, y, desc, static_cast<hipStream_t>(stream));
+}
+int pww_geglu(const void *h, void *y, int64_t rows, int32_t D, int64_t h_stride, int64_t y_stride, int32_t dtype, void *stream) {
+    return pww::geglu(h, y, rows, D, h_stride, y_stride, dtype, static_cast<hipStream_t>(stream));
+}
+int pww_bias_residual(const void *r, const void *v, const void *bias, void *y, int32_t B, int32_t C, int32_t HW, int32_t layout, int32_t dtype, void *stream) {
+    return pww::bias_residual(r, v, bias, y, B, C, HW, layout, dtype, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

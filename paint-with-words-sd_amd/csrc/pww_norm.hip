@@ -2,7 +2,8 @@
 // (diffusers==0.10.0, pinned by the reference's requirements.txt:1, not under /root/reference):
 //   ResnetBlock2D.forward:      h = conv1(silu(norm1(x)));  h = h + time_emb_proj(silu(temb))[:, :, None, None];  h = conv2(silu(norm2(h)))
 //   Transformer2DModel.forward: x = norm(hidden_states) -> proj_in -> [BasicTransformerBlock: attn1 / attn2 = the patched CrossAttention]
-// i.e. per call   y = act( GroupNorm_G( x + t[b, c] ) * gamma[c] + beta[c] ),   act = identity or SiLU,  t optional.
+// i.e. per call   y = act( GroupNorm_G( x + p[c] + t[b, c] ) * gamma[c] + beta[c] ),   act = identity or SiLU;  p (a convolution's bias, handed
+// over instead of being added by a launch of its own) and t optional.
 //
 // Why it is here: at 2 folded rows the stock sequence is 4 - 5 launches per norm (add, row moments with ONE workgroup per (image, group) =
 // 64 workgroups on a 256-CU part, fused-parameter kernel, apply, SiLU): 40 - 50 us where the bytes are worth 2 - 3.
@@ -32,7 +33,7 @@ constexpr int GN_MAX_SLABS = 64;              // partials per (image, group)
 constexpr int GN_GROUP_PIECES = 24;           // single-launch form: pieces a thread keeps in registers
 
 struct GnParams {
-    const void *x, *add, *gamma, *beta;
+    const void *x, *pre, *add, *gamma, *beta;      // pre: [C] per-channel addend applied (and rounded) before `add` -- a convolution's bias
     void *y;
     double *partial;       // [B][nslab][G][2] (NHWC) / [B][G][nslab][2] (NCHW)
     int B, C, HW, G, cg;
@@ -87,10 +88,15 @@ __global__ void __launch_bounds__(NT) gn_moments_nhwc(const GnParams p) {
     double *lk = reinterpret_cast<double *>(lq + PL * p.C);       // [K][G][2]
 
     if (pl < PL) {
-        float s[8], q[8], t[8];
+        float s[8], q[8], t[8], pb[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] = q[j] = t[j] = 0.f;
+        for (int j = 0; j < 8; ++j) s[j] = q[j] = t[j] = pb[j] = 0.f;
         const T *x = reinterpret_cast<const T *>(p.x) + (long)b * p.HW * p.C + ch * 8;
+        if (p.pre) {
+            const V8 pv = *reinterpret_cast<const V8 *>(reinterpret_cast<const T *>(p.pre) + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pb[j] = (float)pv[j];
+        }
         if (p.add) {
             const V8 tv = *reinterpret_cast<const V8 *>(reinterpret_cast<const T *>(p.add) + (long)b * p.add_stride + ch * 8);
 #pragma unroll
@@ -113,6 +119,7 @@ __global__ void __launch_bounds__(NT) gn_moments_nhwc(const GnParams p) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float h = (float)r[u][j];
+                    if (p.pre) h = round_to<T>(h + pb[j]);
                     if (p.add) h = round_to<T>(h + t[j]);
                     h = ok ? h : 0.f;
                     s[j] += h;
@@ -165,7 +172,7 @@ __global__ void __launch_bounds__(NT) gn_apply_nhwc(const GnParams p) {
         part[i] = reinterpret_cast<const f64x2 *>(p.partial)[((long)b * p.nslab + (k < K && sl < p.nslab ? sl : 0)) * p.G + g];
     }
     const int c0 = ch * 8;
-    V8 gv = zero8<V8>(), bv = zero8<V8>(), tv = zero8<V8>();
+    V8 gv = zero8<V8>(), bv = zero8<V8>(), tv = zero8<V8>(), pv = zero8<V8>();
     const T *x = reinterpret_cast<const T *>(p.x) + (long)b * p.HW * p.C + c0;
     T *y = reinterpret_cast<T *>(p.y) + (long)b * p.HW * p.C + c0;
     const int p0 = blockIdx.x * p.apply_px, p1 = min(p0 + p.apply_px, p.HW);
@@ -174,6 +181,7 @@ __global__ void __launch_bounds__(NT) gn_apply_nhwc(const GnParams p) {
         if (p.gamma) gv = *reinterpret_cast<const V8 *>(reinterpret_cast<const T *>(p.gamma) + c0);
         if (p.beta) bv = *reinterpret_cast<const V8 *>(reinterpret_cast<const T *>(p.beta) + c0);
         if (p.add) tv = *reinterpret_cast<const V8 *>(reinterpret_cast<const T *>(p.add) + (long)b * p.add_stride + c0);
+        if (p.pre) pv = *reinterpret_cast<const V8 *>(reinterpret_cast<const T *>(p.pre) + c0);
 #pragma unroll
         for (int u = 0; u < GN_UN; ++u) {
             const int pu = p0 + pl + u * PL;
@@ -197,13 +205,14 @@ __global__ void __launch_bounds__(NT) gn_apply_nhwc(const GnParams p) {
     }
     __syncthreads();
     if (!active) return;
-    float a[8], bb[8], t[8];
+    float a[8], bb[8], t[8], pb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int gg = (c0 + j) / p.cg;
         a[j] = stat[gg * 2 + 1] * (p.gamma ? (float)gv[j] : 1.f);
         bb[j] = (p.beta ? (float)bv[j] : 0.f) - a[j] * stat[gg * 2];
         t[j] = (float)tv[j];
+        pb[j] = (float)pv[j];
     }
     for (int px = p0 + pl; px < p1; px += GN_UN * PL) {
         if (px != p0 + pl) {
@@ -218,8 +227,10 @@ __global__ void __launch_bounds__(NT) gn_apply_nhwc(const GnParams p) {
             V8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float h = (float)r[u][j];
-                o[j] = (T)finish<T, ACT>(p.add ? round_to<T>(h + t[j]) : h, a[j], bb[j]);
+                float h = (float)r[u][j];
+                if (p.pre) h = round_to<T>(h + pb[j]);
+                if (p.add) h = round_to<T>(h + t[j]);
+                o[j] = (T)finish<T, ACT>(h, a[j], bb[j]);
             }
             if (px + u * PL < p1) *reinterpret_cast<V8 *>(y + (long)(px + u * PL) * p.C) = o;
         }
@@ -241,7 +252,7 @@ __global__ void __launch_bounds__(GN_NT) gn_group_nhwc(const GnParams p) {
     T *y = reinterpret_cast<T *>(p.y) + (long)b * p.HW * p.C + c0;
     TV raw[GN_GROUP_PIECES];
     const TV z = {(T)0.f, (T)0.f, (T)0.f, (T)0.f};
-    TV gv = z, bv = z, tv = z;
+    TV gv = z, bv = z, tv = z, pv = z;
     if (active) {
 #pragma unroll
         for (int j = 0; j < GN_GROUP_PIECES; ++j) {
@@ -251,6 +262,7 @@ __global__ void __launch_bounds__(GN_NT) gn_group_nhwc(const GnParams p) {
         if (p.gamma) gv = *reinterpret_cast<const TV *>(reinterpret_cast<const T *>(p.gamma) + c0);
         if (p.beta) bv = *reinterpret_cast<const TV *>(reinterpret_cast<const T *>(p.beta) + c0);
         if (p.add) tv = *reinterpret_cast<const TV *>(reinterpret_cast<const T *>(p.add) + (long)b * p.add_stride + c0);
+        if (p.pre) pv = *reinterpret_cast<const TV *>(reinterpret_cast<const T *>(p.pre) + c0);
     }
     float v[GN_GROUP_PIECES][4];
     float s = 0.f, q = 0.f;
@@ -261,6 +273,7 @@ __global__ void __launch_bounds__(GN_NT) gn_group_nhwc(const GnParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float h = (float)raw[j][e];
+                if (p.pre) h = round_to<T>(h + (float)pv[e]);
                 if (p.add) h = round_to<T>(h + (float)tv[e]);
                 h = ok ? h : 0.f;
                 v[j][e] = h;
@@ -303,17 +316,19 @@ __global__ void __launch_bounds__(GN_NT) gn_moments_nchw(const GnParams p) {
     const long lo = nchunk * seg / p.nslab, hi = nchunk * (seg + 1) / p.nslab;
     const T *x = reinterpret_cast<const T *>(p.x) + ((long)b * p.C + (long)g * p.cg) * p.HW;
     const T *add = p.add ? reinterpret_cast<const T *>(p.add) + (long)b * p.add_stride + g * p.cg : nullptr;
+    const T *pre = p.pre ? reinterpret_cast<const T *>(p.pre) + g * p.cg : nullptr;
     float s = 0.f, q = 0.f;
     double S = 0.0, Q = 0.0;
 #pragma unroll 1
     for (long k = lo + tid; k < hi; k += GN_UN * GN_NT) {
         V8 r[GN_UN];
-        float t[GN_UN];
+        float t[GN_UN], pb[GN_UN];
 #pragma unroll
         for (int u = 0; u < GN_UN; ++u) {
             const long ku = k + (long)u * GN_NT < hi ? k + (long)u * GN_NT : k;
             r[u] = *reinterpret_cast<const V8 *>(x + ku * 8);
             t[u] = add ? (float)add[(ku * 8) / p.HW] : 0.f;
+            pb[u] = pre ? (float)pre[(ku * 8) / p.HW] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < GN_UN; ++u) {
@@ -321,6 +336,7 @@ __global__ void __launch_bounds__(GN_NT) gn_moments_nchw(const GnParams p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 float h = (float)r[u][j];
+                if (pre) h = round_to<T>(h + pb[u]);
                 if (add) h = round_to<T>(h + t[u]);
                 h = ok ? h : 0.f;
                 s += h;
@@ -364,6 +380,7 @@ __global__ void __launch_bounds__(GN_NT) gn_apply_nchw(const GnParams p) {
         const float gm = p.gamma ? (float)reinterpret_cast<const T *>(p.gamma)[c] : 1.f;
         const float bt = p.beta ? (float)reinterpret_cast<const T *>(p.beta)[c] : 0.f;
         const float t = p.add ? (float)reinterpret_cast<const T *>(p.add)[(long)b * p.add_stride + c] : 0.f;
+        const float pb = p.pre ? (float)reinterpret_cast<const T *>(p.pre)[c] : 0.f;
         double S = 0.0, Q = 0.0;
 #pragma unroll
         for (int i = 0; i < GN_NCHW_SLABS; ++i)
@@ -381,8 +398,10 @@ __global__ void __launch_bounds__(GN_NT) gn_apply_nchw(const GnParams p) {
                 V8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float h = (float)r[u][j];
-                    o[j] = (T)finish<T, ACT>(p.add ? round_to<T>(h + t) : h, a, bb);
+                    float h = (float)r[u][j];
+                    if (p.pre) h = round_to<T>(h + pb);
+                    if (p.add) h = round_to<T>(h + t);
+                    o[j] = (T)finish<T, ACT>(h, a, bb);
                 }
                 if (k + u * TPR < cpr) *reinterpret_cast<V8 *>(y + (long)(k + u * TPR) * 8) = o;
             }
@@ -406,7 +425,7 @@ __global__ void __launch_bounds__(GN_NT) gn_group_nchw(const GnParams p) {
     const T *x = reinterpret_cast<const T *>(p.x) + ((long)b * p.C + (long)g * p.cg) * p.HW;
     T *y = reinterpret_cast<T *>(p.y) + ((long)b * p.C + (long)g * p.cg) * p.HW;
     V8 raw[MAXP];
-    float gm[MAXP], bt[MAXP], tt[MAXP];
+    float gm[MAXP], bt[MAXP], tt[MAXP], pp[MAXP];
     // piece j of a thread = (row rl + (j / kper) * RP, chunk k0 + (j % kper) * TPR)
 #pragma unroll
     for (int j = 0; j < MAXP; ++j) {
@@ -418,6 +437,7 @@ __global__ void __launch_bounds__(GN_NT) gn_group_nchw(const GnParams p) {
         gm[j] = p.gamma ? (float)reinterpret_cast<const T *>(p.gamma)[c] : 1.f;
         bt[j] = p.beta ? (float)reinterpret_cast<const T *>(p.beta)[c] : 0.f;
         tt[j] = p.add ? (float)reinterpret_cast<const T *>(p.add)[(long)b * p.add_stride + c] : 0.f;
+        pp[j] = p.pre ? (float)reinterpret_cast<const T *>(p.pre)[c] : 0.f;
     }
     float v[MAXP][8];
     float s = 0.f, q = 0.f;
@@ -428,6 +448,7 @@ __global__ void __launch_bounds__(GN_NT) gn_group_nchw(const GnParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float h = (float)raw[j][e];
+            if (p.pre) h = round_to<T>(h + pp[j]);
             if (p.add) h = round_to<T>(h + tt[j]);
             h = ok ? h : 0.f;
             v[j][e] = h;
@@ -551,7 +572,7 @@ size_t group_norm_workspace_bytes(const pww_gn_desc_t *d) {
     return pl.group ? 16 : pl.partial_bytes;
 }
 
-int group_norm_fwd(const void *x, const void *add_bc, const void *gamma, const void *beta, void *y, const pww_gn_desc_t *d,
+int group_norm_fwd(const void *x, const void *pre_c, const void *add_bc, const void *gamma, const void *beta, void *y, const pww_gn_desc_t *d,
                    void *workspace, size_t workspace_bytes, hipStream_t stream) {
     GnPlan pl;
     if (!x || !y || !d || !workspace) { set_error("group_norm: null argument"); return PWW_EINVAL; }
@@ -564,12 +585,12 @@ int group_norm_fwd(const void *x, const void *add_bc, const void *gamma, const v
     const size_t need = group_norm_workspace_bytes(d);
     if (workspace_bytes < need) { set_error("group_norm: workspace of %zu bytes, need %zu", workspace_bytes, need); return PWW_EINVAL; }
     const int add_stride = add_bc ? (d->add_stride > 0 ? d->add_stride : d->C) : 0;
-    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)workspace | (uintptr_t)add_bc | (uintptr_t)gamma | (uintptr_t)beta) & 15) || (add_stride & 7)) {
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)workspace | (uintptr_t)add_bc | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)pre_c) & 15) || (add_stride & 7)) {
         set_error("group_norm: pointers must be 16-byte aligned (and add_stride a multiple of 8)");
         return PWW_EINVAL;
     }
     GnParams p;
-    p.x = x; p.add = add_bc; p.gamma = gamma; p.beta = beta; p.y = y;
+    p.x = x; p.pre = pre_c; p.add = add_bc; p.gamma = gamma; p.beta = beta; p.y = y;
     p.partial = static_cast<double *>(workspace);
     p.B = d->B; p.C = d->C; p.HW = d->HW; p.G = d->G; p.cg = d->C / d->G;
     p.add_stride = add_stride;

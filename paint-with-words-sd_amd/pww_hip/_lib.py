@@ -22,7 +22,7 @@ EXPORTS = ("pww_version", "pww_last_error", "pww_device_arch", "pww_self_attn_fw
            "pww_qk_reduce", "pww_mask_build", "pww_mask_build_rgb", "pww_mask_build_f32", "pww_resize_tokens", "pww_gauss_blur", "pww_inpaint_prep", "pww_cfg_combine", "pww_store_f32",
            "pww_workspace_bytes", "pww_profile_arm", "pww_profile_elapsed_us", "pww_profile_reset", "pww_debug_timeline",
            "pww_qproj_stat", "pww_qproj_parts", "pww_cross_attn_fwd_parts", "pww_mask_build_f32_levels",
-           "pww_group_norm_fwd", "pww_group_norm_workspace_bytes")
+           "pww_group_norm_fwd", "pww_group_norm_workspace_bytes", "pww_add_layer_norm", "pww_geglu", "pww_bias_residual")
 
 
 class AttnDesc(ctypes.Structure):
@@ -52,6 +52,12 @@ class GnDesc(ctypes.Structure):
     """struct pww_gn_desc (GroupNorm + addend + activation)."""
     _fields_ = [("dtype", ctypes.c_int32), ("layout", ctypes.c_int32), ("B", ctypes.c_int32), ("C", ctypes.c_int32), ("HW", ctypes.c_int32),
                 ("G", ctypes.c_int32), ("eps", ctypes.c_float), ("act", ctypes.c_int32), ("add_stride", ctypes.c_int32), ("_pad", ctypes.c_int32)]
+
+
+class LnDesc(ctypes.Structure):
+    """struct pww_ln_desc (add + LayerNorm)."""
+    _fields_ = [("dtype", ctypes.c_int32), ("C", ctypes.c_int32), ("rows", ctypes.c_int64), ("a_stride", ctypes.c_int64), ("x_stride", ctypes.c_int64),
+                ("s_stride", ctypes.c_int64), ("y_stride", ctypes.c_int64), ("eps", ctypes.c_float), ("_pad", ctypes.c_int32)]
 
 
 class Region(ctypes.Structure):
@@ -100,8 +106,14 @@ def load():
     lib.pww_mask_build_f32_levels.restype = ctypes.c_int
     lib.pww_group_norm_workspace_bytes.argtypes = [ctypes.POINTER(GnDesc)]
     lib.pww_group_norm_workspace_bytes.restype = ctypes.c_size_t
-    lib.pww_group_norm_fwd.argtypes = [vp, vp, vp, vp, vp, ctypes.POINTER(GnDesc), vp, ctypes.c_size_t, vp]
+    lib.pww_group_norm_fwd.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.POINTER(GnDesc), vp, ctypes.c_size_t, vp]
     lib.pww_group_norm_fwd.restype = ctypes.c_int
+    lib.pww_add_layer_norm.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.POINTER(LnDesc), vp]
+    lib.pww_add_layer_norm.restype = ctypes.c_int
+    lib.pww_geglu.argtypes = [vp, vp, ctypes.c_int64, i32, ctypes.c_int64, ctypes.c_int64, i32, vp]
+    lib.pww_geglu.restype = ctypes.c_int
+    lib.pww_bias_residual.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.pww_bias_residual.restype = ctypes.c_int
     lib.pww_debug_timeline.argtypes = [vp, ctypes.c_size_t]
     lib.pww_debug_timeline.restype = None
     lib.pww_cross_fused_workspace_bytes.argtypes = [ctypes.POINTER(AttnDesc)]

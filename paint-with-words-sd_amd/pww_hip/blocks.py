@@ -13,7 +13,12 @@ Installed per INSTANCE (``module.forward = ...``; ``nn.Module.__call__`` and its
   and ``time_emb_proj(silu(temb))`` of all blocks as one GEMM per forward (``TembProjections``).
   Blocks this restatement does not cover (``upsample`` / ``downsample`` inside the block, ``time_embedding_norm != "default"``, a nonlinearity
   other than SiLU) keep their own forward.
+  The biases of ``conv1`` / ``conv2`` ride along as operands of the next fused op (``pre_bias`` of norm2, ``ops.bias_residual`` for the block's
+  output) instead of costing an add launch each.
 * every other ``nn.GroupNorm`` of the model (``Transformer2DModel.norm``, ``conv_norm_out``) -- the same kernels without addend / activation.
+* ``BasicTransformerBlock`` -- ``attn(norm(h)) + h`` and the block's NEXT LayerNorm as one launch (``ops.add_layer_norm``); ``GEGLU`` --
+  ``x * gelu(gate)`` as one launch behind its projection; 1 x 1 ``nn.Conv2d`` (``proj_in`` / ``proj_out`` / ``conv_shortcut``) on channels_last
+  tensors -- a GEMM over the ``[B H W, C]`` view with the bias in its epilogue.
 
 Inputs the kernels do not take (CPU tensors, fp32, a channel count that is not a multiple of 8 ...) go through the module's ORIGINAL forward:
 that is the stock op of the dependency, not a second implementation of this repository. On a GPU without the HIP library ``ops.group_norm``
@@ -30,6 +35,8 @@ from . import ops
 
 FUSED_NORM = os.environ.get("PWW_FUSED_NORM", "1") != "0"      # A/B switch (bench.py --no-fused-norm sets it)
 BATCHED_TEMB = os.environ.get("PWW_BATCHED_TEMB", "1") != "0"  # A/B switch: one time-embedding projection GEMM per forward for all blocks
+FOLD_CONV_BIAS = os.environ.get("PWW_FOLD_CONV_BIAS", "1") != "0"      # A/B: conv1 / conv2 biases of a ResnetBlock2D ride in the next fused op
+CONV1X1_AS_LINEAR = os.environ.get("PWW_CONV1X1_AS_LINEAR", "1") != "0"  # A/B: 1 x 1 convolutions on channels_last tensors as GEMMs
 
 
 def _takes(x, norm):
@@ -110,11 +117,23 @@ class TembProjections:
         return out
 
 
+def _conv_no_bias(conv, x):
+    """`conv(x)` without its bias (the caller hands the bias to the next fused op instead of paying an add launch for it)."""
+    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+def _plain_conv(conv):
+    return isinstance(conv, nn.Conv2d) and conv.bias is not None and conv.padding_mode == "zeros" and type(conv).forward is nn.Conv2d.forward \
+        and "forward" not in conv.__dict__ and not conv._forward_hooks and not conv._forward_pre_hooks
+
+
 def _resnet_forward(self, input_tensor, temb=None):
     """diffusers 0.10.0 ``ResnetBlock2D.forward`` (``up`` / ``down`` = False, ``time_embedding_norm == "default"``)."""
     if not _takes(input_tensor, self.norm1):
         return self._pww_orig_forward(input_tensor, temb)
-    h = self.conv1(fused_group_norm(self.norm1, input_tensor, act="silu"))
+    fold = FOLD_CONV_BIAS and _plain_conv(self.conv1) and _plain_conv(self.conv2) and self.conv1.bias.dtype == input_tensor.dtype
+    h = fused_group_norm(self.norm1, input_tensor, act="silu")
+    h = _conv_no_bias(self.conv1, h) if fold else self.conv1(h)
     add = None
     if temb is not None and getattr(self, "time_emb_proj", None) is not None:
         slot = self.__dict__.get("_pww_temb_slot")
@@ -124,16 +143,72 @@ def _resnet_forward(self, input_tensor, temb=None):
             add = self.time_emb_proj(F.silu(temb))
         if add.dtype != h.dtype:
             add = add.to(h.dtype)
-    h = fused_group_norm(self.norm2, h, add=add, act="silu")
+    if fold and _takes(h, self.norm2):
+        h = ops.group_norm(h, self.norm2.num_groups, self.norm2.weight, self.norm2.bias, self.norm2.eps, add=add, act="silu", pre_bias=self.conv1.bias)
+    else:
+        if fold:
+            h = h + self.conv1.bias[None, :, None, None]
+        h = fused_group_norm(self.norm2, h, add=add, act="silu")
     dropout = getattr(self, "dropout", None)
     if dropout is not None:
         h = dropout(h)
-    h = self.conv2(h)
     if getattr(self, "conv_shortcut", None) is not None:
         input_tensor = self.conv_shortcut(input_tensor)
-    out = input_tensor + h
     scale = getattr(self, "output_scale_factor", 1.0)
+    if fold and input_tensor.dtype == h.dtype and input_tensor.shape[1] % 8 == 0:
+        out = ops.bias_residual(input_tensor, _conv_no_bias(self.conv2, h), self.conv2.bias)          # input + (conv2(h) + bias): one launch
+    else:
+        out = input_tensor + self.conv2(h)
     return out if scale == 1.0 else out / scale
+
+
+# ---- 1 x 1 convolutions on channels_last tensors are GEMMs over the [B H W, C] view: bias in the GEMM's epilogue, no layout kernels ----
+def _conv1x1_forward(self, x):
+    if (FUSED_NORM and CONV1X1_AS_LINEAR and torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == self.weight.dtype
+            and x.shape[2] * x.shape[3] > 1 and x.is_contiguous(memory_format=torch.channels_last) and not torch.is_autocast_enabled()):
+        B, C, H, W = x.shape
+        y = F.linear(x.permute(0, 2, 3, 1).reshape(B * H * W, C), self.weight.reshape(self.out_channels, C), self.bias)
+        return y.view(B, H, W, self.out_channels).permute(0, 3, 1, 2)
+    return self._pww_orig_forward(x)
+
+
+def _is_conv1x1(m):
+    return (isinstance(m, nn.Conv2d) and type(m).forward is nn.Conv2d.forward and m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0)
+            and m.dilation == (1, 1) and m.groups == 1 and m.padding_mode == "zeros")
+
+
+# ---- BasicTransformerBlock / GEGLU -----------------------------------------------------------------------------------------------------
+def _ln_takes(x, norm):
+    return (FUSED_NORM and torch.is_tensor(x) and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.dim() >= 2
+            and len(norm.normalized_shape) == 1 and x.shape[-1] == norm.normalized_shape[0] and x.shape[-1] % 8 == 0 and x.shape[-1] <= 2048
+            and (norm.weight is None or norm.weight.dtype == x.dtype) and not torch.is_autocast_enabled()
+            and not (torch.is_grad_enabled() and (x.requires_grad or (norm.weight is not None and norm.weight.requires_grad))))
+
+
+def _transformer_block_covered(m):
+    return (all(isinstance(getattr(m, n, None), nn.LayerNorm) for n in ("norm1", "norm2", "norm3")) and hasattr(m, "attn1") and hasattr(m, "attn2")
+            and hasattr(m, "ff") and not getattr(m, "only_cross_attention", False))
+
+
+def _transformer_block_forward(self, hidden_states, context=None, **kwargs):
+    """diffusers 0.10.0 ``BasicTransformerBlock.forward``: ``h = attn1(norm1(h)) + h; h = attn2(norm2(h), context) + h; h = ff(norm3(h)) + h`` --
+    with each residual add and the NEXT norm as one launch."""
+    if kwargs or not _ln_takes(hidden_states, self.norm1):
+        return self._pww_orig_forward(hidden_states, context=context, **kwargs) if (kwargs or context is not None) else self._pww_orig_forward(hidden_states)
+    h = hidden_states
+    n = ops.add_layer_norm(h, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+    h, n = ops.add_layer_norm(h, self.norm2.weight, self.norm2.bias, self.norm2.eps, a=self.attn1(n))
+    h, n = ops.add_layer_norm(h, self.norm3.weight, self.norm3.bias, self.norm3.eps, a=self.attn2(n, context=context))
+    return self.ff(n) + h
+
+
+def _geglu_forward(self, x):
+    h = self.proj(x)
+    if FUSED_NORM and h.is_cuda and h.dtype in (torch.float16, torch.bfloat16) and h.shape[-1] % 16 == 0 and not torch.is_autocast_enabled() \
+            and not (torch.is_grad_enabled() and h.requires_grad):
+        return ops.geglu(h)
+    a, gate = h.chunk(2, dim=-1)
+    return a * F.gelu(gate)
 
 
 def install_blocks(unet):
@@ -154,12 +229,22 @@ def install_blocks(unet):
                     m.__dict__["_pww_temb_slot"] = plans.setdefault(lin.in_features, TembProjections()).register(m)
             owned.update((id(m.norm1), id(m.norm2)))
             n_res += 1
+    n_other = 0
     for m in unet.modules():
+        name, fwd = m.__class__.__name__, None
         if isinstance(m, nn.GroupNorm) and id(m) not in owned:
-            if "_pww_orig_forward" not in m.__dict__:
-                m.__dict__["_pww_orig_forward"] = m.forward
-                m.forward = types.MethodType(_group_norm_forward, m)
+            fwd = _group_norm_forward
             n_gn += 1
+        elif name == "BasicTransformerBlock" and _transformer_block_covered(m):
+            fwd = _transformer_block_forward
+        elif name == "GEGLU" and isinstance(getattr(m, "proj", None), nn.Linear):
+            fwd = _geglu_forward
+        elif _is_conv1x1(m):
+            fwd = _conv1x1_forward
+        if fwd is not None and "_pww_orig_forward" not in m.__dict__:
+            m.__dict__["_pww_orig_forward"] = m.forward
+            m.forward = types.MethodType(fwd, m)
+        n_other += fwd is not None and not isinstance(m, nn.GroupNorm)
     return n_res, n_gn
 
 

@@ -560,10 +560,10 @@ def group_norm_workspace(device, need=0):
     return ws
 
 
-def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, add=None, act=None, workspace=None, out=None):
+def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, add=None, act=None, workspace=None, out=None, pre_bias=None):
     """act(GroupNorm(x + add[:, :, None, None])) for a [B, C, H, W] float16 / bfloat16 tensor in NCHW-contiguous or channels_last memory
-    format (the output has x's format); `add` [B, C] (unit stride along C; rows may be views into a wider tensor) or None; act None |
-    "silu". SURVEY.md section 8 row a17 (diffusers 0.10.0 ResnetBlock2D / Transformer2DModel, the callers of the patched CrossAttention).
+    format (the output has x's format); `add` [B, C] (unit stride along C; rows may be views into a wider tensor) or None; `pre_bias` [C] or
+    None: a per-channel addend applied, and rounded, before `add` (the bias of the convolution that produced x); act None | "silu". SURVEY.md section 8 row a17 (diffusers 0.10.0 ResnetBlock2D / Transformer2DModel, the callers of the patched CrossAttention).
     One scratch `workspace` per device serves every call made on ONE stream (launches serialise there); a caller that runs norms on several
     streams at once passes its own uint8 buffer."""
     _require_gpu(x)
@@ -581,11 +581,12 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, add=None, act=No
         out = torch.empty_like(x)     # (preserves the memory format)
     elif out.shape != x.shape or out.dtype != x.dtype or out.stride() != x.stride():
         raise PwwHipError("group_norm: `out` must have x's shape, dtype and strides")
-    for name, t, shape in (("weight", weight, (C,)), ("bias", bias, (C,)), ("add", add, (B, C))):
+    for name, t, shape in (("weight", weight, (C,)), ("bias", bias, (C,)), ("add", add, (B, C)), ("pre_bias", pre_bias, (C,))):
         if t is not None and (t.dtype != x.dtype or tuple(t.shape) != shape or t.device != x.device):
             raise PwwHipError("group_norm: `%s` must be %s %s on %s (got %s %s)" % (name, x.dtype, shape, x.device, t.dtype, tuple(t.shape)))
     weight = weight.contiguous() if weight is not None else None
     bias = bias.contiguous() if bias is not None else None
+    pre_bias = pre_bias.contiguous() if pre_bias is not None else None
     add_stride = 0
     if add is not None:
         if add.stride(1) != 1 or add.stride(0) % 8 != 0 or add.data_ptr() % 16 != 0:
@@ -601,7 +602,94 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, add=None, act=No
                           "groups <= 32, C <= 4096 in channels_last)" % (B, C, H * W, num_groups))
     ws = workspace if workspace is not None else group_norm_workspace(x.device, need)
     with torch.cuda.device(x.device):
-        _lib.check(lib.pww_group_norm_fwd(_ptr(x), _ptr(add) if add is not None else None, _ptr(weight) if weight is not None else None,
+        _lib.check(lib.pww_group_norm_fwd(_ptr(x), _ptr(pre_bias) if pre_bias is not None else None, _ptr(add) if add is not None else None,
+                                          _ptr(weight) if weight is not None else None,
                                           _ptr(bias) if bias is not None else None, _ptr(out), ctypes.byref(d), _ptr(ws), ws.numel(), _stream()),
                    "pww_group_norm_fwd")
     return out
+
+
+def _rows(t, name):
+    """[..., C] tensor as rows: (rows, C, row stride) -- unit stride along C, ONE stride between consecutive rows."""
+    if t.dtype not in _DT or t.dim() < 2:
+        raise PwwHipError("%s: a float16/bfloat16 tensor of at least two dims is needed (got %s %s)" % (name, t.dtype, tuple(t.shape)))
+    if t.stride(-1) != 1 or t.stride(-2) % 8 != 0 or t.data_ptr() % 16 != 0:
+        return None                                 # (the caller makes it contiguous: e.g. the [B, HW, C] view of an NCHW tensor)
+    C = t.shape[-1]
+    rows = t.numel() // C
+    stride = t.stride(-2)
+    exp = stride
+    for d in range(t.dim() - 2, -1, -1):          # every leading dim must continue the same row pitch
+        if t.shape[d] != 1 and t.stride(d) != exp:
+            return None
+        exp *= t.shape[d]
+    return rows, C, stride
+
+
+def add_layer_norm(x, weight, bias, eps, a=None):
+    """LayerNorm over the last dim of x ([..., C]); with `a` (same shape): s = a + x, returns (s, LayerNorm(s)) from ONE launch -- the
+    `attn(norm(h)) + h` of diffusers' BasicTransformerBlock together with the block's next norm. Without `a`: returns LayerNorm(x)."""
+    _require_gpu(x)
+    rx = _rows(x, "add_layer_norm")
+    if rx is None:
+        x = x.contiguous()
+        rx = _rows(x, "add_layer_norm")
+    rows, C, xs = rx
+    ra = None
+    if a is not None:
+        if a.shape != x.shape or a.dtype != x.dtype:
+            raise PwwHipError("add_layer_norm: `a` must have x's shape and dtype")
+        ra = _rows(a, "add_layer_norm")
+        if ra is None:
+            a = a.contiguous()
+            ra = _rows(a, "add_layer_norm")
+    for name, t in (("weight", weight), ("bias", bias)):
+        if t is not None and (t.dtype != x.dtype or tuple(t.shape) != (C,) or not t.is_contiguous()):
+            raise PwwHipError("add_layer_norm: `%s` must be a contiguous %s [%d]" % (name, x.dtype, C))
+    y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    s = torch.empty(x.shape, dtype=x.dtype, device=x.device) if a is not None else None
+    d = _lib.LnDesc(_DT[x.dtype], C, rows, ra[2] if ra else 0, xs, C, C, float(eps), 0)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().pww_add_layer_norm(_ptr(a) if a is not None else None, _ptr(x), _ptr(weight) if weight is not None else None,
+                                                  _ptr(bias) if bias is not None else None, _ptr(s) if s is not None else None, _ptr(y),
+                                                  ctypes.byref(d), _stream()), "pww_add_layer_norm")
+    return (s, y) if a is not None else y
+
+
+def geglu(h):
+    """h[..., :D] * gelu(h[..., D:]) for the output of GEGLU's projection (diffusers FeedForward.net[0]); erf form of gelu."""
+    _require_gpu(h)
+    r = _rows(h, "geglu")
+    if r is None:
+        h = h.contiguous()
+        r = _rows(h, "geglu")
+    rows, C2, hs = r
+    if C2 % 16 != 0:
+        raise PwwHipError("geglu: the last dim must be 2 * D with D a multiple of 8 (got %d)" % C2)
+    D = C2 // 2
+    y = torch.empty(h.shape[:-1] + (D,), dtype=h.dtype, device=h.device)
+    with torch.cuda.device(h.device):
+        _lib.check(_lib.load().pww_geglu(_ptr(h), _ptr(y), rows, D, hs, D, _DT[h.dtype], _stream()), "pww_geglu")
+    return y
+
+
+def bias_residual(residual, value, bias):
+    """residual + (value + bias[None, :, None, None]) for [B, C, H, W] tensors of ONE memory format (NCHW-contiguous or channels_last), the two
+    roundings of the stock sequence kept; one launch."""
+    _require_gpu(residual, value, bias)
+    if residual.shape != value.shape or residual.dtype != value.dtype or residual.dtype not in _DT or residual.dim() != 4 or bias.dtype != residual.dtype:
+        raise PwwHipError("bias_residual: two same-shape 4-d float16/bfloat16 tensors and a bias of that type are needed")
+    B, C, H, W = residual.shape
+    if residual.is_contiguous() and value.is_contiguous():
+        layout = _lib.LAYOUT_NCHW
+    elif residual.is_contiguous(memory_format=torch.channels_last) and value.is_contiguous(memory_format=torch.channels_last):
+        layout = _lib.LAYOUT_NHWC
+    else:
+        value = value.contiguous(memory_format=torch.channels_last) if residual.is_contiguous(memory_format=torch.channels_last) else value.contiguous()
+        residual = residual if residual.stride() == value.stride() else residual.contiguous(memory_format=torch.channels_last if value.is_contiguous(memory_format=torch.channels_last) else torch.contiguous_format)
+        layout = _lib.LAYOUT_NCHW if value.is_contiguous() else _lib.LAYOUT_NHWC
+    y = torch.empty_like(value)
+    with torch.cuda.device(value.device):
+        _lib.check(_lib.load().pww_bias_residual(_ptr(residual), _ptr(value), _ptr(bias.contiguous()), _ptr(y), B, C, H * W, layout, _DT[value.dtype], _stream()),
+                   "pww_bias_residual")
+    return y

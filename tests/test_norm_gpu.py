@@ -168,3 +168,110 @@ def test_resnet_block_and_transformer_norm_through_the_plug(channels_last):
         # (the stock convolutions are not bit-repeatable run to run: DESIGN.md section 2)
         assert (res(x, temb).float() - want.float()).abs().max().item() <= 4 * ULP[torch.bfloat16] * 4 * spread
     assert pww_hip.blocks is blocks
+
+
+# ---- elementwise glue of the same blocks (csrc/pww_blocks.hip) ------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 4096, 320), (2, 1024, 640), (2, 256, 1280), (16, 64, 1280), (3, 50, 1288), (1, 7, 2048), (5, 8)])
+def test_add_layer_norm_matches_the_stock_sequence(shape, dtype):
+    """s = a + x and LayerNorm(s) from one launch: s bit-equal to the stock add; the norm within one rounding step of an fp32 LayerNorm of
+    that s (and of the stock half-precision LayerNorm); strided rows (a column slice of a wider tensor) give the same bits."""
+    from pww_hip import ops
+    g = torch.Generator(device="cpu").manual_seed(sum(shape))
+    C = shape[-1]
+    x = (torch.randn(shape, generator=g) * 2.0 + 0.3).to(DEV, dtype)
+    a = torch.randn(shape, generator=g).to(DEV, dtype)
+    w = (1.0 + 0.2 * torch.randn(C, generator=g)).to(DEV, dtype)
+    b = (0.1 * torch.randn(C, generator=g)).to(DEV, dtype)
+    s, y = ops.add_layer_norm(x, w, b, 1e-5, a=a)
+    assert torch.equal(s, a + x)
+    ref = F.layer_norm(s.float(), (C,), w.float(), b.float(), 1e-5).to(dtype)
+    assert _close(y, ref, dtype)[0] == 0
+    assert _close(y, F.layer_norm(s, (C,), w, b, 1e-5), dtype, steps=2)[0] == 0
+    y0 = ops.add_layer_norm(s, w, b, 1e-5)
+    assert torch.equal(y0, y)                                   # plain form on the same rows: same arithmetic
+    wide = torch.zeros(shape[:-1] + (C + 24,), device=DEV, dtype=dtype)
+    wide[..., 8:8 + C] = x
+    s2, y2 = ops.add_layer_norm(wide[..., 8:8 + C], w, b, 1e-5, a=a)
+    assert torch.equal(s2, s) and torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 4096, 2560), (2, 256, 10240), (16, 64, 10240), (3, 5, 48)])
+def test_geglu_matches_the_stock_sequence(shape, dtype):
+    from pww_hip import ops
+    g = torch.Generator(device="cpu").manual_seed(shape[1])
+    h = (torch.randn(shape, generator=g) * 1.5).to(DEV, dtype)
+    y = ops.geglu(h)
+    xa, gate = h.chunk(2, dim=-1)
+    stock = xa * F.gelu(gate)
+    ref = (xa.float() * F.gelu(gate.float()).to(dtype).float()).to(dtype)
+    assert y.shape == stock.shape and _close(y, ref, dtype)[0] == 0 and _close(y, stock, dtype)[0] == 0
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_bias_residual_is_the_stock_sequence_bit_for_bit(channels_last):
+    from pww_hip import ops
+    g = torch.Generator(device="cpu").manual_seed(4)
+    for dtype in (torch.bfloat16, torch.float16):
+        for shape in ((2, 320, 64, 64), (2, 1280, 8, 8), (3, 64, 4, 2)):
+            r = torch.randn(shape, generator=g).to(DEV, dtype)
+            v = torch.randn(shape, generator=g).to(DEV, dtype)
+            bias = torch.randn(shape[1], generator=g).to(DEV, dtype)
+            if channels_last:
+                r, v = r.contiguous(memory_format=torch.channels_last), v.contiguous(memory_format=torch.channels_last)
+            y = ops.bias_residual(r, v, bias)
+            assert y.stride() == v.stride() and torch.equal(y, r + (v + bias[None, :, None, None]))
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_transformer_model_through_the_plug(channels_last):
+    """Transformer2DModel of the stand-in (GroupNorm -> 1x1 proj_in -> BasicTransformerBlock{LayerNorms, attn1, attn2, GEGLU feed-forward} ->
+    1x1 proj_out -> residual) with install(): every fused op is taken (and the attention runs on the HIP path), the output stays within the
+    half-precision noise of the unplugged module."""
+    import pww_hip
+    from pww_hip import blocks
+    from sd_standin import unet as U
+    torch.manual_seed(5)
+    tm = U.Transformer2DModel(8, 40, 320, 768).to(DEV, torch.bfloat16).eval().requires_grad_(False)
+    x = torch.randn(2, 320, 32, 32, device=DEV).to(torch.bfloat16)
+    ctx = torch.randn(2, 77, 768, device=DEV).to(torch.bfloat16)
+    if channels_last:
+        tm.to(memory_format=torch.channels_last)
+        x = x.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        pww_hip.uninstall(tm)
+        want = tm(x, ctx)
+        pww_hip.install(tm)
+        seen = []
+        names = ("group_norm", "add_layer_norm", "geglu")
+        orig = {n: getattr(blocks.ops, n) for n in names}
+        for n in names:
+            setattr(blocks.ops, n, (lambda n: lambda *a, **k: (seen.append(n), orig[n](*a, **k))[1])(n))
+        try:
+            got = tm(x, ctx)
+        finally:
+            for n in names:
+                setattr(blocks.ops, n, orig[n])
+            pww_hip.uninstall(tm)
+        assert seen == ["group_norm", "add_layer_norm", "add_layer_norm", "add_layer_norm", "geglu"]
+        assert got.shape == want.shape and got.stride() == want.stride()
+        assert (got.float() - want.float()).abs().max().item() <= 3e-2 * want.float().abs().max().item()
+        assert "forward" not in tm.proj_in.__dict__ and "forward" not in tm.transformer_blocks[0].__dict__
+
+
+def test_conv1x1_as_gemm_on_channels_last():
+    from pww_hip import blocks
+    torch.manual_seed(6)
+    conv = nn.Conv2d(320, 640, 1).to(DEV, torch.bfloat16)
+    holder = nn.ModuleList([conv])
+    x = torch.randn(2, 320, 16, 16, device=DEV).to(torch.bfloat16)
+    xcl = x.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        want = conv(xcl)
+        blocks.install_blocks(holder)
+        got = conv(xcl)
+        assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+        assert (got.float() - want.float()).abs().max().item() <= 2 * ULP[torch.bfloat16] * want.float().abs().max().item()
+        assert torch.equal(conv(x), conv._pww_orig_forward(x))              # NCHW input: the convolution itself
+        blocks.uninstall_blocks(holder)
