@@ -342,10 +342,11 @@ def test_one_graph_serves_thirty_steps_and_the_fallback_still_works(gpu_device):
 @pytest.mark.parametrize("shape,dtype,B", [("sd15_n4096", torch.bfloat16, 2), ("sd15_n4096", torch.float16, 16), ("sd15_n1024", torch.float16, 16),
                                            ("sd15_n256", torch.bfloat16, 2), ("sd21_n576", torch.bfloat16, 6)])
 def test_bias_hints_do_not_change_a_bit(gpu_device, shape, dtype, B):
-    """pww_cross_attn_fwd_fused_ex: the bias rows of a query block staged in LDS from the dense map (all columns, or only
-    those below the column bound) or from the compact [N, R] + col_idx form give bit-identical outputs -- and the same as
-    the per-lane global loads of round 2 would (checked natively, tests/native/attn_check.cpp). The gated-images hint (right or
-    wrong) only moves work between workgroups."""
+    """pww_cross_attn_fwd_fused_ex: the bias rows of a query block staged in LDS from the dense map (only the columns below the
+    column bound) or from the compact [N, R] + col_idx form give bit-identical outputs; the gated-images hint (right or wrong) only
+    moves work between workgroups. Against the call WITHOUT hints (per-lane global bias loads: since round 4 the only form that keeps
+    the general online softmax step, the staged forms run the first-tile / lazy steps) and against the two-launch path the outputs agree
+    to the last bit or two of the storage type -- the same mathematics in another rounding order (tests/native/attn_check.cpp too)."""
     from pww_hip import ops
     case = cases.make_attention_case(shape)
     N, C, H = case["N"], case["C"], case["H"]
@@ -359,7 +360,10 @@ def test_bias_hints_do_not_change_a_bit(gpu_device, shape, dtype, B):
     gate = torch.cat([torch.ones(B // 2), torch.zeros(B - B // 2)]).to(gpu_device)
     run = lambda **kw: ops.attention(q, k, v, H, (C // H) ** -0.5, bias=w, bias_coeff=gate, stat=(None, ops.STAT_MAX, 0.37),    # noqa: E731
                                      scratch=ops.FusedScratch(), **kw)
-    base = run()
+    plain = run()
+    base = run(bias_cols=32)
+    last_bits = lambda a, b: (a.float() - b.float()).abs().max().item() <= (2.0 ** -9 if dtype == torch.float16 else 2.0 ** -6) * b.float().abs().max().item()    # noqa: E731
+    assert last_bits(base, plain)
     idx = torch.cat([cols.to(torch.int32), torch.full((8 - cols.numel() % 8,), -1, dtype=torch.int32, device=gpu_device)])
     wc = torch.zeros((N, idx.numel()), device=gpu_device)
     wc[:, :cols.numel()] = w[:, cols]
@@ -371,7 +375,7 @@ def test_bias_hints_do_not_change_a_bit(gpu_device, shape, dtype, B):
         out = run(**kw)
         assert torch.equal(out, base), (name, (out.float() - base.float()).abs().max().item())
     two = ops.attention(q, k, v, H, (C // H) ** -0.5, bias=w, bias_coeff=gate, stat=(ops.qk_stats(q, k, H), ops.STAT_MAX, 0.37))
-    assert torch.equal(two, base)
+    assert last_bits(base, two)
 
 
 def test_opt_in_compact_maps_through_the_product(gpu_device, monkeypatch):

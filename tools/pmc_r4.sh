@@ -30,7 +30,8 @@ for case in sorted(os.listdir(out)):
         m['dispatches'] = max(len(v) for v in d.values())
         g = m.get('GRBM_GUI_ACTIVE')
         if g and 'SQ_VALU_MFMA_BUSY_CYCLES' in m:
-            m['mfma_busy_frac'] = m['SQ_VALU_MFMA_BUSY_CYCLES'] / (g * 1024.0)          # 256 CUs x 4 SIMDs
+            m['kernel_cycles'] = g / 8.0                                                  # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+            m['mfma_busy_frac'] = m['SQ_VALU_MFMA_BUSY_CYCLES'] / (g / 8.0 * 1024.0)    # 256 CUs x 4 SIMDs
         if 'SQ_WAVE_CYCLES' in m:
             for c in ('SQ_ACTIVE_INST_ANY', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY'):
                 if c in m: m[c + '_frac_of_wave_cycles'] = m[c] / m['SQ_WAVE_CYCLES']
