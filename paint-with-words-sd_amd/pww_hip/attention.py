@@ -35,7 +35,18 @@ FUSED_CROSS = os.environ.get("PWW_FUSED_CROSS", "1") != "0" and os.environ.get("
 # Default since round 4: the statistic's partials come out of the to_q GEMM's epilogue (pww_qproj_stat) and the attention launch folds them
 # at entry (pww_cross_attn_fwd_parts) -- no in-kernel hand-off, nothing has to be resident, no time-out path. 0 = the round-3 launch
 # (pww_cross_attn_fwd_fused: statistic + hand-off inside the attention kernel), kept as the A/B baseline and for shapes the GEMM does not cover.
-QPROJ_STAT = os.environ.get("PWW_QPROJ_STAT", "1") != "0"
+QPROJ_STAT = os.environ.get("PWW_QPROJ_STAT", "1")       # "1" where it wins (default) | "0" never | "all" wherever the kernel supports the shape
+
+
+def qproj_route(C, D):
+    """Does `to_q` + statistic as ONE launch beat stock GEMM + the round-3 fused launch for a layer of C channels and head dim D?
+    Per-shape measurement, both routes back to back on MI355X (profiles/r04_qproj.md): the projection kernel's tile is a whole number of
+    heads in 160 channels, so it keeps up with hipBLASLt for C = 320 (every head dim) and for C = 640 when 160 % D == 0 (SD1.5: +5 us on the
+    GEMM, -8 on the attention); wider layers meet too few workgroups and a long contraction (C = 1280: tie at 2 rows x 256 tokens, -4 us at
+    64 tokens), SD2.1's C = 640 / d = 64 needs 320-channel tiles (+10 us on the GEMM)."""
+    if QPROJ_STAT == "all":
+        return True
+    return QPROJ_STAT != "0" and (C <= 320 or (C <= 640 and 160 % D == 0))
 _warned = set()
 
 
@@ -654,7 +665,7 @@ def pww_attention(attn, hidden_states, context=None):
         have_stats = bias.stat is not None and bias.stat._proxy._stats is not None
         # Q and the statistic's partials from ONE launch (the to_q GEMM with the score statistic in its epilogue): taken when the weight
         # function left both untouched (nobody asked for the query or the statistics as tensors) and the GEMM covers the shape
-        if (QPROJ_STAT and lazy_q is not None and not lazy_q.done and not have_stats and kind != ops.STAT_NONE and pdt in _HALF
+        if (qproj_route(hidden_states.shape[-1], hidden_states.shape[-1] // attn.heads) and lazy_q is not None and not lazy_q.done and not have_stats and kind != ops.STAT_NONE and pdt in _HALF
                 and key.dtype == pdt and key.shape[1] <= ops.FUSED_MAX_KEYS and getattr(attn.to_q, "bias", None) is None):
             wq = _fused_weight(attn, ("to_q",), pdt)
             x = hidden_states if hidden_states.dtype == pdt else hidden_states.to(pdt)

@@ -637,3 +637,15 @@ def test_batched_time_embedding_projection_tracks_its_source_weights():
         for lin in lins:
             lin.double()
         assert torch.allclose(plan.project(t64)[:, 0:8], lins[0](F.silu(t64)), atol=1e-12)
+
+
+def test_qproj_route_follows_the_measured_table(monkeypatch):
+    """attention.qproj_route: `to_q` + statistic as one launch only where profiles/r04_qproj.md says the route wins."""
+    import pww_hip.attention as A
+    monkeypatch.setattr(A, "QPROJ_STAT", "1")
+    assert A.qproj_route(320, 40) and A.qproj_route(320, 64) and A.qproj_route(640, 80)           # SD1.5 N = 4096 / SD2.1 N = 9216 / SD1.5 N = 1024
+    assert not A.qproj_route(640, 64) and not A.qproj_route(1280, 160) and not A.qproj_route(1280, 64)
+    monkeypatch.setattr(A, "QPROJ_STAT", "all")
+    assert A.qproj_route(1280, 64)
+    monkeypatch.setattr(A, "QPROJ_STAT", "0")
+    assert not A.qproj_route(320, 40)

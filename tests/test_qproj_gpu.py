@@ -116,9 +116,9 @@ def test_product_path_with_and_without_the_gemm_epilogue_statistic(gpu_device, s
     for wname, wf in cases.WEIGHT_FUNCTIONS.items():
         ctx = {"CONTEXT_TENSOR": case["ctx"].to(gpu_device, dtype), f"CROSS_ATTENTION_WEIGHT_{N}": case["w"].to(gpu_device),
                "SIGMA": torch.tensor(7.84), "WEIGHT_FUNCTION": wf, "_PWW_ROW_GATE": torch.tensor([1.0, 1.0], device=gpu_device)}
-        monkeypatch.setattr(A, "QPROJ_STAT", True)
+        monkeypatch.setattr(A, "QPROJ_STAT", "all")
         a = pww_hip.inj_forward(mod, hidden, dict(ctx)).float()
-        monkeypatch.setattr(A, "QPROJ_STAT", False)
+        monkeypatch.setattr(A, "QPROJ_STAT", "0")
         b = pww_hip.inj_forward(mod, hidden, dict(ctx)).float()
         scale = b.abs().max().item()
         d = (a - b).abs().max().item()

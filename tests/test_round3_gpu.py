@@ -285,7 +285,7 @@ def test_sampler_raises_on_a_set_error_word(gpu_device, monkeypatch):
             assert not sampler.handoff_pending        # (the request above was checked before its latents came back)
             # (the 1/8-width UNet's channel counts -- 32 / 64 / 128 -- have no pww_qproj_stat tile, so its layers take the round-3 launch
             # either way; the full-size models take the GEMM-epilogue route: test_qproj_gpu.py)
-            monkeypatch.setattr(A, "QPROJ_STAT", False)
+            monkeypatch.setattr(A, "QPROJ_STAT", "0")
             pw.paint_with_words(color_context=dict(cases.RUNNER_CONTEXT), return_latents=True, **kw)
             scr = [m.__dict__["_pww_fused_scratch"] for m in tools[1].modules() if "_pww_fused_scratch" in m.__dict__]
             assert len(scr) >= 3
