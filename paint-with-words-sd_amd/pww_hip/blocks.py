@@ -215,9 +215,6 @@ def install_blocks(unet):
     """Put the fused norms under every ``ResnetBlock2D`` and every other ``nn.GroupNorm`` of `unet`. Returns (resnets, norms) patched."""
     n_res = n_gn = 0
     owned = set()
-    dev = next((p.device for p in unet.parameters()), None)
-    if dev is not None and dev.type == "cuda":
-        ops.group_norm_workspace(dev)            # allocated now: never inside a hipGraph capture
     plans = {}                 # time-embedding width -> one batched projection for all blocks that share it
     for m in unet.modules():
         if m.__class__.__name__ == "ResnetBlock2D" and _resnet_covered(m):
@@ -229,7 +226,6 @@ def install_blocks(unet):
                     m.__dict__["_pww_temb_slot"] = plans.setdefault(lin.in_features, TembProjections()).register(m)
             owned.update((id(m.norm1), id(m.norm2)))
             n_res += 1
-    n_other = 0
     for m in unet.modules():
         name, fwd = m.__class__.__name__, None
         if isinstance(m, nn.GroupNorm) and id(m) not in owned:
@@ -244,7 +240,6 @@ def install_blocks(unet):
         if fwd is not None and "_pww_orig_forward" not in m.__dict__:
             m.__dict__["_pww_orig_forward"] = m.forward
             m.forward = types.MethodType(fwd, m)
-        n_other += fwd is not None and not isinstance(m, nn.GroupNorm)
     return n_res, n_gn
 
 

@@ -540,32 +540,12 @@ def cfg_combine(cond, uncond, guidance_scale):
 
 
 # ---- GroupNorm (+ per-(image, channel) addend, + SiLU) of the blocks that call the attention path ------------------------------------
-_GN_WORKSPACE = {}          # device index -> scratch for the partial sums (every launch writes what it reads: no initial state)
-_GN_WORKSPACE_BYTES = 4 << 20
-
-
-def group_norm_workspace(device, need=0):
-    """The device's shared group_norm scratch (created on first use; `blocks.install_blocks` creates it up front so that a hipGraph capture
-    never allocates it)."""
-    device = torch.device(device)
-    index = device.index if device.index is not None else torch.cuda.current_device()
-    ws = _GN_WORKSPACE.get(index)
-    if ws is None or ws.numel() < need:
-        if torch.cuda.is_current_stream_capturing():
-            raise PwwHipError("group_norm: the workspace must exist before a hipGraph capture (call ops.group_norm_workspace(device) first)")
-        with torch.cuda.device(index):
-            torch.cuda.synchronize()           # (a larger replacement: nothing may still be reading the old one)
-            ws = torch.empty(max(_GN_WORKSPACE_BYTES, int(need)), dtype=torch.uint8, device=torch.device("cuda", index))
-        _GN_WORKSPACE[index] = ws
-    return ws
-
-
 def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, add=None, act=None, workspace=None, out=None, pre_bias=None):
     """act(GroupNorm(x + add[:, :, None, None])) for a [B, C, H, W] float16 / bfloat16 tensor in NCHW-contiguous or channels_last memory
     format (the output has x's format); `add` [B, C] (unit stride along C; rows may be views into a wider tensor) or None; `pre_bias` [C] or
     None: a per-channel addend applied, and rounded, before `add` (the bias of the convolution that produced x); act None | "silu". SURVEY.md section 8 row a17 (diffusers 0.10.0 ResnetBlock2D / Transformer2DModel, the callers of the patched CrossAttention).
-    One scratch `workspace` per device serves every call made on ONE stream (launches serialise there); a caller that runs norms on several
-    streams at once passes its own uint8 buffer."""
+    The scratch for the partial sums (<= 1 MB; none for the single-launch form) comes from the caching allocator per call -- stream-ordered,
+    so concurrent streams never share it and a hipGraph capture takes it from the graph's pool -- unless the caller passes `workspace`."""
     _require_gpu(x)
     if x.dim() != 4 or x.dtype not in _DT:
         raise PwwHipError("group_norm needs a 4-d float16/bfloat16 tensor (got %s %s)" % (tuple(x.shape), x.dtype))
@@ -600,7 +580,7 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, add=None, act=No
     if need == 0:
         raise PwwHipError("group_norm: unsupported shape B %d C %d HW %d groups %d (C and H*W multiples of 8, C %% groups == 0, "
                           "groups <= 32, C <= 4096 in channels_last)" % (B, C, H * W, num_groups))
-    ws = workspace if workspace is not None else group_norm_workspace(x.device, need)
+    ws = workspace if workspace is not None else torch.empty(int(need), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(lib.pww_group_norm_fwd(_ptr(x), _ptr(pre_bias) if pre_bias is not None else None, _ptr(add) if add is not None else None,
                                           _ptr(weight) if weight is not None else None,
@@ -680,14 +660,10 @@ def bias_residual(residual, value, bias):
     if residual.shape != value.shape or residual.dtype != value.dtype or residual.dtype not in _DT or residual.dim() != 4 or bias.dtype != residual.dtype:
         raise PwwHipError("bias_residual: two same-shape 4-d float16/bfloat16 tensors and a bias of that type are needed")
     B, C, H, W = residual.shape
-    if residual.is_contiguous() and value.is_contiguous():
-        layout = _lib.LAYOUT_NCHW
-    elif residual.is_contiguous(memory_format=torch.channels_last) and value.is_contiguous(memory_format=torch.channels_last):
-        layout = _lib.LAYOUT_NHWC
-    else:
-        value = value.contiguous(memory_format=torch.channels_last) if residual.is_contiguous(memory_format=torch.channels_last) else value.contiguous()
-        residual = residual if residual.stride() == value.stride() else residual.contiguous(memory_format=torch.channels_last if value.is_contiguous(memory_format=torch.channels_last) else torch.contiguous_format)
-        layout = _lib.LAYOUT_NCHW if value.is_contiguous() else _lib.LAYOUT_NHWC
+    nhwc = value.is_contiguous(memory_format=torch.channels_last) and not value.is_contiguous()
+    fmt = torch.channels_last if nhwc else torch.contiguous_format
+    value, residual = value.contiguous(memory_format=fmt), residual.contiguous(memory_format=fmt)       # (no-ops when both already are)
+    layout = _lib.LAYOUT_NHWC if nhwc else _lib.LAYOUT_NCHW
     y = torch.empty_like(value)
     with torch.cuda.device(value.device):
         _lib.check(_lib.load().pww_bias_residual(_ptr(residual), _ptr(value), _ptr(bias.contiguous()), _ptr(y), B, C, H * W, layout, _DT[value.dtype], _stream()),
