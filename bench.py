@@ -183,6 +183,13 @@ class EventTimer:
             return self._timed(key, fn, (x, weight, k, heads, kind), dict(gate=gate), kernel_only=True)
         return wrapped
 
+    def wrap_qkparts(self, fn):
+        """the statistic's partials over a finished Q (pww_qk_parts: the layers whose to_q stays the stock GEMM): kernel-only"""
+        def wrapped(q, k, heads, kind, gate=None, gated=0):
+            key = ("qk_parts", q.shape[0], q.shape[1], k.shape[1], q.shape[2] // heads, heads, k.shape[0])
+            return self._timed(key, fn, (q, k, heads, kind), dict(gate=gate, gated=gated), kernel_only=True)
+        return wrapped
+
     def wrap_stats(self, fn):
         def wrapped(q, k, heads):
             key = ("qk_reduce", q.shape[0], q.shape[1], k.shape[1], q.shape[2] // heads, heads, k.shape[0])
@@ -249,11 +256,11 @@ def replay_us(call, reps=40):
 def kernel_row(kind, us, B, N, M, D, Hh, Bk, elem_bytes, launches, label=None):
     C = Hh * D
     names = {"qk_reduce": "qk_reduce (ticket init + reduce)", "cross+stat": "cross (attention with the statistic: folded partials, or formed in the launch)",
-             "qproj+stat": "to_q GEMM + score-statistic partials (pww_qproj_stat)"}
+             "qproj+stat": "to_q GEMM + score-statistic partials (pww_qproj_stat)", "qk_parts": "score-statistic partials over the finished Q (pww_qk_parts)"}
     if kind == "qproj+stat":      # (Bk carries Cin here) algorithmic: the GEMM alone -- the score blocks of the epilogue are not counted
         flops = 2.0 * B * N * C * Bk
         nbytes = elem_bytes * (B * N * Bk + B * N * C + C * Bk)
-    elif kind == "qk_reduce":
+    elif kind in ("qk_reduce", "qk_parts"):
         flops = 2.0 * B * Hh * N * M * D
         nbytes = elem_bytes * (B * N * C + Bk * M * C)
     else:
@@ -634,8 +641,9 @@ def main():
         # instrumented pass (same workload, folded mode so single launches can be bracketed by HIP events
         # on the launch stream): dominant kernel = self-attention at the finest resolution
         timer = EventTimer()
-        orig, orig_stats, orig_mask, orig_cfg, orig_qproj = ops.attention, ops.qk_stats, ops.mask_build, ops.cfg_combine, ops.qproj_stat
+        orig, orig_stats, orig_mask, orig_cfg, orig_qproj, orig_qkparts = ops.attention, ops.qk_stats, ops.mask_build, ops.cfg_combine, ops.qproj_stat, ops.qk_parts
         ops.attention, ops.qk_stats, ops.qproj_stat = timer.wrap_attention(orig), timer.wrap_stats(orig_stats), timer.wrap_qproj(orig_qproj)
+        ops.qk_parts = timer.wrap_qkparts(orig_qkparts)
         # K4: reads the RGB map once per resolution, writes the [N_r, 77] fp32 maps; CFG combine: 2 half reads + 1 fp32 write
         ops.mask_build = timer.wrap_stream("mask_build", orig_mask, lambda rgb, regions, cols, ratios=(8, 16, 32, 64):
                                            sum(rgb.numel() + (-(-rgb.shape[0] // r)) * (-(-rgb.shape[1] // r)) * len(cols) * 4 for r in ratios))
@@ -644,13 +652,24 @@ def main():
         try:
             one_step(0)
         finally:
-            ops.attention, ops.qk_stats, ops.mask_build, ops.cfg_combine, ops.qproj_stat = orig, orig_stats, orig_mask, orig_cfg, orig_qproj
+            ops.attention, ops.qk_stats, ops.mask_build, ops.cfg_combine, ops.qproj_stat, ops.qk_parts = orig, orig_stats, orig_mask, orig_cfg, orig_qproj, orig_qkparts
             pw_api.DEFAULT_MODE = args.mode
         H, W = request["rgb"].shape[:2]
         n_dom = (H // 8) * (W // 8)
         us_situ, n_launch, b_rows = timer.mean_us(lambda k: k[0] == "self" and k[2] == n_dom)
         result["kernels"] = timer.table(2)
         dom = [r for r in result["kernels"] if r["kernel"] == "self" and r.get("N") == n_dom]
+        # the attention path per UNet forward (everything outside the dominant launch <= 400 us): sum over the launch classes of
+        # kernel-only time x launches of the instrumented pass / its UNet forwards (one forward = the 5 dominant launches)
+        if dom and dom[0]["launches"]:
+            fw = dom[0]["launches"] / 5.0
+            attn_rows = [r for r in result["kernels"] if "N" in r]
+            tot = lambda rows, f: round(sum(r[f] * r["launches"] for r in rows if r.get(f) is not None) / fw, 1)      # noqa: E731
+            others = [r for r in attn_rows if r is not dom[0]]
+            result["attention_path"] = {"unet_forwards_in_pass": fw, "dominant_us_per_forward": tot(dom[:1], "avg_us"), "others_us_per_forward": tot(others, "avg_us"),
+                                        "others_us_per_forward_back_to_back": tot(others, "avg_us_back_to_back"),
+                                        "method": "sum over the pww launch classes of the instrumented eager pass: kernel-only duration x launches / UNet forwards (to_q GEMMs of "
+                                                  "the stock library are not pww launches and not counted; pww_qproj_stat, which contains its GEMM, is)"}
         us_b2b = dom[0]["avg_us_back_to_back"] if dom else None     # hipGraph replay of 40 back-to-back launches, event interval / 40 (incl. the dispatch gaps)
         # the roofline number: the kernel's own start -> end device timestamps (HIP events stamped by the dispatch itself,
         # pww_profile_arm) averaged over every launch of the dominant class in the workload pass above -- what rocprofv3

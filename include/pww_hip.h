@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define PWW_VERSION 123 /* 0.1.23: pww_group_norm_fwd / pww_group_norm_workspace_bytes, pww_add_layer_norm, pww_geglu, pww_bias_residual (norms and elementwise glue of the blocks that call the attention path); 0.1.22: pww_qproj_stat / pww_qproj_parts / pww_cross_attn_fwd_parts (score statistic formed in the to_q GEMM's epilogue), pww_mask_build_f32_levels, PWW_STAT_ALL; 0.1.21: pww_cross_opts_t.gated_images (was padding); 0.1.20: + pww_cross_attn_fwd_fused_ex / pww_cross_attn_fwd_stat_ex (pww_cross_opts_t: device-side coefficient word, bias column bound,
+#define PWW_VERSION 124 /* 0.1.24: pww_qk_parts / pww_qk_parts_count (statistic partials over a finished Q; pww_cross_attn_fwd_parts takes the small one-block-per-workgroup kernel where it fits); 0.1.23: pww_group_norm_fwd / pww_group_norm_workspace_bytes, pww_add_layer_norm, pww_geglu, pww_bias_residual (norms and elementwise glue of the blocks that call the attention path); 0.1.22: pww_qproj_stat / pww_qproj_parts / pww_cross_attn_fwd_parts (score statistic formed in the to_q GEMM's epilogue), pww_mask_build_f32_levels, PWW_STAT_ALL; 0.1.21: pww_cross_opts_t.gated_images (was padding); 0.1.20: + pww_cross_attn_fwd_fused_ex / pww_cross_attn_fwd_stat_ex (pww_cross_opts_t: device-side coefficient word, bias column bound,
                            compact bias), pww_debug_timeline (0.1.11: pww_profile_*; 0.1.10: fused cross-attention, blur, resize, inpaint prep) */
 
 #define PWW_OK 0
@@ -250,6 +250,24 @@ int32_t pww_qproj_parts(const pww_qproj_desc_t *desc);
 int pww_cross_attn_fwd_parts(const void *q, const void *k, const void *v, void *o, const float *bias, int32_t stat_kind,
                              float coeff_scalar, const float *gate, const pww_attn_desc_t *desc, const double *partials,
                              int32_t nparts, double *stats_out, const pww_cross_opts_t *opts, void *stream);
+
+/*
+ * The statistic's partials over a FINISHED Q (version >= 124): what pww_qproj_stat's epilogue forms, for the layers whose to_q stays the
+ * stock GEMM (SD1.5 / SD2.1 at C = 1280: the projection kernel meets too few workgroups there). paint_with_words.py:87 + the global
+ * reduction weight_function applies to `qk` (:402-405 qk.max(); runner.py:104; README.md:152 qk.std()). One wave per (image, head, 32-row
+ * block, 32-key block): loads -> MFMAs -> one fp64 partial; no LDS, no barrier, no atomics, nothing waits for another workgroup.
+ *   q, k      as in pww_attn_desc_t (only dtype, B / H / N / M / D and the q / k strides of the descriptor are read), M any
+ *   gate      fp32 [B] or NULL: images with gate[b] == 0 get no partials (their rows of `partials` are left untouched)
+ *   stat_kind PWW_STAT_* (PWW_STAT_ALL: all four fields): only the fields that statistic is made of are formed, the others hold the
+ *             neutral element
+ *   gated_images  the caller's hint that gate[b] != 0 exactly for b < gated_images (0 = unknown): the grid then covers those images only
+ *   partials  double [B][pww_qk_parts_count(desc)][4] = { max, min, sum, sum of squares }, 16-byte aligned: the input of
+ *             pww_cross_attn_fwd_parts
+ * Sums accumulate in fp32 over a lane's 16 scores and in fp64 from there (within 1e-6, relative, of pww_qk_reduce).
+ */
+int pww_qk_parts(const void *q, const void *k, const float *gate, const pww_attn_desc_t *desc, int32_t stat_kind, int32_t gated_images,
+                 double *partials, size_t partials_bytes, void *stream);
+int32_t pww_qk_parts_count(const pww_attn_desc_t *desc);
 
 /*
  * GroupNorm of the UNet blocks that call the attention path, fused with the elementwise neighbours those callers put around it

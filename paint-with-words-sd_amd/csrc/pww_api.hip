@@ -31,7 +31,8 @@ const DebugKnobs &debug_knobs() {
             {"attn_rf", &k.attn_rf}, {"attn_ksplit", &k.attn_ksplit}, {"attn_fold", &k.attn_fold}, {"attn_nw8", &k.attn_nw8},
             {"attn_pair_major", &k.attn_pair_major}, {"attn_wide_store", &k.attn_wide_store}, {"cross_wg_per_cu", &k.cross_wg_per_cu},
             {"cross_assume_resident", &k.cross_assume_resident}, {"cross_gate_weight", &k.cross_gate_weight},
-            {"cross_tile_nbuf", &k.cross_tile_nbuf}, {"cross_bias_lds", &k.cross_bias_lds}};
+            {"cross_tile_nbuf", &k.cross_tile_nbuf}, {"cross_bias_lds", &k.cross_bias_lds}, {"cross_lean", &k.cross_lean},
+            {"cross_lean_nw", &k.cross_lean_nw}, {"attn_ksplit_nw", &k.attn_ksplit_nw}};
         const char *p = e;
         while (*p) {
             const char *eq = strchr(p, '='), *end = strchr(p, ',');
@@ -160,10 +161,13 @@ size_t qk_reduce_workspace_bytes(const pww_attn_desc_t *d);
 int cross_attn_fused(const void *q, const void *k, const void *v, void *o, const float *bias, int stat_kind, float coeff_scalar,
                      const float *gate, const pww_attn_desc_t *d, double *stats_out, void *state, size_t state_bytes,
                      void *workspace, size_t workspace_bytes, const pww_cross_opts_t *opts, hipStream_t stream,
-                     const double *ext_part = nullptr, int ext_nparts = 0);
+                     const double *ext_part = nullptr, int ext_nparts = 0, bool pass2_only = false);
 int qproj_stat(const void *x, const void *w, void *q, const void *k, const float *gate, const pww_qproj_desc_t *d, int stat_kind,
                double *partials, size_t partials_bytes, hipStream_t stream);
 int qproj_parts(const pww_qproj_desc_t *d);
+int qk_parts(const void *q, const void *k, const float *gate, const pww_attn_desc_t *d, int stat_kind, int gated_images, double *partials,
+             size_t partials_bytes, hipStream_t stream);
+int qk_parts_count(const pww_attn_desc_t *d);
 int mask_build_f32_levels(const float *masks, int H, int W, int R, const int32_t *col_ptr, const int32_t *col_reg, int T,
                           float *out8, float *out16, float *out32, float *out64, hipStream_t stream);
 size_t cross_fused_workspace_bytes(const pww_attn_desc_t *d);
@@ -255,12 +259,19 @@ int pww_qproj_stat(const void *x, const void *w, void *q, const void *k, const f
 
 int32_t pww_qproj_parts(const pww_qproj_desc_t *desc) { return pww::qproj_parts(desc); }
 
+int pww_qk_parts(const void *q, const void *k, const float *gate, const pww_attn_desc_t *desc, int32_t stat_kind, int32_t gated_images,
+                 double *partials, size_t partials_bytes, void *stream) {
+    return pww::qk_parts(q, k, gate, desc, stat_kind, gated_images, partials, partials_bytes, static_cast<hipStream_t>(stream));
+}
+
+int32_t pww_qk_parts_count(const pww_attn_desc_t *desc) { return pww::qk_parts_count(desc); }
+
 int pww_cross_attn_fwd_parts(const void *q, const void *k, const void *v, void *o, const float *bias, int32_t stat_kind,
                              float coeff_scalar, const float *gate, const pww_attn_desc_t *desc, const double *partials,
                              int32_t nparts, double *stats_out, const pww_cross_opts_t *opts, void *stream) {
-    if (!partials) { pww::set_error("pww_cross_attn_fwd_parts: null partials"); return PWW_EINVAL; }
+    if (!partials && stat_kind != PWW_STAT_NONE) { pww::set_error("pww_cross_attn_fwd_parts: null partials"); return PWW_EINVAL; }
     return pww::cross_attn_fused(q, k, v, o, bias, stat_kind, coeff_scalar, gate, desc, stats_out, nullptr, 0, nullptr, 0, opts,
-                                 static_cast<hipStream_t>(stream), partials, nparts);
+                                 static_cast<hipStream_t>(stream), partials, partials ? nparts : 0, true);
 }
 
 int pww_mask_build_f32_levels(const float *masks, int32_t H, int32_t W, int32_t R, const int32_t *col_ptr, const int32_t *col_reg,

@@ -782,6 +782,10 @@ static int launch_attn(const AttnParams &p, hipStream_t stream) {
         // every SIMD and half the serial stage count
         const long wgs = (long)((p.N + 63) / 64) * p.B * p.H;
         if (ksplit_mode() == 1 && wgs <= 256 && p.M >= 512) {
+            if (debug_knobs().attn_ksplit_nw == 4) {      // A/B: 4 row groups x 2 key groups (half the workgroups, half the K / V staging traffic, 2 waves per SIMD on half the CUs)
+                if ((p.D & 31) != 0) return launch_attn_ksplit<T, KS, DT, 4, 2, true>(p, stream);
+                return launch_attn_ksplit<T, KS, DT, 4, 2, false>(p, stream);
+            }
             if ((p.D & 31) != 0) return launch_attn_ksplit<T, KS, DT, 2, 2, true>(p, stream);
             return launch_attn_ksplit<T, KS, DT, 2, 2, false>(p, stream);
         }

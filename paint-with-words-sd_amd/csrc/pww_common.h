@@ -59,6 +59,9 @@ struct DebugKnobs {
     int cross_gate_weight = 2;     // cost of a gated-in image's query block in units of a gated-out one's (1: ignore the hint)
     int cross_tile_nbuf = 2;       // 1: never double-buffer the bias tile
     int cross_bias_lds = 2;        // bias rows: 0 per lane from global memory / 1 LDS tile in single-block launches only / 2 LDS tile everywhere
+    int cross_lean = 1;            // pass-2-only launches on the small kernel (pww_cross_lean.hip): 0 never / 1 where it fits (default) / 2 also for large batches
+    int cross_lean_nw = 0;         // waves per workgroup of that kernel: 0 by problem size / 2 / 4
+    int attn_ksplit_nw = 2;        // row groups of the key-split d = 80 / 96 self-attention workgroup: 2 (x 2 key groups) or 4 (x 2)
 };
 const DebugKnobs &debug_knobs();
 

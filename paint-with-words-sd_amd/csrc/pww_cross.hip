@@ -28,6 +28,7 @@
 // a launch that could not be made resident takes the two-launch path instead -- same result, bit for bit.
 #include <string.h>
 #include "pww_attn_core.h"
+#include "pww_cross_tile.h"
 
 namespace pww {
 
@@ -56,6 +57,7 @@ struct CrossParams {
     // hand-off, no residency requirement, Q read once -- the kernel boundary was the synchronisation.
     const double *ext_part;
     int ext_nparts;
+    int pass2_only;      // host side: the launch has no hand-off (external partials, or no statistic asked for through pww_cross_attn_fwd_parts): any grid is correct
 };
 
 constexpr unsigned long long SPIN_LIMIT_TICKS = 100000000ull;   // wall_clock64 runs at 100 MHz: 1 s (the grid is sized to be resident:
@@ -72,20 +74,6 @@ __device__ __forceinline__ unsigned long long slot_read(const unsigned long long
 }
 __device__ __forceinline__ double slot_value(unsigned long long x) { return __longlong_as_double((long long)~x); }
 
-// Q fragments through a buffer descriptor: UNCONDITIONAL loads (validity goes into the offset: an out-of-range offset returns zeros).
-// A load under an `if` -- rows past N, fragment halves past D -- sits in its own basic block and hipcc then waits for everything in
-// flight at the join: a prefetch issued that way is no prefetch (the query-block loops of this kernel ran one exposed global-load
-// latency per block until round 3). row_off = byte offset of the lane's row within the (image, head) slice, or OOB_OFF.
-template <typename T, int KS, typename SRD>
-__device__ __forceinline__ void load_q_frags_buf(typename Vec<T>::v8 (&qf)[KS], SRD srd, unsigned row_off, int hi, int D) {
-    typedef typename Vec<T>::v8 V8;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int d0 = ks * 16 + hi * 8;
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srd, d0 < D ? row_off + (unsigned)d0 * 2u : OOB_OFF, 0, 0);
-        qf[ks] = __builtin_bit_cast(V8, v);
-    }
-}
 // acc + x * x with the product rounded before the sum: what the select form `acc += live ? x * x : 0` compiles to here and in
 // pww_qk_reduce (the select keeps hipcc from contracting it into an fma); the statistics of the two paths are compared bit for bit.
 __device__ __forceinline__ float add_square_unfused(float acc, float x) {
@@ -738,6 +726,9 @@ int qk_reduce(const void *q, const void *k, const pww_attn_desc_t *d, double *st
               hipStream_t stream);
 size_t qk_reduce_workspace_bytes(const pww_attn_desc_t *d);
 bool attn_wide_groups(const pww_attn_desc_t *d);
+int cross_attn_lean(const void *q, const void *k, const void *v, void *o, const float *bias, int stat_kind, float coeff_scalar, const float *gate,
+                    const pww_attn_desc_t *d, double *stats_out, const pww_cross_opts_t &op, hipStream_t stream, const double *parts, int nparts,
+                    bool *launched);
 
 static int current_device() { int dev = 0; return hipGetDevice(&dev) == hipSuccess ? dev : -1; }
 
@@ -823,7 +814,7 @@ static int launch_cross(CrossParams cp, hipStream_t stream, bool *launched) {
     const long BH = (long)p.B * p.H;
     cp.nqb = (p.N + NW * 32 - 1) / (NW * 32);
     const long cap = (long)per_cu * device_cus();
-    const bool ext = cp.ext_part != nullptr;      // partials came with Q: nothing waits for another workgroup, any grid is correct
+    const bool ext = cp.pass2_only != 0;      // partials came with Q (or none are needed): nothing waits for another workgroup, any grid is correct
     if (cap < BH && !ext) { *launched = false; return PWW_OK; }      // cannot be made resident: the caller takes the two-launch path
     long nchunk = cap / BH;
     if (nchunk < 1) nchunk = 1;
@@ -916,10 +907,11 @@ static int bias_tile_mode() {
 int cross_attn_fused(const void *q, const void *k, const void *v, void *o, const float *bias, int stat_kind, float coeff_scalar,
                      const float *gate, const pww_attn_desc_t *d, double *stats_out, void *state, size_t state_bytes,
                      void *workspace, size_t workspace_bytes, const pww_cross_opts_t *opts, hipStream_t stream,
-                     const double *ext_part, int ext_nparts) {
+                     const double *ext_part, int ext_nparts, bool pass2_only) {
     if (int rc = attn_validate(q, k, v, o, bias, d)) return rc;
-    const bool ext = ext_part != nullptr;
-    if (ext && (ext_nparts < 1 || (reinterpret_cast<uintptr_t>(ext_part) & 15) || (long)ext_nparts * 32 >= (1L << 31))) {
+    const bool ext = pass2_only;
+    if (ext && !ext_part && stat_kind != PWW_STAT_NONE) { set_error("cross_attn_parts: a statistic needs its partials"); return PWW_EINVAL; }
+    if (ext && ext_part && (ext_nparts < 1 || (reinterpret_cast<uintptr_t>(ext_part) & 15) || (long)ext_nparts * 32 >= (1L << 31))) {
         set_error("cross_attn_parts: partials must be 16-byte aligned, 1 <= nparts (got %d)", ext_nparts);
         return PWW_EINVAL;
     }
@@ -952,6 +944,12 @@ int cross_attn_fused(const void *q, const void *k, const void *v, void *o, const
             return PWW_EINVAL;
         }
     }
+    if (ext || stat_kind == PWW_STAT_NONE) {
+        // nothing in this launch waits for another workgroup: the small one-block-per-workgroup kernel (pww_cross_lean.hip) where it fits
+        bool lean = false;
+        if (int rc = cross_attn_lean(q, k, v, o, bias, stat_kind, coeff_scalar, gate, d, stats_out, op, stream, ext_part, ext_nparts, &lean)) return rc;
+        if (lean) return PWW_OK;
+    }
     CrossParams cp;
     attn_fill_params(cp.a, q, k, v, o, bias, gate, d);
     cp.a.bias_coeff = gate;     // (attn_fill_params drops the coefficient pointer when the dense map is absent)
@@ -960,7 +958,7 @@ int cross_attn_fused(const void *q, const void *k, const void *v, void *o, const
     cp.a.bias_cols = bias_cols;
     cp.sync = ext ? nullptr : reinterpret_cast<unsigned *>(state);
     cp.slots = ext ? nullptr : reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(state) + state_sync_bytes(d));
-    cp.ext_part = ext_part; cp.ext_nparts = ext ? ext_nparts : 0;
+    cp.ext_part = ext ? ext_part : nullptr; cp.ext_nparts = (ext && ext_part) ? ext_nparts : 0; cp.pass2_only = ext ? 1 : 0;
     cp.stats_out = stats_out;
     cp.nqb = cp.nchunk = cp.nchunk_u = 0;
     cp.n_gated = op.gated_images > 0 && op.gated_images < d->B ? op.gated_images : 0;

@@ -1,0 +1,481 @@
+// The product path's cross-attention launches since round 5: two SMALL kernels with short dependent chains.
+//
+//   qk_parts_kernel     partials of the per-image score statistic over a FINISHED Q (paint_with_words/paint_with_words.py:87 + the global
+//                       reduction weight_function applies to `qk`: :402-405 qk.max(), runner.py:104, README.md:152 qk.std()) -- for the
+//                       layers whose to_q stays the stock GEMM (C = 1280 in SD1.5 / SD2.1: pww_qproj.hip meets too few workgroups there).
+//                       One wave per (image, head, 32-row block, 32-key block): 2 KS 16-byte loads per lane, KS MFMAs, one fp64 partial.
+//                       No LDS, no barrier, no atomics: load -> MFMA -> reduce -> store.
+//   cross_lean_kernel   O = softmax((Q K^T + c[b] w) scale) V over the prompt tokens (:106-116) with c[b] = c0 * stat(fold(partials[b])) * gate[b]:
+//                       the pass-2-only form of pww_cross.hip (partials folded at entry, the kernel boundary is the synchronisation), ONE query
+//                       block per workgroup.
+//
+// Why a second kernel instead of the general one (pww_cross.hip, cross_fused_kernel: pass 1, in-kernel hand-off, several blocks per
+// workgroup, compact bias, four pass-2 forms): that kernel is 56 - 82 KB of code per instantiation and 310 of its 340 MFMAs (d = 160) sat
+// directly behind an `s_waitcnt lgkmcnt(0)` -- at the 2 folded rows of a batch-1 request every launch is ONE dependent chain per wave
+// (entry -> loads -> LDS -> scores -> softmax -> PV -> store, 1 wave per SIMD, nothing to overlap with), and the chain paid an LDS zero-fill
+// pass with its own barrier, an fp64 fold through LDS with two more barriers and an exposed LDS latency per MFMA: 12.6 us for 1.3 MB of
+// traffic (N = 256). Here: every global load of the workgroup is issued before anything is waited for; K / V padding arrives as
+// out-of-range zeros instead of a fill pass; every wave folds the partials itself (shuffles only); bias rows are wave-private (no barrier);
+// K fragments are requested ahead of the MFMAs (pww_tile.h score_tile); ONE barrier in the kernel; ~15 KB of code.
+// Large batches (several query blocks per workgroup pay off: configs 3 / 4) and everything this kernel does not take (compact bias, maps
+// wider than 64 columns, M < 64, > 256 + tail partials) keep the general kernel -- same arithmetic, same results to the last few bits.
+#include <string.h>
+#include "pww_attn_core.h"
+#include "pww_cross_tile.h"
+
+namespace pww {
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// qk_parts: statistic partials over a finished Q
+// ------------------------------------------------------------------------------------------------------------------------------------
+struct QkPartsParams {
+    const void *q, *k;
+    const float *gate;        // [B] or null
+    double *partials;         // [B][nparts][4]
+    int B, H, N, M, D;
+    long q_sb, q_sh, q_sn, k_sb, k_sh, k_sm;
+    int nrb, nkb, nparts;     // 32-row blocks, 32-key blocks, partials per image = H * nrb * nkb
+    int n_img;                // images the grid covers (the hinted-in ones first)
+    int fields;               // bit 0 max, 1 min, 2 sum, 3 sum of squares
+};
+
+template <typename T, int KS>
+__global__ void __launch_bounds__(256) qk_parts_kernel(const QkPartsParams p) {
+    typedef typename Vec<T>::v8 V8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const long unit = (long)blockIdx.x * 4 + wave;
+    const int b = __builtin_amdgcn_readfirstlane((int)(unit / p.nparts));        // (wave-uniform: scalars, so that the descriptors below are)
+    if (b >= p.n_img) return;
+    const int u = __builtin_amdgcn_readfirstlane((int)(unit - (long)b * p.nparts));
+    // unit -> (head, row block, key block): key blocks fastest (the waves of a workgroup share a Q block), heads slowest
+    const int kb = __builtin_amdgcn_readfirstlane(u % p.nkb), rb = __builtin_amdgcn_readfirstlane((u / p.nkb) % p.nrb), h = __builtin_amdgcn_readfirstlane(u / (p.nkb * p.nrb));
+    const float gate = p.gate ? p.gate[b] : 1.f;                  // requested with everything else, looked at before the store
+    const T *Qp = reinterpret_cast<const T *>(p.q) + b * p.q_sb + h * p.q_sh;
+    const T *Kp = reinterpret_cast<const T *>(p.k) + b * p.k_sb + h * p.k_sh;
+    const auto srd_q = head_srd(Qp, p.N, p.q_sn, p.D);
+    const auto srd_k = head_srd(Kp, p.M, p.k_sm, p.D);
+    const int qrow = rb * 32 + l31, krow = kb * 32 + swap23(l31);
+    V8 qf[KS], kf[KS];
+    load_q_frags_buf<T, KS>(qf, srd_q, qrow < p.N ? (unsigned)((long)qrow * p.q_sn * 2) : OOB_OFF, hi, p.D);
+    load_q_frags_buf<T, KS>(kf, srd_k, krow < p.M ? (unsigned)((long)krow * p.k_sm * 2) : OOB_OFF, hi, p.D);
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) s = mfma32(kf[ks], qf[ks], s);
+    // register r = key kb * 32 + 16 (r >> 3) + 8 hi + (r & 7) of row qrow. Rows past N / keys past M were loaded as zeros: their scores
+    // are exactly 0 and leave the sums alone; the extremes take them out with a select.
+    const bool rvalid = qrow < p.N;
+    float vmax = -INFINITY, vmin = INFINITY, vsum = 0.f, vsq = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const bool live = rvalid && kb * 32 + 16 * (r >> 3) + 8 * hi + (r & 7) < p.M;
+        const float x = s[r];
+        vmax = fmaxf(vmax, live ? x : -INFINITY);
+        vmin = fminf(vmin, live ? x : INFINITY);
+        vsum += x;
+        vsq = fmaf(x, x, vsq);
+    }
+    double dsum = (double)vsum, dsq = (double)vsq;
+    if (p.fields & 1) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+    }
+    if (p.fields & 2) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) vmin = fminf(vmin, __shfl_xor(vmin, off));
+    }
+    if (p.fields & 4) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) dsum += __shfl_xor(dsum, off);
+    }
+    if (p.fields & 8) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) dsq += __shfl_xor(dsq, off);
+    }
+    if (lane == 0 && gate != 0.f) {       // (a gated-out image's rows are left untouched, like pww_qproj_stat)
+        double *out = p.partials + ((long)b * p.nparts + u) * 4;
+        out[0] = (p.fields & 1) ? (double)vmax : -INFINITY;
+        out[1] = (p.fields & 2) ? (double)vmin : INFINITY;
+        out[2] = (p.fields & 4) ? dsum : 0.0;
+        out[3] = (p.fields & 8) ? dsq : 0.0;
+    }
+}
+
+int qk_parts_count(const pww_attn_desc_t *d) {
+    if (!d || d->B <= 0 || d->H <= 0 || d->N <= 0 || d->M <= 0 || d->D <= 0 || d->D % 8 || d->D > PWW_MAX_HEAD_DIM) return 0;
+    const long n = (long)d->H * ((d->N + 31) / 32) * ((d->M + 31) / 32);
+    return n > 0x7fffffffL ? 0 : (int)n;
+}
+
+static int stat_fields(int stat_kind) {
+    switch (stat_kind) {
+        case PWW_STAT_NONE: return 0;
+        case PWW_STAT_MAX: return 1;
+        case PWW_STAT_MIN: return 2;
+        case PWW_STAT_ABSMAX: return 3;
+        case PWW_STAT_MEAN: return 4;
+        case PWW_STAT_STD: return 12;
+        case PWW_STAT_ALL: return 15;
+        default: return -1;
+    }
+}
+
+int qk_parts(const void *q, const void *k, const float *gate, const pww_attn_desc_t *d, int stat_kind, int gated_images, double *partials,
+             size_t partials_bytes, hipStream_t stream) {
+    if (!q || !k || !d || !partials) { set_error("qk_parts: null argument"); return PWW_EINVAL; }
+    if (!arch_ok()) return PWW_ENOTSUP;
+    if (d->dtype != PWW_DTYPE_F16 && d->dtype != PWW_DTYPE_BF16) { set_error("qk_parts: dtype %d unsupported", d->dtype); return PWW_ENOTSUP; }
+    const int nparts = qk_parts_count(d);
+    if (nparts <= 0) { set_error("qk_parts: unsupported problem (B=%d H=%d N=%d M=%d D=%d; D a multiple of 8, <= %d)", d->B, d->H, d->N, d->M, d->D, PWW_MAX_HEAD_DIM); return PWW_ENOTSUP; }
+    const int fields = stat_fields(stat_kind);
+    if (fields <= 0) { set_error("qk_parts: bad statistic selector %d", stat_kind); return PWW_EINVAL; }
+    if ((reinterpret_cast<uintptr_t>(q) & 15) || (reinterpret_cast<uintptr_t>(k) & 15) || (reinterpret_cast<uintptr_t>(partials) & 15)) {
+        set_error("qk_parts: q, k and partials must be 16-byte aligned");
+        return PWW_EINVAL;
+    }
+    for (int i = 0; i < 3; ++i)
+        if (d->q_stride[i] % 8 || d->k_stride[i] % 8) { set_error("qk_parts: strides must be multiples of 8 elements"); return PWW_EINVAL; }
+    if (d->q_stride[2] < d->D || d->k_stride[2] < d->D || ((long)d->N * d->q_stride[2] + d->D) * 2 >= (1L << 31) || ((long)d->M * d->k_stride[2] + d->D) * 2 >= (1L << 31)) {
+        set_error("qk_parts: one head's Q / K extent must be < 2 GiB and rows must not overlap");
+        return PWW_EINVAL;
+    }
+    if (partials_bytes < (size_t)d->B * nparts * 4 * sizeof(double)) { set_error("qk_parts: partials buffer too small (need %zu bytes)", (size_t)d->B * nparts * 4 * sizeof(double)); return PWW_EINVAL; }
+    QkPartsParams p;
+    p.q = q; p.k = k; p.gate = gate; p.partials = partials;
+    p.B = d->B; p.H = d->H; p.N = d->N; p.M = d->M; p.D = d->D;
+    p.q_sb = d->q_stride[0]; p.q_sh = d->q_stride[1]; p.q_sn = d->q_stride[2];
+    p.k_sb = d->k_stride[0]; p.k_sh = d->k_stride[1]; p.k_sm = d->k_stride[2];
+    p.nrb = (d->N + 31) / 32; p.nkb = (d->M + 31) / 32; p.nparts = nparts;
+    p.n_img = (gate && gated_images > 0 && gated_images < d->B) ? gated_images : d->B;
+    p.fields = fields;
+    const long units = (long)p.n_img * nparts;
+    const dim3 grid((unsigned)((units + 3) / 4));
+#define PWW_QKP(T)                                                                                     \
+    do {                                                                                               \
+        const int ks = (d->D + 15) / 16;                                                               \
+        if (ks <= 3) launch_attn_kernel(qk_parts_kernel<T, 3>, grid, dim3(256), 0, stream, p);         \
+        else if (ks == 4) launch_attn_kernel(qk_parts_kernel<T, 4>, grid, dim3(256), 0, stream, p);    \
+        else if (ks == 5) launch_attn_kernel(qk_parts_kernel<T, 5>, grid, dim3(256), 0, stream, p);    \
+        else if (ks == 6) launch_attn_kernel(qk_parts_kernel<T, 6>, grid, dim3(256), 0, stream, p);    \
+        else if (ks <= 8) launch_attn_kernel(qk_parts_kernel<T, 8>, grid, dim3(256), 0, stream, p);    \
+        else launch_attn_kernel(qk_parts_kernel<T, 10>, grid, dim3(256), 0, stream, p);                \
+    } while (0)
+    if (d->dtype == PWW_DTYPE_F16) PWW_QKP(f16); else PWW_QKP(bf16);
+#undef PWW_QKP
+    return check_hip(hipGetLastError(), "qk_parts_kernel launch");
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// cross_lean: pass-2-only cross-attention, one query block per workgroup
+// ------------------------------------------------------------------------------------------------------------------------------------
+struct LeanParams {
+    AttnParams a;             // a.bias_coeff = the row gate [B] (or null)
+    const double *parts;      // [B][nparts][4] or null (stat_kind == NONE)
+    int nparts;
+    double *stats_out;        // optional [B][4]
+    int nqb;                  // query blocks per (image, head)
+    int tile_stride;          // floats per LDS tile row (16 / 32 / 64: bias_cols rounded up to a power of two)
+};
+
+constexpr int LEAN_PUNROLL = 4;        // partials per lane folded from the prologue's load batch (256 per image); more take the tail loop
+constexpr int LEAN_TILE_LOADS = 8;     // 16-byte pieces per lane of a wave's 32 bias rows: 64 columns at most
+
+template <typename T, int KS, int DT, int NW>
+__global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_lean_kernel(const LeanParams lp) {
+    typedef typename Vec<T>::v8 V8;
+    typedef KTile<KS> KT;
+    typedef VTile<DT> VT;
+    constexpr bool RSM = KS * 16 < DT * 32;      // padding channels in the V tile: channel D is a column of ones, the PV MFMAs deliver the row sums
+    constexpr int NT = NW * 64;
+    constexpr int SUB_BYTES = KT::BYTES + VT::BYTES;
+    constexpr int STAGE_BYTES = 2 * SUB_BYTES;
+    constexpr int KPT = (2 * KT::NCHUNK + NT - 1) / NT;
+    constexpr int VPT = (2 * VT::NCHUNK + NT - 1) / NT;
+    const AttnParams &p = lp.a;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [K|V stage: two 64-key sub-tiles][bias tile: NW x 32 rows]
+    char *tile = smem + STAGE_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int BH = p.B * p.H;
+    tl_stamp(p, 0);
+    // workgroup -> (image, head, query block): query block c on XCD c % 8 for every head (the heads of an image share the bias rows of a block)
+    // (readfirstlane: the integer divisions run on the vector ALU, and behind the debug stamp's divergent branch hipcc no longer proves their
+    // results uniform -- every buffer descriptor built from b / h would then be loaded through a waterfall loop)
+    int bh, qb;
+    if ((lp.nqb & 7) == 0) { const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3; bh = j % BH; qb = (j / BH) * 8 + xcd; }
+    else { bh = blockIdx.x % BH; qb = blockIdx.x / BH; }
+    bh = __builtin_amdgcn_readfirstlane(bh);
+    qb = __builtin_amdgcn_readfirstlane(qb);
+    const int b = __builtin_amdgcn_readfirstlane(bh / p.H), h = bh - b * p.H;
+
+    // ---- every global load of the workgroup, before anything is waited for: gate, partials, Q fragments, K / V chunks, bias rows
+    const float gate = p.bias_coeff ? p.bias_coeff[b] : 1.f;
+    const float c0 = coeff_scalar_of(p);
+    const bool maybe_biased = p.bias != nullptr;      // (from the kernel arguments alone: a gated-out image requests its bias rows in vain -- a few KB from L2)
+    const bool need_stat = p.stat_kind != PWW_STAT_NONE;
+    const bool f_all = lp.stats_out != nullptr;
+    const bool f_max = f_all || p.stat_kind == PWW_STAT_MAX || p.stat_kind == PWW_STAT_ABSMAX;
+    const bool f_min = f_all || p.stat_kind == PWW_STAT_MIN || p.stat_kind == PWW_STAT_ABSMAX;
+    const bool f_sum = f_all || p.stat_kind == PWW_STAT_MEAN || p.stat_kind == PWW_STAT_STD;
+    const bool f_sq = f_all || p.stat_kind == PWW_STAT_STD;
+    const bool want_lo = need_stat && (f_max || f_min), want_hi = need_stat && (f_sum || f_sq);
+    u32x4 plo[LEAN_PUNROLL], phi[LEAN_PUNROLL];
+    {
+        // (without partials the descriptor covers zero bytes: the loads return zeros without touching memory)
+        const unsigned bytes = (need_stat && lp.parts && maybe_biased) ? (unsigned)lp.nparts * 32u : 0u;
+        const auto srd_e = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(lp.parts + (lp.parts ? (long)b * lp.nparts * 4 : 0)), 0, bytes, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < LEAN_PUNROLL; ++j) {
+            const unsigned off = (unsigned)(lane + j * 64) * 32u;
+            plo[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_e, want_lo ? off : OOB_OFF, 0, 0);
+            phi[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_e, want_hi ? off + 16u : OOB_OFF, 0, 0);
+        }
+    }
+    const T *Qp = reinterpret_cast<const T *>(p.q) + b * p.q_sb + h * p.q_sh;
+    const T *Kp = reinterpret_cast<const T *>(p.k) + b * p.k_sb + h * p.k_sh;
+    const T *Vp = reinterpret_cast<const T *>(p.v) + b * p.v_sb + h * p.v_sh;
+    T *Op = reinterpret_cast<T *>(p.o) + b * p.o_sb + h * p.o_sh;
+    const int qrow = (qb * NW + wave) * 32 + l31;
+    const bool qvalid = qrow < p.N;
+    V8 qf[KS];
+    load_q_frags_buf<T, KS>(qf, head_srd(Qp, p.N, p.q_sn, p.D), qvalid ? (unsigned)((long)qrow * p.q_sn * 2) : OOB_OFF, hi, p.D);
+
+    // K / V: rows [0, ceil32(M)) of both tiles, EVERY 16-byte chunk of a row including the head-dim padding -- padding chunks and rows past
+    // M carry an out-of-range offset and arrive as zeros (no zero-fill pass, no barrier for it); rows nobody reads are not touched at all
+    u32x4 kreg[KPT], vreg[VPT];
+    int k_lds[KPT], v_lds[VPT];
+    bool k_ok[KPT], v_ok[VPT], v_one[VPT];
+    {
+        const int rows = min(2 * KVBLK, (p.M + 31) & ~31);
+        const auto srd_k = head_srd(Kp, p.M, p.k_sm, p.D);
+        const auto srd_v = head_srd(Vp, p.M, p.v_sm, p.D);
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int c = tid + i * NT, key = c / KT::CHK, ch = c - key * KT::CHK;
+            k_ok[i] = key < rows;
+            k_lds[i] = (key >> 6) * SUB_BYTES + (key & 63) * KT::STRIDE + ch * 16;
+            kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_k, (k_ok[i] && ch * 8 < p.D) ? (unsigned)((key * p.k_sm + ch * 8) * 2) : OOB_OFF, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int c = tid + i * NT, key = c / VT::CHK, ch = c - key * VT::CHK;
+            v_ok[i] = key < rows;
+            v_one[i] = RSM && ch * 8 == p.D;          // first padding chunk: channel D = 1.0 (the softmax denominator's column)
+            v_lds[i] = (key >> 6) * SUB_BYTES + KT::BYTES + (key & 63) * VT::STRIDE + ch * 16;
+            vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_v, (v_ok[i] && ch * 8 < p.D) ? (unsigned)((key * p.v_sm + ch * 8) * 2) : OOB_OFF, 0, 0);
+        }
+    }
+    // bias rows of THIS WAVE's 32 query rows (wave-private piece of the tile: no barrier between its store and its reads)
+    const int cprl = lp.tile_stride == 16 ? 2 : lp.tile_stride == 32 ? 3 : 4;      // log2 of the 16-byte chunks per tile row
+    u32x4 treg[LEAN_TILE_LOADS];
+    BiasRef bias;
+    if (maybe_biased) {
+        const float *bbase = p.bias + b * p.b_sb + h * p.b_sh;
+        const unsigned bytes = (unsigned)((((long)(p.N - 1) * p.b_sn + (long)(p.M - 1) * p.b_sm) + 1) * 4);
+        bias.srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bbase), 0, bytes, 0x00020000);
+        const long row0 = (long)(qb * NW + wave) * 32;
+#pragma unroll
+        for (int i = 0; i < LEAN_TILE_LOADS; ++i) {
+            const int g = lane + i * 64, rowl = g >> cprl, pc = g & ((1 << cprl) - 1);
+            const bool ok = rowl < 32 && pc * 4 < p.bias_cols && row0 + rowl < p.N;
+            treg[i] = __builtin_amdgcn_raw_buffer_load_b128(bias.srd, ok ? (unsigned)(((row0 + rowl) * p.b_sn + pc * 4) * 4) : OOB_OFF, 0, 0);
+        }
+    }
+    tl_stamp(p, 6);
+
+    // ---- fold the image's partials: EVERY WAVE folds all of them itself (<= 4 per lane from the batch above, shuffles only -- no LDS, no
+    // barrier; the extremes in fp32: a partial's max / min is a float stored as a double). The same order in every wave of every workgroup.
+    float coeff = 0.f;
+    const bool biased = maybe_biased && gate != 0.f;      // workgroup-uniform
+    if (biased) {
+        coeff = c0;
+        if (need_stat) {
+            auto as_double = [](unsigned lo, unsigned hi32) { return __longlong_as_double((long long)(((unsigned long long)hi32 << 32) | lo)); };
+            float vmax = -INFINITY, vmin = INFINITY;
+            double dsum = 0.0, dsq = 0.0;
+#pragma unroll
+            for (int j = 0; j < LEAN_PUNROLL; ++j) {
+                const bool mine = lane + j * 64 < lp.nparts;
+                if (f_max) vmax = fmaxf(vmax, mine ? (float)as_double(plo[j][0], plo[j][1]) : -INFINITY);
+                if (f_min) vmin = fminf(vmin, mine ? (float)as_double(plo[j][2], plo[j][3]) : INFINITY);
+                if (f_sum) dsum += mine ? as_double(phi[j][0], phi[j][1]) : 0.0;
+                if (f_sq) dsq += mine ? as_double(phi[j][2], phi[j][3]) : 0.0;
+            }
+            for (int i = lane + LEAN_PUNROLL * 64; i < lp.nparts; i += 64) {      // (more than 256 partials per image: rare, not prefetched)
+                const double *pp = lp.parts + ((long)b * lp.nparts + i) * 4;
+                if (f_max) vmax = fmaxf(vmax, (float)pp[0]);
+                if (f_min) vmin = fminf(vmin, (float)pp[1]);
+                if (f_sum) dsum += pp[2];
+                if (f_sq) dsq += pp[3];
+            }
+            if (f_max) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
+            }
+            if (f_min) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) vmin = fminf(vmin, __shfl_xor(vmin, off));
+            }
+            if (f_sum) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) dsum += __shfl_xor(dsum, off);
+            }
+            if (f_sq) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) dsq += __shfl_xor(dsq, off);
+            }
+            const double st[4] = {(double)vmax, (double)vmin, dsum, dsq};
+            if (tid == 0 && lp.stats_out && h == 0 && qb == 0) {
+                double *so = lp.stats_out + (long)b * 4;
+                so[0] = st[0]; so[1] = st[1]; so[2] = st[2]; so[3] = st[3];
+            }
+            coeff = stat_coefficient(c0, p.stat_kind, st, p.stat_count);
+        }
+        if (p.bias_coeff) coeff = coeff * gate;
+    }
+    tl_stamp(p, 3);
+
+    // ---- park K / V and the wave's bias rows, ONE barrier
+#pragma unroll
+    for (int i = 0; i < KPT; ++i)
+        if (k_ok[i]) *reinterpret_cast<u32x4 *>(smem + k_lds[i]) = kreg[i];
+    {
+        const T one = (T)1.0f;
+        unsigned short one_bits;
+        __builtin_memcpy(&one_bits, &one, 2);
+#pragma unroll
+        for (int i = 0; i < VPT; ++i)
+            if (v_ok[i]) *reinterpret_cast<u32x4 *>(smem + v_lds[i]) = v_one[i] ? u32x4{(unsigned)one_bits, 0u, 0u, 0u} : vreg[i];
+    }
+    if (biased) {
+#pragma unroll
+        for (int i = 0; i < LEAN_TILE_LOADS; ++i) {
+            const int g = lane + i * 64, rowl = g >> cprl, pc = g & ((1 << cprl) - 1), row = wave * 32 + rowl;
+            if (rowl < 32 && pc * 4 < p.bias_cols)
+                *reinterpret_cast<u32x4 *>(tile + (long)row * lp.tile_stride * 4 + ((pc ^ tile_swz(row, 1 << cprl)) << 4)) = treg[i];
+        }
+        bias_ref_tile(bias, tile, wave * 32 + l31, lp.tile_stride, p.bias_cols, hi);
+    }
+    __syncthreads();
+    tl_stamp(p, 1);
+
+    // ---- scores -> (bias) -> softmax -> PV: the FIRST 64-key tile is all live (the host sends M < 64 to the general kernel), sets the row's
+    // reference and starts O^T from a zero constant (STEP 1); the second keeps that reference unless a score exceeds it by 2^8 (STEP 2)
+    const float c1 = p.scale_log2e;
+    f32x16 oacc[DT];
+    float m_run = -INFINITY, l_run = 0.f;
+    if (biased) {
+        attn_tile<T, KS, DT, 2, false, RSM, 1>(oacc, m_run, l_run, qf, smem, smem + KT::BYTES, 0, p.M, l31, hi, bias, coeff, c1);
+        if (KVBLK < p.M)
+            attn_tile<T, KS, DT, 2, true, RSM, 2>(oacc, m_run, l_run, qf, smem + SUB_BYTES, smem + SUB_BYTES + KT::BYTES, KVBLK, p.M, l31, hi, bias, coeff, c1);
+    } else {
+        attn_tile<T, KS, DT, 0, false, RSM, 1>(oacc, m_run, l_run, qf, smem, smem + KT::BYTES, 0, p.M, l31, hi, bias, coeff, c1);
+        if (KVBLK < p.M)
+            attn_tile<T, KS, DT, 0, true, RSM, 2>(oacc, m_run, l_run, qf, smem + SUB_BYTES, smem + SUB_BYTES + KT::BYTES, KVBLK, p.M, l31, hi, bias, coeff, c1);
+    }
+    float l_tot;
+    if (RSM) {      // row D of O^T: tile D / 32, register (D % 32) / 2, held by the hi == 0 half
+        const int rl = p.D & 31, tl = p.D >> 5;
+        float lv = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const float c = rl == 0 ? oacc[dt][0] : rl == 8 ? oacc[dt][4] : rl == 16 ? oacc[dt][8] : oacc[dt][12];
+            lv = dt == tl ? c : lv;
+        }
+        const float other = __shfl_xor(lv, 32);
+        l_tot = hi ? other : lv;
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32);
+    }
+    const float inv = 1.f / l_tot;
+    store_o_block<T, DT>(Op + (long)(qvalid ? qrow : 0) * p.o_sn, oacc, inv, p.D, hi, qvalid, p.o_wide != 0);
+    tl_stamp(p, 4);
+}
+
+int attn_validate(const void *q, const void *k, const void *v, void *o, const float *bias, const pww_attn_desc_t *d);
+void attn_fill_params(AttnParams &p, const void *q, const void *k, const void *v, void *o, const float *bias,
+                      const float *bias_coeff, const pww_attn_desc_t *d);
+
+static int lean_nw_knob() { return debug_knobs().cross_lean_nw; }
+
+template <typename T, int KS, int DT, int NW>
+static int launch_lean(LeanParams lp, hipStream_t stream) {
+    constexpr size_t stage = 2 * (KTile<KS>::BYTES + VTile<DT>::BYTES);
+    const size_t lds = stage + (size_t)NW * 32 * lp.tile_stride * 4;
+    auto kern = cross_lean_kernel<T, KS, DT, NW>;
+    if (lds > 64 * 1024) {
+        static thread_local size_t lds_attr[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // per device
+        int dev = 0;
+        if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return PWW_EHIP;
+        if (dev >= 8 || lds > lds_attr[dev]) {
+            if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"))
+                return PWW_EHIP;
+            if (dev < 8) lds_attr[dev] = lds;
+        }
+    }
+    lp.nqb = (lp.a.N + NW * 32 - 1) / (NW * 32);
+    const long wgs = (long)lp.a.B * lp.a.H * lp.nqb;
+    launch_attn_kernel(kern, dim3((unsigned)wgs), dim3(NW * 64), lds, stream, lp);
+    return check_hip(hipGetLastError(), "cross_lean_kernel launch");
+}
+
+template <typename T, int NW> static int dispatch_lean_d(const LeanParams &lp, hipStream_t s) {
+    const int D = lp.a.D;
+    if (D <= 48) return launch_lean<T, 3, 2, NW>(lp, s);
+    if (D <= 64) return launch_lean<T, 4, 2, NW>(lp, s);
+    if (D <= 80) return launch_lean<T, 5, 3, NW>(lp, s);
+    if (D <= 96) return launch_lean<T, 6, 3, NW>(lp, s);
+    if constexpr (NW == 2) { set_error("cross_attn_lean: internal dispatch error"); return PWW_EINVAL; } else {      // D > 96 always gets 4 waves
+        if (D <= 128) return launch_lean<T, 8, 4, NW>(lp, s);
+        return launch_lean<T, 10, 5, NW>(lp, s);
+    }
+}
+
+// How many query blocks of 128 rows a launch may have and still take this kernel (one block per workgroup): beyond it the general
+// kernel's several-blocks-per-workgroup form amortises the K / V staging and the prologue (configs 3 / 4: 16 folded rows x 4096 tokens).
+constexpr long LEAN_MAX_BLOCKS128 = 1024;
+
+// Takes the launch if it is of the shape this kernel was written for; *launched = false hands it back to the general kernel.
+int cross_attn_lean(const void *q, const void *k, const void *v, void *o, const float *bias, int stat_kind, float coeff_scalar, const float *gate,
+                    const pww_attn_desc_t *d, double *stats_out, const pww_cross_opts_t &op, hipStream_t stream, const double *parts, int nparts,
+                    bool *launched) {
+    *launched = false;
+    const int mode = debug_knobs().cross_lean;        // 0: never, 1: where it fits (default), 2: also for large batches
+    if (!mode || !bias || op.bias_compact) return PWW_OK;
+    if (d->M < KVBLK || d->M > 2 * KVBLK || d->bias_stride[3] != 1) return PWW_OK;
+    if (stat_kind != PWW_STAT_NONE && !parts) return PWW_OK;
+    const int m16 = (d->M + 15) & ~15;
+    int bias_cols = op.bias_cols > 0 ? ((op.bias_cols + 15) & ~15) : m16;
+    if (bias_cols > m16) bias_cols = m16;
+    if (bias_cols > 64) return PWW_OK;
+    const long blocks128 = (long)d->B * d->H * ((d->N + 127) / 128);
+    if (mode == 1 && blocks128 > LEAN_MAX_BLOCKS128) return PWW_OK;
+    LeanParams lp;
+    attn_fill_params(lp.a, q, k, v, o, bias, gate, d);
+    lp.a.bias_coeff = gate;
+    lp.a.stats = nullptr; lp.a.stat_kind = stat_kind; lp.a.stat_count = (double)d->H * d->N * d->M; lp.a.coeff_scalar = coeff_scalar;
+    lp.a.coeff_scalar_dev = op.coeff_scalar_dev;
+    lp.a.bias_cols = bias_cols;
+    lp.parts = stat_kind != PWW_STAT_NONE ? parts : nullptr;
+    lp.nparts = stat_kind != PWW_STAT_NONE ? nparts : 0;
+    lp.stats_out = stat_kind != PWW_STAT_NONE ? stats_out : nullptr;
+    lp.nqb = 0;
+    lp.tile_stride = bias_cols <= 16 ? 16 : bias_cols <= 32 ? 32 : 64;
+    // waves of 32 rows; 4 per workgroup once that still gives the chip ~a workgroup per CU, else 2 (the widest heads always share their
+    // K / V staging between 4: 2 waves would need > 256 staging registers each)
+    int nw = (blocks128 >= 192 || d->D > 96) ? 4 : 2;
+    if (lean_nw_knob() == 2 && d->D <= 96) nw = 2;
+    if (lean_nw_knob() == 4) nw = 4;
+    int rc;
+    if (d->dtype == PWW_DTYPE_F16) rc = nw == 4 ? dispatch_lean_d<f16, 4>(lp, stream) : dispatch_lean_d<f16, 2>(lp, stream);
+    else rc = nw == 4 ? dispatch_lean_d<bf16, 4>(lp, stream) : dispatch_lean_d<bf16, 2>(lp, stream);
+    *launched = rc == PWW_OK;
+    return rc;
+}
+
+}  // namespace pww

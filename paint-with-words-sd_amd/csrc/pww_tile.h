@@ -73,24 +73,34 @@ __device__ __forceinline__ void ktile_store(const u32x4 (&kreg)[KPT], char *Ks, 
 
 // s[kb] = K_block(kb) Q^T for the two 32-key blocks of the tile; a block entirely past M is
 // skipped (wave-uniform) and left at zero.
+// EVERY K fragment of the tile is requested from LDS before the first MFMA (round 5). The straightforward form -- one ds_read_b128 in
+// front of each MFMA -- compiles to read -> s_waitcnt lgkmcnt(0) -> MFMA per k-step (hipcc re-uses one register quad for all the
+// fragments): 2 KS exposed LDS latencies per tile, which is what a tile cost at one wave per SIMD (the N <= 1024 self-attention and
+// every cross-attention launch at 2 folded rows: ~3000 cycles per tile for ~700 cycles of MFMA). Same MFMAs in the same order: bit-identical scores.
 template <typename T, int KS>
 __device__ __forceinline__ void score_tile(f32x16 (&s)[2], const typename Vec<T>::v8 (&qf)[KS],
                                            const char *Ks, int key0, int M, int l31, int hi) {
     typedef typename Vec<T>::v8 V8;
     typedef KTile<KS> KT;
-    const int krow = swap23(l31);
+    const char *base = Ks + swap23(l31) * KT::STRIDE + hi * 16;
+    const bool live0 = key0 < M, live1 = key0 + 32 < M;      // wave-uniform
+    V8 kf[2][KS];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        if (kb == 0 ? live0 : live1) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kf[kb][ks] = *reinterpret_cast<const V8 *>(base + kb * 32 * KT::STRIDE + ks * 32);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);          // keep the requests ahead of the MFMAs (hipcc sinks them otherwise)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        if (key0 + kb * 32 < M) {
-            const char *base = Ks + (kb * 32 + krow) * KT::STRIDE + hi * 16;
+        if (kb == 0 ? live0 : live1) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const V8 kf = *reinterpret_cast<const V8 *>(base + ks * 32);
-                acc = mfma32(kf, qf[ks], acc);
-            }
+            for (int ks = 0; ks < KS; ++ks) acc = mfma32(kf[kb][ks], qf[ks], acc);
         }
         s[kb] = acc;
     }

@@ -29,12 +29,12 @@ BIAS_COLS = "_PWW_BIAS_COLS"       # private context key: int, columns >= this o
 COMPACT_W = "_PWW_COMPACT_W_"      # private context key prefix: compact form [N, R] (or [B, N, R]) of CROSS_ATTENTION_WEIGHT_<N>
 COMPACT_IDX = "_PWW_COMPACT_IDX"   # private context key: int32 [R] (or [B, R]) columns of the compact slots, -1 = unused
 GATED_ROWS = "_PWW_GATED_ROWS"     # private context key: int, _PWW_ROW_GATE is 1 for exactly the first so many rows, 0 after (a CFG-folded batch)
-# statistic + attention in one launch (pww_cross_attn_fwd_fused); 0 = two launches (A/B). The fused launch needs all its workgroups
-# resident at once: two ranks sharing one device (PWW_DIST_ONE_DEVICE, a test mode) take the two-launch path.
-FUSED_CROSS = os.environ.get("PWW_FUSED_CROSS", "1") != "0" and os.environ.get("PWW_DIST_ONE_DEVICE", "0") != "1"
-# Default since round 4: the statistic's partials come out of the to_q GEMM's epilogue (pww_qproj_stat) and the attention launch folds them
-# at entry (pww_cross_attn_fwd_parts) -- no in-kernel hand-off, nothing has to be resident, no time-out path. 0 = the round-3 launch
-# (pww_cross_attn_fwd_fused: statistic + hand-off inside the attention kernel), kept as the A/B baseline and for shapes the GEMM does not cover.
+# Where the score statistic of `weight_function(w, sigma, qk)` is formed (round 5): ALWAYS outside the attention launch -- as partials
+# that the attention launch folds at entry (pww_cross_attn_fwd_parts: nothing waits for another workgroup, nothing has to be resident,
+# no time-out path) -- either in the epilogue of the to_q GEMM (pww_qproj_stat, where qproj_route says it wins) or by one small launch
+# over the finished Q of the stock GEMM (pww_qk_parts: the C = 1280 layers). PWW_FUSED_CROSS=1 selects round 3's form instead (statistic
+# + device-scope hand-off inside the attention launch, pww_cross_attn_fwd_fused: needs every workgroup resident at once): TEST / A-B only.
+FUSED_CROSS = os.environ.get("PWW_FUSED_CROSS", "0") == "1"
 QPROJ_STAT = os.environ.get("PWW_QPROJ_STAT", "1")       # "1" where it wins (default) | "0" never | "all" wherever the kernel supports the shape
 
 
@@ -679,6 +679,14 @@ def pww_attention(attn, hidden_states, context=None):
             scratch = attn.__dict__.get("_pww_fused_scratch")
             if scratch is None:
                 scratch = attn.__dict__["_pww_fused_scratch"] = ops.FusedScratch()
+        elif not have_stats and key.shape[1] <= ops.FUSED_MAX_KEYS:
+            # the default for every layer the GEMM-epilogue route does not take: stock to_q, one small launch for the statistic's partials
+            # over the finished Q, pass-2-only attention (a statistic-free `c * w` needs no partials at all)
+            if query is None:
+                query = _half(lazy_q.get(), cdt)
+            if kind != ops.STAT_NONE:
+                parts = ops.qk_parts(query, key, attn.heads, kind, gate=gate, gated=gated)
+            stat = (None, kind, scalar)
         else:
             stat = (bias.stat.stats() if bias.stat is not None else None, kind, scalar)
         bias = w_map

@@ -260,10 +260,16 @@ def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None, scra
                     bias_coeff = bias_coeff.expand(B).contiguous()
                 if bias_coeff.numel() != B:
                     raise PwwHipError("bias_coeff must have B=%d elements" % B)
-            if stat is not None and stat[0] is None and parts is not None:
+            if stat is not None and stat[0] is None and scratch is None:
+                # pass-2-only launch: the statistic's partials came from qproj_stat / qk_parts (none needed for STAT_NONE); nothing in it
+                # waits for another workgroup
                 _, kind, scalar = stat
-                if parts.dtype != torch.float64 or parts.dim() != 3 or parts.shape[0] != B or parts.shape[2] != 4 or not parts.is_contiguous() or M > FUSED_MAX_KEYS:
-                    raise PwwHipError("parts must be a contiguous float64 [B, nparts, 4] tensor (and M <= %d)" % FUSED_MAX_KEYS)
+                if kind != STAT_NONE and parts is None:
+                    raise PwwHipError("a statistic formed outside the attention launch needs its partials (qproj_stat / qk_parts), or a FusedScratch for the in-launch form")
+                if parts is not None and (parts.dtype != torch.float64 or parts.dim() != 3 or parts.shape[0] != B or parts.shape[2] != 4 or not parts.is_contiguous()):
+                    raise PwwHipError("parts must be a contiguous float64 [B, nparts, 4] tensor")
+                if M > FUSED_MAX_KEYS:
+                    raise PwwHipError("the pass-2-only cross-attention launch takes at most %d keys" % FUSED_MAX_KEYS)
                 if stats_out is not None and (stats_out.dtype != torch.float64 or tuple(stats_out.shape) != (B, 4) or not stats_out.is_contiguous()):
                     raise PwwHipError("stats_out must be a contiguous float64 [B, 4] tensor")
                 keep = []
@@ -271,12 +277,12 @@ def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None, scra
                     compact = None
                 op = _cross_opts(B, N, coeff_dev, bias_cols, compact, keep, gated)
                 rc = lib.pww_cross_attn_fwd_parts(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(bias), int(kind), float(scalar), _ptr(bias_coeff),
-                                                  ctypes.byref(d), _ptr(parts), int(parts.shape[1]), _ptr(stats_out),
+                                                  ctypes.byref(d), _ptr(parts), int(parts.shape[1]) if parts is not None else 0, _ptr(stats_out),
                                                   ctypes.byref(op) if op is not None else None, _stream())
                 _lib.check(rc, "pww_cross_attn_fwd_parts")
-            elif stat is not None and stat[0] is None and (scratch is not None or stat[1] != STAT_NONE):
+            elif stat is not None and stat[0] is None:
                 _, kind, scalar = stat
-                if scratch is None or M > FUSED_MAX_KEYS:
+                if M > FUSED_MAX_KEYS:
                     raise PwwHipError("fused statistic needs a FusedScratch and at most %d keys" % FUSED_MAX_KEYS)
                 state, ws = scratch.ensure(lib, d, q.device)
                 if stats_out is not None and (stats_out.dtype != torch.float64 or tuple(stats_out.shape) != (B, 4) or not stats_out.is_contiguous()):
@@ -357,6 +363,32 @@ def qproj_stat(x, weight, k, heads, kind, gate=None):
         _lib.check(lib.pww_qproj_stat(_ptr(x), _ptr(weight), _ptr(q), _ptr(k), _ptr(gate), ctypes.byref(d), int(kind), _ptr(parts),
                                       parts.numel() * 8, _stream()), "pww_qproj_stat")
     return q, parts
+
+
+def qk_parts(q, k, heads, kind, gate=None, gated=0):
+    """Partials of the per-image score statistic of q k^T over a FINISHED q (paint_with_words.py:87 + the reduction weight_function
+    applies): float64 [B, nparts, 4], the input of attention(..., parts=...). One small launch (pww_qk_parts): the layers whose to_q
+    stays the stock GEMM. gate: optional fp32 [B] (images with gate 0 get no partials); gated: hint that exactly the first `gated`
+    images have a non-zero gate."""
+    _require_gpu(q, k, gate)
+    if q.dtype != k.dtype:
+        raise PwwHipError("qk_parts: dtypes differ: %s %s" % (q.dtype, k.dtype))
+    q, k = _prep(q), _prep(k)
+    d = _desc(q, k, None, None, heads, 1.0)
+    lib = _lib.load()
+    nparts = int(lib.pww_qk_parts_count(ctypes.byref(d)))
+    if nparts <= 0:
+        raise PwwHipError("qk_parts: unsupported problem %s x %s, %d heads" % (tuple(q.shape), tuple(k.shape), heads))
+    B = q.shape[0]
+    parts = torch.empty((B, nparts, 4), dtype=torch.float64, device=q.device)
+    if gate is not None:
+        gate = gate.to(torch.float32).reshape(-1).contiguous()
+        if gate.numel() != B:
+            raise PwwHipError("gate must have B=%d elements" % B)
+    with torch.cuda.device(q.device):
+        _lib.check(lib.pww_qk_parts(_ptr(q), _ptr(k), _ptr(gate), ctypes.byref(d), int(kind), int(gated or 0), _ptr(parts), parts.numel() * 8, _stream()),
+                   "pww_qk_parts")
+    return parts
 
 
 def fold_parts(parts):

@@ -686,6 +686,33 @@ static void run_qproj(const QCase &c, bool timing) {
            ok_q && ok_s ? "PASS" : "FAIL", c.name, c.dtype == PWW_DTYPE_F16 ? "f16" : "bf16", B, N, Cin, H, D, M, nparts, qerr, qmax, bad, nq, serr, ok_s ? "ok" : "BAD",
            untouched ? "" : " (partials of a gated-out image were written)");
     if (!(ok_q && ok_s)) g_fail++;
+    // (2b) pww_qk_parts over the finished Q (the route of the layers whose to_q stays the stock GEMM): folded partials vs pww_qk_reduce
+    const int nparts2 = pww_qk_parts_count(&d);
+    double *dparts2 = dalloc<double>((size_t)B * std::max(nparts2, 1) * 4);
+    {
+        HIPCHECK(hipMemset(dparts2, 0xff, (size_t)B * std::max(nparts2, 1) * 32));
+        const int r = nparts2 > 0 ? pww_qk_parts(dq, dk, dgate, &d, PWW_STAT_ALL, B > 1 ? B - 1 : 0, dparts2, (size_t)B * nparts2 * 32, nullptr) : -1;
+        HIPCHECK(hipDeviceSynchronize());
+        std::vector<double> p2((size_t)B * std::max(nparts2, 1) * 4);
+        HIPCHECK(hipMemcpy(p2.data(), dparts2, p2.size() * 8, hipMemcpyDeviceToHost));
+        double e2 = 0; bool untouched2 = true;
+        for (int b = 0; b < B && r == 0; ++b) {
+            const double *pp = &p2[(size_t)b * nparts2 * 4];
+            if (gate[b] == 0.f) { for (int i = 0; i < nparts2 * 4; ++i) { uint64_t u; memcpy(&u, &pp[i], 8); untouched2 = untouched2 && u == ~0ull; } continue; }
+            double f[4] = {-1e300, 1e300, 0, 0};
+            for (int i = 0; i < nparts2; ++i) { f[0] = std::max(f[0], pp[i * 4]); f[1] = std::min(f[1], pp[i * 4 + 1]); f[2] += pp[i * 4 + 2]; f[3] += pp[i * 4 + 3]; }
+            const double *g = &stats[4 * b];
+            const double mag = std::max(fabs(g[0]), fabs(g[1])) + 1e-9;
+            e2 = std::max(e2, std::max(fabs(f[0] - g[0]), fabs(f[1] - g[1])) / mag);
+            const double sd = sqrt(std::max((g[3] - g[2] * g[2] / cnt) / (cnt - 1), 0.0)) + 1e-9;
+            e2 = std::max(e2, fabs(f[2] - g[2]) / cnt / sd);
+            e2 = std::max(e2, fabs(f[3] - g[3]) / fabs(g[3]));
+        }
+        const bool ok2 = r == 0 && e2 <= 1e-6 && untouched2;
+        printf("%s %-30s pww_qk_parts: %d partials / image, folded vs pww_qk_reduce rel_err=%.2e%s (rc %d %s)\n", ok2 ? "PASS" : "FAIL", c.name, nparts2, e2,
+               untouched2 ? "" : " (partials of a gated-out image were written)", r, r ? pww_last_error() : "");
+        if (!ok2) g_fail++;
+    }
     // (3) attention from the partials vs pww_cross_attn_fwd_stat from pww_qk_reduce's statistics, same Q
     std::vector<float> bias((size_t)N * M);
     for (auto &bv : bias) bv = (rng_uniform() < 0.3f) ? rng_uniform() * 1.5f : 0.f;
@@ -709,6 +736,21 @@ static void run_qproj(const QCase &c, bool timing) {
         printf("%s %-30s parts-attention kind=%d: max diff %.3e vs two-step path (max|O| %.2f, %ld of %zu elements differ, nan=%ld, rc %d %d%s%s)\n", ok ? "PASS" : "FAIL",
                c.name, kind, dmax, omax, ndiff, h1.size(), nan, r1, r2, r2 ? " " : "", r2 ? pww_last_error() : "");
         if (!ok) g_fail++;
+        // the same from pww_qk_parts' partials (formed for THIS statistic only), and the folded statistics it hands back
+        HIPCHECK(hipMemset(o2, 0xee, (size_t)B * N * C * 2)); HIPCHECK(hipMemset(dfold, 0, 4 * B * 8));
+        int r3 = pww_qk_parts(dq, dk, dgate, &d, kind, B > 1 ? B - 1 : 0, dparts2, (size_t)B * nparts2 * 32, nullptr);
+        if (!r3) r3 = pww_cross_attn_fwd_parts(dq, dk, dv, o2, dbias, kind, 0.37f, dgate, &d, dparts2, nparts2, nullptr, &op, nullptr);
+        HIPCHECK(hipDeviceSynchronize());
+        HIPCHECK(hipMemcpy(h2.data(), o2, h2.size() * 2, hipMemcpyDeviceToHost));
+        double dmax3 = 0; long nan3 = 0;
+        for (size_t i = 0; i < h1.size(); ++i) {
+            const double a = from_t(h1[i], c.dtype), bq = from_t(h2[i], c.dtype);
+            if (!(bq == bq)) ++nan3;
+            dmax3 = std::max(dmax3, fabs(a - bq));
+        }
+        const bool ok3 = r3 == 0 && nan3 == 0 && dmax3 <= 4 * ulp * omax;
+        printf("%s %-30s qk_parts + parts-attention kind=%d: max diff %.3e vs two-step path (nan=%ld, rc %d %s)\n", ok3 ? "PASS" : "FAIL", c.name, kind, dmax3, nan3, r3, r3 ? pww_last_error() : "");
+        if (!ok3) g_fail++;
     }
     if (timing && g_timeline) {
         std::vector<float> g2(B, 1.f); if (B > 1) for (int b = B / 2; b < B; ++b) g2[b] = 0.f;
@@ -728,15 +770,18 @@ static void run_qproj(const QCase &c, bool timing) {
         const size_t fws_bytes = pww_cross_fused_workspace_bytes(&d), sync_bytes = pww_cross_fused_state_bytes(&d);
         void *fws = dalloc<char>(fws_bytes + 8); unsigned *dsync = dalloc<unsigned>(sync_bytes / 4 + 1);
         HIPCHECK(hipMemset(dsync, 0, sync_bytes));
-        float ms[4] = {0, 0, 0, 0};
-        for (int pass = 0; pass < 4; ++pass) {
+        float ms[6] = {0, 0, 0, 0, 0, 0};
+        for (int pass = 0; pass < 6; ++pass) {
             for (int i = 0; i < 5 + iters; ++i) {
                 if (i == 5) HIPCHECK(hipEventRecord(e0, nullptr));
                 if (pass == 0) pww_qproj_stat(dx, dw, dq, dk, dgate, &qd, PWW_STAT_MAX, dparts, (size_t)B * nparts * 32, nullptr);
                 else if (pass == 1) pww_cross_attn_fwd_parts(dq, dk, dv, o2, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, dparts, nparts, nullptr, &op, nullptr);
                 else if (pass == 2) pww_cross_attn_fwd_fused_ex(dq, dk, dv, o1, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, nullptr, dsync, sync_bytes, fws, fws_bytes, &op, nullptr);
-                else { pww_qproj_stat(dx, dw, dq, dk, dgate, &qd, PWW_STAT_MAX, dparts, (size_t)B * nparts * 32, nullptr);
+                else if (pass == 3) { pww_qproj_stat(dx, dw, dq, dk, dgate, &qd, PWW_STAT_MAX, dparts, (size_t)B * nparts * 32, nullptr);
                        pww_cross_attn_fwd_parts(dq, dk, dv, o2, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, dparts, nparts, nullptr, &op, nullptr); }
+                else if (pass == 4) pww_qk_parts(dq, dk, dgate, &d, PWW_STAT_MAX, op.gated_images, dparts2, (size_t)B * nparts2 * 32, nullptr);
+                else { pww_qk_parts(dq, dk, dgate, &d, PWW_STAT_MAX, op.gated_images, dparts2, (size_t)B * nparts2 * 32, nullptr);
+                       pww_cross_attn_fwd_parts(dq, dk, dv, o2, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, dparts2, nparts2, nullptr, &op, nullptr); }
             }
             HIPCHECK(hipEventRecord(e1, nullptr)); HIPCHECK(hipEventSynchronize(e1));
             HIPCHECK(hipEventElapsedTime(&ms[pass], e0, e1));
@@ -751,11 +796,11 @@ static void run_qproj(const QCase &c, bool timing) {
         pww_profile_reset();
         const double gemm_flops = 2.0 * B * N * (double)C * Cin, bytes = 2.0 * ((double)B * N * Cin + (double)B * N * C + (double)C * Cin);
         printf("TIME %-30s qproj_stat %.2f us (kernel-only %.2f; %.1f TFLOP/s, %.0f GB/s algorithmic) | parts-attention %.2f us (kernel-only %.2f) | both back to back %.2f us | "
-               "round-3 fused launch alone (needs its own to_q GEMM before it) %.2f us\n", c.name, ms[0] * 1e3 / iters, kq, gemm_flops / (ms[0] * 1e3 / iters) * 1e-6,
-               bytes / (ms[0] * 1e3 / iters) * 1e-3, ms[1] * 1e3 / iters, ka, ms[3] * 1e3 / iters, ms[2] * 1e3 / iters);
+               "round-3 fused launch alone (needs its own to_q GEMM before it) %.2f us | qk_parts %.2f us, qk_parts + parts-attention %.2f us (needs its own to_q GEMM before it)\n", c.name, ms[0] * 1e3 / iters, kq, gemm_flops / (ms[0] * 1e3 / iters) * 1e-6,
+               bytes / (ms[0] * 1e3 / iters) * 1e-3, ms[1] * 1e3 / iters, ka, ms[3] * 1e3 / iters, ms[2] * 1e3 / iters, ms[4] * 1e3 / iters, ms[5] * 1e3 / iters);
         (void)hipFree(fws); (void)hipFree(dsync);
     }
-    for (void *ptr : {(void *)dx, (void *)dw, (void *)dk, (void *)dv, (void *)dq, (void *)o1, (void *)o2, (void *)dparts, (void *)dstats, (void *)dfold, (void *)dgate, (void *)dws, (void *)dbias})
+    for (void *ptr : {(void *)dx, (void *)dw, (void *)dk, (void *)dv, (void *)dq, (void *)o1, (void *)o2, (void *)dparts, (void *)dstats, (void *)dfold, (void *)dgate, (void *)dws, (void *)dbias, (void *)dparts2})
         (void)hipFree(ptr);
 }
 

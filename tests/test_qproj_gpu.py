@@ -119,11 +119,16 @@ def test_product_path_with_and_without_the_gemm_epilogue_statistic(gpu_device, s
         monkeypatch.setattr(A, "QPROJ_STAT", "all")
         a = pww_hip.inj_forward(mod, hidden, dict(ctx)).float()
         monkeypatch.setattr(A, "QPROJ_STAT", "0")
+        monkeypatch.setattr(A, "FUSED_CROSS", True)          # round 3: stock to_q + statistic and hand-off inside the attention launch
         b = pww_hip.inj_forward(mod, hidden, dict(ctx)).float()
+        monkeypatch.setattr(A, "FUSED_CROSS", False)         # round 5: stock to_q + pww_qk_parts + pass-2-only attention (what the C = 1280 layers take)
+        c = pww_hip.inj_forward(mod, hidden, dict(ctx)).float()
         scale = b.abs().max().item()
         d = (a - b).abs().max().item()
-        print(f"{shape} {dtype} {wname}: default path vs round-3 launch: max diff {d:.3e} of max|out| {scale:.3f}")
+        d5 = (c - b).abs().max().item()
+        print(f"{shape} {dtype} {wname}: GEMM-epilogue route vs round-3 launch: max diff {d:.3e}, qk_parts route vs round-3 launch: {d5:.3e} of max|out| {scale:.3f}")
         assert torch.isfinite(a).all() and d <= TOL[dtype] * scale
+        assert torch.isfinite(c).all() and d5 <= TOL[dtype] * scale
         assert (a[0] - a[1]).abs().max().item() > 10 * d or wname == "none"       # the two images really are different rows
 
 

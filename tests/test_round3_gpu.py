@@ -267,8 +267,8 @@ print("state clean:", not m.__dict__["_pww_fused_scratch"].error())
 
 
 def test_sampler_raises_on_a_set_error_word(gpu_device, monkeypatch):
-    """The round-3 launch (statistic + hand-off inside the attention kernel; since round 4 only behind PWW_QPROJ_STAT=0 or for shapes
-    the to_q GEMM does not cover) can fail at run time. PwWSampler posts the error words of every attention layer after the loop (one
+    """The round-3 launch (statistic + hand-off inside the attention kernel; since round 5 only behind PWW_FUSED_CROSS=1 / attention.FUSED_CROSS,
+    a test and A/B switch) can fail at run time. PwWSampler posts the error words of every attention layer after the loop (one
     device -> host copy behind an event) and raises when they are looked at: in the PIL-returning entry points right after the
     decode, and -- round 4 -- BEFORE `return_latents=True` hands the latents back (a single call must not return NaN
     latents silently). The default path has no hand-off, creates no state buffers and never waits."""
@@ -283,9 +283,11 @@ def test_sampler_raises_on_a_set_error_word(gpu_device, monkeypatch):
             pw.paint_with_words(color_context=dict(cases.RUNNER_CONTEXT), return_latents=True, **kw)
             sampler = tools[1]._pww_samplers[(id(tools[4]), "folded")]
             assert not sampler.handoff_pending        # (the request above was checked before its latents came back)
-            # (the 1/8-width UNet's channel counts -- 32 / 64 / 128 -- have no pww_qproj_stat tile, so its layers take the round-3 launch
-            # either way; the full-size models take the GEMM-epilogue route: test_qproj_gpu.py)
+            # the default path created no hand-off state at all (round 5: the 1/8-width UNet's layers, which have no pww_qproj_stat tile, take
+            # pww_qk_parts + the pass-2-only launch like the C = 1280 layers of the full-size models)
+            assert not [m for m in tools[1].modules() if "_pww_fused_scratch" in m.__dict__]
             monkeypatch.setattr(A, "QPROJ_STAT", "0")
+            monkeypatch.setattr(A, "FUSED_CROSS", True)
             pw.paint_with_words(color_context=dict(cases.RUNNER_CONTEXT), return_latents=True, **kw)
             scr = [m.__dict__["_pww_fused_scratch"] for m in tools[1].modules() if "_pww_fused_scratch" in m.__dict__]
             assert len(scr) >= 3

@@ -1,0 +1,45 @@
+#!/bin/bash
+# Round-5 GPU runner: `bash tools/gpu_r5.sh <stage> [...]`, stages run in the order given; everything lands under gpurun_out/r5_<stage>*.
+#   native     tests/native/attn_check --quick (PASS count, FAIL lines) + TIME lines of the product shapes
+#   small      tools/time_small_attn.py under the library variants (one process per PWW_DEBUG setting)
+#   timeline   phase time stamps of the small launches
+#   subset     the GPU tests that touch the attention path
+#   pytest     the whole GPU suite
+#   bench      python bench.py (short) -> r5_bench.json
+#   benchfull  python bench.py with its defaults
+export TMPDIR=/tmp
+mkdir -p gpurun_out; O=gpurun_out
+for stage in "$@"; do
+case $stage in
+native)
+  (cd tests/native && timeout 600 ./attn_check --quick > ../../$O/r5_native.log 2>&1; grep -c "^PASS" ../../$O/r5_native.log; grep -v "^PASS\|^TIME\|^TIMELINE" ../../$O/r5_native.log | tail -15)
+  (cd tests/native && for c in qproj_sd15_n4096_b2 qproj_sd15_n1024_b2 qproj_sd15_n256_b2 qproj_sd15_n64_b2 qproj_sd15_n4096_b16 qproj_sd15_n256_b16 qproj_sd21_n576_b8; do timeout 120 ./attn_check --only $c 2>&1 | grep "^TIME\|^FAIL"; done) | tee $O/r5_native_time.log | cut -c1-400
+  ;;
+small)
+  for v in "" "cross_lean=0" "cross_lean_nw=4" "cross_lean_nw=2"; do PWW_DEBUG="$v" timeout 300 python tools/time_small_attn.py cross --out $O/r5_small.md 2>&1 | grep -v amdgpu.ids | tail -6; done
+  for v in "" "attn_ksplit_nw=4" "attn_ksplit=0"; do PWW_DEBUG="$v" timeout 300 python tools/time_small_attn.py self --out $O/r5_small.md 2>&1 | grep -v amdgpu.ids | tail -6; done
+  ;;
+timeline)
+  (cd tests/native && for c in qproj_sd15_n256_b2 qproj_sd15_n4096_b2; do timeout 120 ./attn_check --timeline --only $c 2>&1 | grep "^TIMELINE"; done; for c in sd15_self_n1024_d80 sd15_self_n256_d160; do timeout 120 ./attn_check --timeline --only $c 2>&1 | grep "^TIMELINE"; done) > $O/r5_timeline.log 2>&1; tail -60 $O/r5_timeline.log | cut -c1-200
+  ;;
+subset)
+  timeout 900 python -m pytest tests/test_native_gpu.py tests/test_attention_gpu.py tests/test_qproj_gpu.py tests/test_round3_gpu.py tests/test_round5_gpu.py -m gpu -q -x 2>&1 | tail -15 | tee $O/r5_subset.log
+  ;;
+pytest)
+  timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -12 | tee $O/r5_pytest.log
+  ;;
+bench)
+  timeout 600 python bench.py --steps 3 --warmup 2 --cpu-steps 0 --no-reference-ops > $O/r5_bench.json 2> $O/r5_bench.log; tail -3 $O/r5_bench.log; python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r5_bench.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"], d.get("attention_path"), d["roofline"]["frac"])
+for r in d.get("kernels", []):
+    print(r.get("kernel")[:60], r.get("N"), r.get("D"), r.get("launches"), r.get("avg_us"), r.get("avg_us_back_to_back"))
+PY
+  ;;
+benchfull)
+  timeout 900 python bench.py > $O/r5_bench_default.json 2> $O/r5_bench_default.log; tail -2 $O/r5_bench_default.log; tail -1 $O/r5_bench_default.json | cut -c1-300
+  ;;
+*) echo "unknown stage $stage";;
+esac
+done
