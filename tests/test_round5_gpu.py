@@ -114,7 +114,7 @@ def test_pass2_only_launch_vs_fp64(gpu_device, dtype, name, B, N, H, D, M, share
     stats_out = torch.zeros(B, 4, dtype=torch.float64, device=gpu_device)
     out = ops.attention(q, k, v, H, scale, bias=bias, bias_coeff=gate, stat=(None, kind, c0), parts=parts, bias_cols=cols, gated=gated, stats_out=stats_out)
     # coefficient from the raw fp64 scores
-    _, s = _reference(q, k, v, H, scale, bias, torch.zeros(B))
+    _, s = _reference(q, k, v, H, scale, bias, torch.zeros(B, device=q.device))
     sb = s.reshape(B, -1)
     stat = {ops.STAT_MAX: sb.max(1).values, ops.STAT_MIN: sb.min(1).values, ops.STAT_MEAN: sb.mean(1), ops.STAT_STD: sb.std(1), ops.STAT_ABSMAX: sb.abs().max(1).values}[kind]
     coeff = c0 * stat * gate.double()
