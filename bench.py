@@ -604,6 +604,7 @@ def main():
         return
 
     warm_s = []
+    pww_hip.blocks.reset_stats()
     for w in range(args.warmup):
         t0 = time.perf_counter()
         one_step(w)
@@ -611,6 +612,12 @@ def main():
         warm_s.append(round(time.perf_counter() - t0, 2))
         log("warmup step", w, "done in %.2f s" % warm_s[-1])
     result["config"]["warmup_s"] = warm_s      # the first one holds MIOpen's solver search and the ONE hipGraph capture of the geometry
+    # what the block plug did with the calls of the warm-up passes (in graph mode: the discovery pass and the capture the timed steps replay).
+    # A call the kernels declined ran the stock op: the line must say so, and the default configuration must not have any.
+    bst = pww_hip.blocks.stats()
+    result["config"]["block_norms_calls"] = bst
+    if pww_hip.blocks.FUSED_NORM and args.warmup > 0 and not args.tiny:
+        assert bst["hit_rate"] == 1.0, "the block plug handed calls to the stock ops: %s" % bst
     if args.mode == "graph":
         smp = getattr(unet, "_pww_samplers", {}).get((id(sched), "graph"))
         if smp is not None and smp._graphed is not None:
@@ -623,7 +630,9 @@ def main():
         lat = one_step(args.warmup + s)
     pdist.barrier(device)
     torch.cuda.synchronize()
-    elapsed = pdist.max_over_ranks(time.perf_counter() - t0, device)
+    elapsed_local = time.perf_counter() - t0
+    elapsed = pdist.max_over_ranks(elapsed_local, device)
+    per_rank_s = pdist.all_ranks(elapsed_local, device)
     log("timed region CLOCK_MONOTONIC ns %d %d" % (mono0, time.monotonic_ns()))      # (tools/rocpd_stats.py --window: the kernels of the timed steps only)
     for smp in getattr(unet, "_pww_samplers", {}).values():
         smp.check_errors()            # fused hand-off time-outs of any timed request (raises; the requests are complete: synchronised above)
@@ -636,6 +645,11 @@ def main():
     images = args.steps * n_global
     result["value"] = round(images / elapsed, 4)
     result["ms_per_step"] = round(elapsed / args.steps * 1e3, 2)
+    # per-rank view of the same timed region (the line's value is the job's: total images / the slowest rank's time): a rank that lags --
+    # a slower box slot, a MIOpen search that did not finish in the warm-up -- shows here instead of hiding behind the max
+    lo_hi = [pdist.shard_range(n_global, r, world) for r in range(world)]
+    result["config"]["per_rank"] = {"seconds": [round(t, 4) for t in per_rank_s],
+                                    "images_per_s": [round(args.steps * (hi - lo) / t, 4) for (lo, hi), t in zip(lo_hi, per_rank_s)]}
 
     if rank == 0 and not args.no_roofline_pass:
         # instrumented pass (same workload, folded mode so single launches can be bracketed by HIP events

@@ -772,7 +772,9 @@ class PwWAttnProcessor:
         ctx = encoder_hidden_states
         if getattr(attn, "norm_cross", None) is not None and ctx is not None:
             if isinstance(ctx, dict):
-                ctx = dict(ctx, CONTEXT_TENSOR=attn.norm_encoder_hidden_states(ctx["CONTEXT_TENSOR"]))
+                normed = attn.norm_encoder_hidden_states(ctx["CONTEXT_TENSOR"])
+                ctx = ctx.copy()          # (PwWContext.copy keeps the entries that are built on first access: CROSS_ATTENTION_WEIGHT_ORIG; dict(ctx) would drop them)
+                ctx["CONTEXT_TENSOR"] = normed
             else:
                 ctx = attn.norm_encoder_hidden_states(ctx)
         out = pww_attention(attn, hidden_states, ctx)

@@ -26,6 +26,7 @@ raises like every other op here.
 """
 import os
 import types
+import warnings
 
 import torch
 import torch.nn as nn
@@ -37,6 +38,48 @@ FUSED_NORM = os.environ.get("PWW_FUSED_NORM", "1") != "0"      # A/B switch (ben
 BATCHED_TEMB = os.environ.get("PWW_BATCHED_TEMB", "1") != "0"  # A/B switch: one time-embedding projection GEMM per forward for all blocks
 FOLD_CONV_BIAS = os.environ.get("PWW_FOLD_CONV_BIAS", "1") != "0"      # A/B: conv1 / conv2 biases of a ResnetBlock2D ride in the next fused op
 CONV1X1_AS_LINEAR = os.environ.get("PWW_CONV1X1_AS_LINEAR", "1") != "0"  # A/B: 1 x 1 convolutions on channels_last tensors as GEMMs
+
+
+# ---- what the plug did with the calls it saw (a call the kernels decline must not go unnoticed) ----------------
+# per op: [calls taken by the HIP kernels, calls handed to the module's own forward / the stock op]. Counted on the host, i.e. in eager
+# passes and while a hipGraph is captured (a replay runs no Python). `stats()` returns a copy, `reset_stats()` zeroes; the first decline of
+# a HIP half-precision tensor per (op, reason) also warns once -- under torch.autocast, the reference's own run mode, the whole plug steps
+# aside (autocast runs the norms in fp32) and that is worth knowing when a benchmark claims the fused blocks.
+_STATS = {k: [0, 0] for k in ("group_norm", "resnet_block", "transformer_block", "geglu", "conv1x1")}
+_warned = set()
+
+
+def stats():
+    """{op: {"fused": n, "declined": n}} since the last reset_stats(), and the hit rate over the norm / elementwise ops (the 1 x 1
+    convolutions are listed but not rated: an NCHW tensor keeps MIOpen's convolution by the caller's choice of memory format)."""
+    out = {k: {"fused": v[0], "declined": v[1]} for k, v in _STATS.items()}
+    rated = [v for k, v in _STATS.items() if k != "conv1x1"]
+    tot = sum(v[0] + v[1] for v in rated)
+    out["hit_rate"] = (sum(v[0] for v in rated) / tot) if tot else None
+    return out
+
+
+def reset_stats():
+    for v in _STATS.values():
+        v[0] = v[1] = 0
+
+
+def _count(op, fused, x=None, reason=None):
+    _STATS[op][0 if fused else 1] += 1
+    if not fused and FUSED_NORM and torch.is_tensor(x) and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16):
+        key = (op, reason)
+        if key not in _warned:
+            _warned.add(key)
+            warnings.warn("pww_hip.blocks: %s call on a HIP %s tensor handed to the stock op (%s); pww_hip.blocks.stats() counts them"
+                          % (op, str(x.dtype).split(".")[-1], reason or "shape / dtype the kernels do not take"), stacklevel=3)
+
+
+def _why_not(x):
+    if torch.is_autocast_enabled():
+        return "torch.autocast is on: the norms run in fp32 there"
+    if torch.is_grad_enabled() and torch.is_tensor(x) and x.requires_grad:
+        return "autograd is recording: the kernels are forward-only"
+    return None
 
 
 def _takes(x, norm):
@@ -59,8 +102,12 @@ def fused_group_norm(norm, x, add=None, act=None):
     return F.silu(y) if act == "silu" else y
 
 
-def _group_norm_forward(self, x):
-    return fused_group_norm(self, x) if _takes(x, self) else self._pww_orig_forward(x)
+def _group_norm_forward(self, x, *args, **kwargs):
+    if args or kwargs or not _takes(x, self):
+        _count("group_norm", False, x, "unexpected arguments" if (args or kwargs) else _why_not(x))
+        return self._pww_orig_forward(x, *args, **kwargs)
+    _count("group_norm", True)
+    return fused_group_norm(self, x)
 
 
 def _is_silu(m):
@@ -77,7 +124,8 @@ class TembProjections:
     """``time_emb_proj(silu(temb))`` of ALL the plugged ResnetBlock2D of a model as ONE GEMM per forward (22 blocks in the SD1.5 UNet: 22
     SiLU launches on the same [B, 1280] tensor and 22 GEMMs of 2 rows become one each). The concatenated weight is a COPY: it is rebuilt
     when any source parameter was replaced, modified in place (tensor version counter), moved or cast. The result is cached ON the temb
-    tensor object (a fresh one every forward), block i takes its columns as a view -- `ops.group_norm` reads strided rows."""
+    tensor object (a fresh one every forward; the hit test also compares the tensor's version counter and data pointer), block i takes its
+    columns as a view -- `ops.group_norm` reads strided rows."""
 
     def __init__(self):
         self.linears = []          # (block, offset, width) in registration order
@@ -100,8 +148,10 @@ class TembProjections:
         return tuple(sig)
 
     def project(self, temb):
+        # the cache entry is valid for THIS tensor in THIS state: a caller that keeps one temb tensor and updates it in place between
+        # forwards (static buffers, hipGraph-style input copies) bumps its version counter
         hit = temb.__dict__.get("_pww_temb_proj")
-        if hit is not None and hit[0] is self:
+        if hit is not None and hit[0] is self and hit[2] == (temb._version, temb.data_ptr()):
             return hit[1]
         sig = self._signature(temb.dtype, temb.device)
         if sig != self._sig:
@@ -113,7 +163,7 @@ class TembProjections:
                     b[off:off + n] = lin.bias.detach().to(temb.dtype)
             self._w, self._b, self._sig = w, b, sig
         out = F.linear(F.silu(temb), self._w, self._b)
-        temb.__dict__["_pww_temb_proj"] = (self, out)
+        temb.__dict__["_pww_temb_proj"] = (self, out, (temb._version, temb.data_ptr()))
         return out
 
 
@@ -127,10 +177,16 @@ def _plain_conv(conv):
         and "forward" not in conv.__dict__ and not conv._forward_hooks and not conv._forward_pre_hooks
 
 
-def _resnet_forward(self, input_tensor, temb=None):
-    """diffusers 0.10.0 ``ResnetBlock2D.forward`` (``up`` / ``down`` = False, ``time_embedding_norm == "default"``)."""
-    if not _takes(input_tensor, self.norm1):
-        return self._pww_orig_forward(input_tensor, temb)
+def _resnet_forward(self, *args, **kwargs):
+    """diffusers 0.10.0 ``ResnetBlock2D.forward(input_tensor, temb)`` (``up`` / ``down`` = False, ``time_embedding_norm == "default"``). Any other
+    call -- later diffusers pass ``scale=`` (0.21 - 0.26: the LoRA scale) -- reaches the module's own forward with its arguments as given."""
+    covered = 1 <= len(args) <= 2 and set(kwargs) <= {"temb"} and not (len(args) == 2 and kwargs)
+    input_tensor = args[0] if args else None
+    if not covered or not _takes(input_tensor, self.norm1):
+        _count("resnet_block", False, input_tensor, ("a call beyond (input_tensor, temb): %d positional, keywords %s" % (len(args), sorted(kwargs))) if not covered else _why_not(input_tensor))
+        return self._pww_orig_forward(*args, **kwargs)
+    temb = args[1] if len(args) == 2 else kwargs.get("temb")
+    _count("resnet_block", True)
     fold = FOLD_CONV_BIAS and _plain_conv(self.conv1) and _plain_conv(self.conv2) and self.conv1.bias.dtype == input_tensor.dtype
     h = fused_group_norm(self.norm1, input_tensor, act="silu")
     h = _conv_no_bias(self.conv1, h) if fold else self.conv1(h)
@@ -163,13 +219,15 @@ def _resnet_forward(self, input_tensor, temb=None):
 
 
 # ---- 1 x 1 convolutions on channels_last tensors are GEMMs over the [B H W, C] view: bias in the GEMM's epilogue, no layout kernels ----
-def _conv1x1_forward(self, x):
-    if (FUSED_NORM and CONV1X1_AS_LINEAR and torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == self.weight.dtype
+def _conv1x1_forward(self, x, *args, **kwargs):
+    if (not args and not kwargs and FUSED_NORM and CONV1X1_AS_LINEAR and torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == self.weight.dtype
             and x.shape[2] * x.shape[3] > 1 and x.is_contiguous(memory_format=torch.channels_last) and not torch.is_autocast_enabled()):
         B, C, H, W = x.shape
+        _STATS["conv1x1"][0] += 1
         y = F.linear(x.permute(0, 2, 3, 1).reshape(B * H * W, C), self.weight.reshape(self.out_channels, C), self.bias)
         return y.view(B, H, W, self.out_channels).permute(0, 3, 1, 2)
-    return self._pww_orig_forward(x)
+    _STATS["conv1x1"][1] += 1          # (an NCHW tensor keeps MIOpen's 1 x 1 convolution: a layout choice of the caller, not worth a warning)
+    return self._pww_orig_forward(x, *args, **kwargs)
 
 
 def _is_conv1x1(m):
@@ -190,11 +248,21 @@ def _transformer_block_covered(m):
             and hasattr(m, "ff") and not getattr(m, "only_cross_attention", False))
 
 
-def _transformer_block_forward(self, hidden_states, context=None, **kwargs):
-    """diffusers 0.10.0 ``BasicTransformerBlock.forward``: ``h = attn1(norm1(h)) + h; h = attn2(norm2(h), context) + h; h = ff(norm3(h)) + h`` --
-    with each residual add and the NEXT norm as one launch."""
-    if kwargs or not _ln_takes(hidden_states, self.norm1):
-        return self._pww_orig_forward(hidden_states, context=context, **kwargs) if (kwargs or context is not None) else self._pww_orig_forward(hidden_states)
+def _transformer_block_forward(self, *args, **kwargs):
+    """diffusers 0.10.0 ``BasicTransformerBlock.forward(hidden_states, context=None, timestep=None)``: ``h = attn1(norm1(h)) + h;
+    h = attn2(norm2(h), context) + h; h = ff(norm3(h)) + h`` -- with each residual add and the NEXT norm as one launch. 0.10.0's
+    ``Transformer2DModel`` always passes ``timestep=`` (None unless the norms are AdaLayerNorm, which `_transformer_block_covered` excludes):
+    a None timestep is accepted and ignored. Every other call -- a real timestep, more positionals, keywords this restatement does not know
+    (later diffusers: ``encoder_hidden_states=``, ``attention_mask=``, ``cross_attention_kwargs=`` ...) -- reaches the module's own forward
+    with its arguments exactly as they were given."""
+    covered = 1 <= len(args) <= 2 and set(kwargs) <= {"context", "timestep"} and kwargs.get("timestep") is None and not (len(args) == 2 and "context" in kwargs)
+    hidden_states = args[0] if args else None
+    if not covered or not _ln_takes(hidden_states, self.norm1):
+        _count("transformer_block", False, hidden_states, ("a call beyond (hidden_states, context, timestep=None): %d positional, keywords %s" % (len(args), sorted(kwargs)))
+               if not covered else _why_not(hidden_states))
+        return self._pww_orig_forward(*args, **kwargs)
+    context = args[1] if len(args) == 2 else kwargs.get("context")
+    _count("transformer_block", True)
     h = hidden_states
     n = ops.add_layer_norm(h, self.norm1.weight, self.norm1.bias, self.norm1.eps)
     h, n = ops.add_layer_norm(h, self.norm2.weight, self.norm2.bias, self.norm2.eps, a=self.attn1(n))
@@ -202,11 +270,17 @@ def _transformer_block_forward(self, hidden_states, context=None, **kwargs):
     return self.ff(n) + h
 
 
-def _geglu_forward(self, x):
+def _geglu_forward(self, x, *args, **kwargs):
+    """diffusers ``GEGLU.forward(hidden_states)``; later versions add ``scale`` (0.21 - 0.26): anything extra -> the module's own forward."""
+    if args or kwargs:
+        _count("geglu", False, x, "arguments beyond (hidden_states): %s" % (sorted(kwargs) or len(args)))
+        return self._pww_orig_forward(x, *args, **kwargs)
     h = self.proj(x)
     if FUSED_NORM and h.is_cuda and h.dtype in (torch.float16, torch.bfloat16) and h.shape[-1] % 16 == 0 and not torch.is_autocast_enabled() \
             and not (torch.is_grad_enabled() and h.requires_grad):
+        _count("geglu", True)
         return ops.geglu(h)
+    _count("geglu", False, h, _why_not(h))
     a, gate = h.chunk(2, dim=-1)
     return a * F.gelu(gate)
 

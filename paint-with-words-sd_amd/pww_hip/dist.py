@@ -218,6 +218,17 @@ def max_over_ranks(value, device, group=None):
     return float(t.item())
 
 
+def all_ranks(value, device, group=None):
+    """[value of rank 0, rank 1, ...] on every rank (one all_gather of a float64): per-rank timings of a benchmark line, so that a slow
+    rank is visible in the record instead of hiding behind the max."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    world = dist.get_world_size(group)
+    out = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+    dist.all_gather(out, torch.tensor([float(value)], dtype=torch.float64, device=device), group=group)
+    return [float(t.item()) for t in out]
+
+
 def barrier(device=None, group=None):
     if dist.is_available() and dist.is_initialized():
         if device is not None and torch.device(device).type == "cuda":

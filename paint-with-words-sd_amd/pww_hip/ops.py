@@ -692,6 +692,8 @@ def bias_residual(residual, value, bias):
     if residual.shape != value.shape or residual.dtype != value.dtype or residual.dtype not in _DT or residual.dim() != 4 or bias.dtype != residual.dtype:
         raise PwwHipError("bias_residual: two same-shape 4-d float16/bfloat16 tensors and a bias of that type are needed")
     B, C, H, W = residual.shape
+    if tuple(bias.shape) != (C,):
+        raise PwwHipError("bias_residual: bias must have shape (%d,), got %s" % (C, tuple(bias.shape)))
     nhwc = value.is_contiguous(memory_format=torch.channels_last) and not value.is_contiguous()
     fmt = torch.channels_last if nhwc else torch.contiguous_format
     value, residual = value.contiguous(memory_format=fmt), residual.contiguous(memory_format=fmt)       # (no-ops when both already are)

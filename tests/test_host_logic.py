@@ -639,6 +639,109 @@ def test_batched_time_embedding_projection_tracks_its_source_weights():
         assert torch.allclose(plan.project(t64)[:, 0:8], lins[0](F.silu(t64)), atol=1e-12)
 
 
+def test_block_plug_is_safe_on_later_diffusers_signatures():
+    """VERDICT round 4 item 4 / ADVICE: diffusers 0.21 - 0.26 call `resnet(hidden_states, temb, scale=...)`, `GEGLU(hidden_states, scale)`
+    and `BasicTransformerBlock(hidden_states, attention_mask=..., encoder_hidden_states=..., timestep=...)`; 0.10.0's Transformer2DModel
+    calls `block(hidden_states, context=..., timestep=None)`. The per-instance plug accepts the 0.10.0 call (a None timestep included) and
+    hands anything beyond it to the module's OWN forward, arguments untouched -- never a TypeError. Fake modules carry the later signatures."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from pww_hip import blocks
+
+    class ResnetBlock2D(nn.Module):                 # 0.21-style: forward(input_tensor, temb, scale=1.0)
+        def __init__(self):
+            super().__init__()
+            self.norm1, self.norm2 = nn.GroupNorm(4, 8), nn.GroupNorm(4, 8)
+            self.conv1, self.conv2 = nn.Conv2d(8, 8, 3, padding=1), nn.Conv2d(8, 8, 3, padding=1)
+            self.time_emb_proj = nn.Linear(16, 8)
+            self.nonlinearity = nn.SiLU()
+            self.seen = None
+
+        def forward(self, input_tensor, temb, scale=1.0):
+            self.seen = scale
+            h = self.conv1(F.silu(self.norm1(input_tensor)))
+            h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None] * scale
+            return input_tensor + self.conv2(F.silu(self.norm2(h)))
+
+    class GEGLU(nn.Module):                         # 0.21-style: forward(hidden_states, scale=1.0)
+        def __init__(self):
+            super().__init__()
+            self.proj = nn.Linear(8, 32)
+            self.seen = None
+
+        def forward(self, hidden_states, scale=1.0):
+            self.seen = scale
+            a, g = (self.proj(hidden_states) * scale).chunk(2, dim=-1)
+            return a * F.gelu(g)
+
+    class BasicTransformerBlock(nn.Module):         # later signature: encoder_hidden_states=..., timestep=..., cross_attention_kwargs=...
+        def __init__(self):
+            super().__init__()
+            self.norm1, self.norm2, self.norm3 = nn.LayerNorm(8), nn.LayerNorm(8), nn.LayerNorm(8)
+            self.attn1 = self.attn2 = self.ff = nn.Identity()
+            self.seen = None
+
+        def forward(self, hidden_states, attention_mask=None, encoder_hidden_states=None, encoder_attention_mask=None, timestep=None,
+                    cross_attention_kwargs=None, class_labels=None, context=None):
+            self.seen = dict(encoder_hidden_states=encoder_hidden_states, timestep=timestep, context=context, cross_attention_kwargs=cross_attention_kwargs)
+            return self.norm1(hidden_states) + hidden_states
+
+    torch.manual_seed(3)
+    res, geglu, blk = ResnetBlock2D().eval(), GEGLU().eval(), BasicTransformerBlock().eval()
+    model = nn.ModuleList([res, geglu, blk])
+    x, temb, tok = torch.randn(2, 8, 4, 4), torch.randn(2, 16), torch.randn(2, 5, 8)
+    with torch.no_grad():
+        want_r, want_g, want_b = res(x, temb, scale=0.5), geglu(tok, 0.5), blk(tok, encoder_hidden_states="ctx", timestep=7)
+        blocks.reset_stats()
+        blocks.install_blocks(model)
+        try:
+            assert all("_pww_orig_forward" in m.__dict__ for m in (res, geglu, blk))
+            res.seen = geglu.seen = blk.seen = None
+            assert torch.equal(res(x, temb, scale=0.5), want_r) and res.seen == 0.5
+            assert torch.equal(res(x, temb, 0.5), want_r)                                    # positional extra
+            assert torch.equal(geglu(tok, 0.5), want_g) and geglu.seen == 0.5
+            assert torch.equal(geglu(tok, scale=0.5), want_g)
+            assert torch.equal(blk(tok, encoder_hidden_states="ctx", timestep=7), want_b)
+            assert blk.seen["encoder_hidden_states"] == "ctx" and blk.seen["timestep"] == 7
+            blk(tok, None, None, None, None, {"scale": 1.0})                                  # six positionals of the later signature
+            assert blk.seen["cross_attention_kwargs"] == {"scale": 1.0}
+            # the 0.10.0 call: context + a None timestep is the covered form (CPU tensors: handed to the module's own forward, not a TypeError)
+            blk(tok, context="c", timestep=None)
+            assert blk.seen["context"] == "c" and blk.seen["timestep"] is None
+            st = blocks.stats()
+            assert st["resnet_block"]["declined"] == 2 and st["geglu"]["declined"] == 2 and st["transformer_block"]["declined"] == 3
+            assert st["hit_rate"] == 0.0
+        finally:
+            blocks.uninstall_blocks(model)
+        blocks.reset_stats()
+        assert blocks.stats()["hit_rate"] is None
+
+
+def test_time_embedding_cache_follows_in_place_updates_of_temb():
+    """a caller that keeps ONE temb tensor and updates it in place between forwards (static buffers, hipGraph-style input
+    copies) must not get the previous step's projection: the cache entry on the tensor is keyed by its version counter and data pointer."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from pww_hip.blocks import TembProjections
+    torch.manual_seed(2)
+    lin = nn.Linear(16, 8)
+    plan = TembProjections()
+    plan.register(type("B", (), {"time_emb_proj": lin})())
+    temb = torch.randn(2, 16)
+    with torch.no_grad():
+        a = plan.project(temb)
+        assert plan.project(temb) is a
+        temb.mul_(-1.5)                                                     # in place: same object, new values
+        b = plan.project(temb)
+        assert b is not a and torch.allclose(b[:, :8], lin(F.silu(temb)), atol=1e-6)
+        temb.copy_(torch.randn(2, 16))                                      # a static input buffer refilled
+        assert torch.allclose(plan.project(temb)[:, :8], lin(F.silu(temb)), atol=1e-6)
+        view = temb[:]                                                      # another tensor object on the same storage: its own cache slot
+        assert torch.allclose(plan.project(view)[:, :8], lin(F.silu(temb)), atol=1e-6)
+
+
 def test_qproj_route_follows_the_measured_table(monkeypatch):
     """attention.qproj_route: `to_q` + statistic as one launch only where profiles/r04_qproj.md says the route wins."""
     import pww_hip.attention as A
