@@ -255,8 +255,10 @@ int pww_cross_attn_fwd_parts(const void *q, const void *k, const void *v, void *
  * The statistic's partials over a FINISHED Q (version >= 124): what pww_qproj_stat's epilogue forms, for the layers whose to_q stays the
  * stock GEMM (SD1.5 / SD2.1 at C = 1280: the projection kernel meets too few workgroups there). paint_with_words.py:87 + the global
  * reduction weight_function applies to `qk` (:402-405 qk.max(); runner.py:104; README.md:152 qk.std()). One wave per (image, head, 32-row
- * block, 32-key block): loads -> MFMAs -> one fp64 partial; no LDS, no barrier, no atomics, nothing waits for another workgroup.
- *   q, k      as in pww_attn_desc_t (only dtype, B / H / N / M / D and the q / k strides of the descriptor are read), M any
+ * block, 32-key block) and a partial per wave -- loads -> MFMAs -> one fp64 partial, no LDS, no barrier -- while that gives at most 256
+ * partials per image; beyond, one wave per (head, 32-row block) walks the key blocks and a workgroup's four waves share one partial.
+ * No atomics, nothing waits for another workgroup.
+ *   q, k      as in pww_attn_desc_t (only dtype, B / H / N / M / D and the q / k strides of the descriptor are read), M <= 128
  *   gate      fp32 [B] or NULL: images with gate[b] == 0 get no partials (their rows of `partials` are left untouched)
  *   stat_kind PWW_STAT_* (PWW_STAT_ALL: all four fields): only the fields that statistic is made of are formed, the others hold the
  *             neutral element

@@ -32,7 +32,7 @@ const DebugKnobs &debug_knobs() {
             {"attn_pair_major", &k.attn_pair_major}, {"attn_wide_store", &k.attn_wide_store}, {"cross_wg_per_cu", &k.cross_wg_per_cu},
             {"cross_assume_resident", &k.cross_assume_resident}, {"cross_gate_weight", &k.cross_gate_weight},
             {"cross_tile_nbuf", &k.cross_tile_nbuf}, {"cross_bias_lds", &k.cross_bias_lds}, {"cross_lean", &k.cross_lean},
-            {"cross_lean_nw", &k.cross_lean_nw}, {"attn_ksplit_nw", &k.attn_ksplit_nw}};
+            {"cross_lean_nw", &k.cross_lean_nw}, {"attn_ksplit_nw", &k.attn_ksplit_nw}, {"attn_ksplit1", &k.attn_ksplit1}};
         const char *p = e;
         while (*p) {
             const char *eq = strchr(p, '='), *end = strchr(p, ',');

@@ -301,6 +301,155 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
     tl_cycles(p, tl_c0);
 }
 
+// ---- key-split workgroups for the SMALL launches (round 5): NW row groups x KG key groups, ONE stage buffer --------------------------
+// Self-attention at the coarse UNet levels (SD1.5: N = 1024 d = 80, N = 256 d = 160 at 2 folded rows) has 128 - 512 wave tasks of 32 rows
+// for 1024 SIMDs: with the double-buffered form above (two 128-key stage buffers = 94 KB at d = 80) a workgroup cannot hold more than
+// 2 key groups, every wave walks 8 tiles at one wave per SIMD, and a tile costs ~2800 cycles there (~700 of them MFMA: nothing overlaps
+// the latency chain LDS -> MFMA -> max -> exp -> MFMA of a single wave; profiles/r05_timeline_call2.log). Here the stage buffer is
+// SINGLE (KG x 64 keys of K and V), which makes room for KG = 4 at d = 80 (2 at d = 160): every SIMD runs two waves of different key
+// groups, each walks a QUARTER of the keys, and the next stage's global loads fly under the current stage's compute (registers, parked
+// between two barriers). The KG partial softmax states of a row group are merged once at the end through the then free stage buffer.
+// Staging as in pww_cross_lean.hip: a thread moves one 16-byte column of consecutive row groups (one offset per operand; a pass adds a
+// uniform step), rows past M and the head-dim padding are out of the descriptor's range (zeros: no fill pass), grid = (query block, head, image).
+template <typename T, int KS, int DT, int NW, int KG, bool RSM>
+__global__ void __launch_bounds__(NW * KG * 64, (NW * KG >= 8 ? 2 : 1)) attn_ksplit1_kernel(const AttnParams p) {
+    typedef typename Vec<T>::v8 V8;
+    typedef KTile<KS> KT;
+    typedef VTile<DT> VT;
+    constexpr int NT = NW * KG * 64;
+    constexpr int SROWS = KG * KVBLK;                                          // key rows per stage
+    constexpr int KRPP = NT / KT::CHK, VRPP = NT / VT::CHK;                    // key rows a pass of the workgroup covers
+    constexpr int KPASS = (SROWS + KRPP - 1) / KRPP, VPASS = (SROWS + VRPP - 1) / VRPP;
+    constexpr int K_BYTES = SROWS * KT::STRIDE;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];               // [K rows of the stage][V rows of the stage]; the merge records afterwards
+    char *Kl = smem, *Vl = smem + K_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wave % NW, kg = wave / NW;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    tl_stamp(p, 0);
+
+    const T *Qp = reinterpret_cast<const T *>(p.q) + b * p.q_sb + h * p.q_sh;
+    const T *Kp = reinterpret_cast<const T *>(p.k) + b * p.k_sb + h * p.k_sh;
+    const T *Vp = reinterpret_cast<const T *>(p.v) + b * p.v_sb + h * p.v_sh;
+    T *Op = reinterpret_cast<T *>(p.o) + b * p.o_sb + h * p.o_sh;
+    const int qrow = (qb * NW + rg) * 32 + l31;
+    const bool qvalid = qrow < p.N;
+
+    const auto srd_k = head_srd(Kp, p.M, p.k_sm, p.D);
+    const auto srd_v = head_srd(Vp, p.M, p.v_sm, p.D);
+    const int kr = tid / KT::CHK, kc = tid - kr * KT::CHK;
+    const int vr = tid / VT::CHK, vc = tid - vr * VT::CHK;
+    const bool k_act = kr < KRPP, v_act = vr < VRPP;
+    const unsigned k0 = (k_act && kc * 8 < p.D) ? (unsigned)((kr * p.k_sm + kc * 8) * 2) : OOB_OFF, kstep = (unsigned)(KRPP * p.k_sm * 2);
+    const unsigned v0 = (v_act && vc * 8 < p.D) ? (unsigned)((vr * p.v_sm + vc * 8) * 2) : OOB_OFF, vstep = (unsigned)(VRPP * p.v_sm * 2);
+    const unsigned k_stage = (unsigned)(SROWS * p.k_sm * 2), v_stage = (unsigned)(SROWS * p.v_sm * 2);
+    u32x4 kreg[KPASS], vreg[VPASS];
+    auto request = [&](int st) {      // stage st -> registers (rows past M: out of range, zeros, no traffic; the host bounds the extent below 2^31)
+#pragma unroll
+        for (int i = 0; i < KPASS; ++i) kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_k, k0 + (unsigned)st * k_stage + (unsigned)i * kstep, 0, 0);
+#pragma unroll
+        for (int i = 0; i < VPASS; ++i) vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_v, v0 + (unsigned)st * v_stage + (unsigned)i * vstep, 0, 0);
+    };
+    const T one = (T)1.0f;
+    unsigned short one_bits;
+    __builtin_memcpy(&one_bits, &one, 2);
+    const bool v_one = RSM && vc * 8 == p.D;          // first padding chunk of a V row: channel D = 1.0 (the softmax denominator's column)
+    auto park = [&]() {
+        if (k_act) {
+            char *kd = Kl + kr * KT::STRIDE + kc * 16;
+#pragma unroll
+            for (int i = 0; i < KPASS; ++i)
+                if ((i + 1) * KRPP <= SROWS || i * KRPP + kr < SROWS) *reinterpret_cast<u32x4 *>(kd + i * KRPP * KT::STRIDE) = kreg[i];
+        }
+        if (v_act) {
+            char *vd = Vl + vr * VT::STRIDE + vc * 16;
+#pragma unroll
+            for (int i = 0; i < VPASS; ++i)
+                if ((i + 1) * VRPP <= SROWS || i * VRPP + vr < SROWS) *reinterpret_cast<u32x4 *>(vd + i * VRPP * VT::STRIDE) = v_one ? u32x4{(unsigned)one_bits, 0u, 0u, 0u} : vreg[i];
+        }
+    };
+
+    request(0);
+    V8 qf[KS];
+    load_q_frags<T, KS>(qf, Qp + (long)(qvalid ? qrow : 0) * p.q_sn, true, hi, p.D);      // (rows past N compute on row 0's values and are never stored)
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c1 = p.scale_log2e;
+    BiasRef bias;
+    const int nstage = (p.M + SROWS - 1) / SROWS;
+    park();
+    __syncthreads();
+    tl_stamp(p, 1);
+    for (int st = 0; st < nstage; ++st) {
+        request(st + 1);          // (past the last stage: out of range -- issued anyway: a load under a branch is waited for at the join)
+        const int key0 = st * SROWS + kg * KVBLK;
+        const char *Ks = Kl + kg * KT::BYTES, *Vs = Vl + kg * VT::BYTES;
+        if (key0 + KVBLK <= p.M) attn_tile<T, KS, DT, 0, false, RSM>(oacc, m_run, l_run, qf, Ks, Vs, key0, p.M, l31, hi, bias, 1.f, c1);
+        else if (key0 < p.M) attn_tile<T, KS, DT, 0, true, RSM>(oacc, m_run, l_run, qf, Ks, Vs, key0, p.M, l31, hi, bias, 1.f, c1);
+        __syncthreads();          // every wave is done reading the stage
+        if (st + 1 < nstage) {    // (workgroup-uniform)
+            park();
+            __syncthreads();
+        }
+    }
+    tl_stamp(p, 2);
+
+    // merge the KG partial softmax states of each row group: key groups 1.. publish (m, l, O^T) in LDS, key group 0 folds them
+    constexpr int REC = (DT * 16 + 2) * 64;           // floats per published wave state
+    float *xch = reinterpret_cast<float *>(smem);
+    if (kg > 0) {
+        float *rec = xch + ((kg - 1) * NW + rg) * REC;
+        rec[lane] = m_run;
+        rec[64 + lane] = l_run;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rec[(2 + dt * 16 + r) * 64 + lane] = oacc[dt][r];
+    }
+    __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int g = 1; g < KG; ++g) {
+        const float *rec = xch + ((g - 1) * NW + rg) * REC;
+        const float m_o = rec[lane];
+        const float m_n = fmaxf(m_run, m_o);
+        // a key group that saw no key (m = -inf: a short sequence) contributes nothing
+        const float a_s = m_run == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m_run - m_n) * c1);
+        const float a_o = m_o == -INFINITY ? 0.f : __builtin_amdgcn_exp2f((m_o - m_n) * c1);
+        l_run = l_run * a_s + rec[64 + lane] * a_o;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[dt][r] = oacc[dt][r] * a_s + rec[(2 + dt * 16 + r) * 64 + lane] * a_o;
+        m_run = m_n;
+    }
+    float l_tot;
+    if (RSM) {      // row D of O^T: tile D / 32, register (D % 32) / 2, held by the hi == 0 half
+        const int rl = p.D & 31, tl = p.D >> 5;
+        float lv = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const float c = rl == 0 ? oacc[dt][0] : rl == 8 ? oacc[dt][4] : rl == 16 ? oacc[dt][8] : oacc[dt][12];
+            lv = dt == tl ? c : lv;
+        }
+        const float other = __shfl_xor(lv, 32);
+        l_tot = hi ? other : lv;
+    } else {
+        l_tot = l_run + __shfl_xor(l_run, 32);
+    }
+    const float inv = 1.f / l_tot;
+    store_o_block<T, DT>(Op + (long)(qvalid ? qrow : 0) * p.o_sn, oacc, inv, p.D, hi, qvalid, p.o_wide != 0);
+    tl_stamp(p, 3);
+}
+
 // ---- folded-reference variant (head dims with D % 16 == 8: SD1.x's d = 40) -----------------------------
 // A stage of this kernel costs about the SUM of its LDS, MFMA and VALU times (profiles/r01_attn_phases.md), so the
 // way to make d = 40 faster is to remove work from one of the three. This variant removes VALU work per score:
@@ -727,6 +876,30 @@ static int launch_attn_ksplit(const AttnParams &p, hipStream_t stream) {
     return check_hip(hipGetLastError(), "attn_fwd_kernel<key-split> launch");
 }
 
+// the single-buffer kernel requests one stage past the last key (out of range by construction): keep every offset it forms far below 2^31
+static bool ksplit1_extent_ok(const AttnParams &p) {
+    return (long)(p.M + 512) * p.k_sm * 2 < (1L << 30) && (long)(p.M + 512) * p.v_sm * 2 < (1L << 30);
+}
+
+template <typename T, int KS, int DT, int NW, int KG, bool RSM>
+static int launch_attn_ksplit1(const AttnParams &p, hipStream_t stream) {
+    constexpr size_t stage = (size_t)KG * KVBLK * (KTile<KS>::STRIDE + VTile<DT>::STRIDE);
+    constexpr size_t merge = (size_t)(KG - 1) * NW * (DT * 16 + 2) * 64 * sizeof(float);
+    constexpr size_t lds = stage > merge ? stage : merge;
+    static_assert(lds <= 158 * 1024, "stage buffer of the key-split kernel");
+    const int qblocks = (p.N + NW * 32 - 1) / (NW * 32);
+    if (p.H > 65535 || p.B > 65535) { set_error("attn_fwd: more than 65535 heads or images"); return PWW_EINVAL; }
+    auto kern = attn_ksplit1_kernel<T, KS, DT, NW, KG, RSM>;
+    static thread_local bool done = false;
+    if (!done) {
+        if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"))
+            return PWW_EHIP;
+        done = true;
+    }
+    launch_attn_kernel(kern, dim3((unsigned)qblocks, (unsigned)p.H, (unsigned)p.B), dim3(NW * KG * 64), lds, stream, p);
+    return check_hip(hipGetLastError(), "attn_ksplit1_kernel launch");
+}
+
 static int ksplit_mode() {   // PWW_DEBUG=attn_ksplit=0|1 (A/B testing); default on
     static int mode = -2;
     if (mode == -2) { mode = debug_knobs().attn_ksplit; }
@@ -781,6 +954,11 @@ static int launch_attn(const AttnParams &p, hipStream_t stream) {
         // d = 80 / 96 with at most one 2-wave workgroup per CU (SD1.5 N = 1024 at B <= 2): two key groups -> a wave on
         // every SIMD and half the serial stage count
         const long wgs = (long)((p.N + 63) / 64) * p.B * p.H;
+        if (ksplit_mode() == 1 && debug_knobs().attn_ksplit1 && wgs <= 256 && p.M >= 512 && ksplit1_extent_ok(p)) {
+            // (round 5) 2 row groups x 4 key groups on ONE stage buffer: two waves per SIMD, a quarter of the keys per wave
+            if ((p.D & 31) != 0) return launch_attn_ksplit1<T, KS, DT, 2, 4, true>(p, stream);
+            return launch_attn_ksplit1<T, KS, DT, 2, 4, false>(p, stream);
+        }
         if (ksplit_mode() == 1 && wgs <= 256 && p.M >= 512) {
             if (debug_knobs().attn_ksplit_nw == 4) {      // A/B: 4 row groups x 2 key groups (half the workgroups, half the K / V staging traffic, 2 waves per SIMD on half the CUs)
                 if ((p.D & 31) != 0) return launch_attn_ksplit<T, KS, DT, 4, 2, true>(p, stream);
@@ -788,6 +966,15 @@ static int launch_attn(const AttnParams &p, hipStream_t stream) {
             }
             if ((p.D & 31) != 0) return launch_attn_ksplit<T, KS, DT, 2, 2, true>(p, stream);
             return launch_attn_ksplit<T, KS, DT, 2, 2, false>(p, stream);
+        }
+    }
+    if constexpr (!HAS_BIAS && DT >= 4 && NW == 4) {
+        // (round 5) the widest heads at the coarsest levels (SD1.5 N = 256 d = 160: 32 workgroups of 4 waves walking 4 tiles each): 64-row
+        // workgroups of 2 row groups x 2 key groups -- twice the workgroups, half the tiles per wave
+        const long wgs = (long)((p.N + 63) / 64) * p.B * p.H;
+        if (ksplit_mode() == 1 && debug_knobs().attn_ksplit1 && wgs <= 256 && p.M >= 128 && ksplit1_extent_ok(p)) {
+            if ((p.D & 31) != 0) return launch_attn_ksplit1<T, KS, DT, 2, 2, true>(p, stream);
+            return launch_attn_ksplit1<T, KS, DT, 2, 2, false>(p, stream);
         }
     }
     // head dims with padding columns in the V tile get the row sum from the MFMA (self-attention path)

@@ -39,45 +39,69 @@ struct QkPartsParams {
     int fields;               // bit 0 max, 1 min, 2 sum, 3 sum of squares
 };
 
-template <typename T, int KS>
+// Granularity. FINE: one wave per (head, 32-row block, 32-key block) -- a partial per wave, H * nrb * nkb per image; nothing but
+// load -> MFMA -> reduce -> store: for the coarse UNet levels (N <= 576), where the point is to put ~200 independent waves on the chip.
+// COARSE (H * nrb * nkb > 256: the consumer folds at most 256 partials from its prologue's load batch, more cost it a round trip per 64):
+// one wave per (head, 32-row block) walks the key blocks (the next block's K fragments in flight under the current block's MFMAs), the four
+// waves of a workgroup meet in LDS, ONE partial per workgroup: H * ceil(nrb / 4) per image.
+// Grid (blockIdx.x: row-block / unit groups, y: head, z: image): no integer division on the way to the first load.
+constexpr int QKP_MAX_FINE = 256;
+
+template <typename T, int KS, bool COARSE>
 __global__ void __launch_bounds__(256) qk_parts_kernel(const QkPartsParams p) {
     typedef typename Vec<T>::v8 V8;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
-    const long unit = (long)blockIdx.x * 4 + wave;
-    const int b = __builtin_amdgcn_readfirstlane((int)(unit / p.nparts));        // (wave-uniform: scalars, so that the descriptors below are)
-    if (b >= p.n_img) return;
-    const int u = __builtin_amdgcn_readfirstlane((int)(unit - (long)b * p.nparts));
-    // unit -> (head, row block, key block): key blocks fastest (the waves of a workgroup share a Q block), heads slowest
-    const int kb = __builtin_amdgcn_readfirstlane(u % p.nkb), rb = __builtin_amdgcn_readfirstlane((u / p.nkb) % p.nrb), h = __builtin_amdgcn_readfirstlane(u / (p.nkb * p.nrb));
+    const int b = blockIdx.z, h = blockIdx.y;
     const float gate = p.gate ? p.gate[b] : 1.f;                  // requested with everything else, looked at before the store
     const T *Qp = reinterpret_cast<const T *>(p.q) + b * p.q_sb + h * p.q_sh;
     const T *Kp = reinterpret_cast<const T *>(p.k) + b * p.k_sb + h * p.k_sh;
     const auto srd_q = head_srd(Qp, p.N, p.q_sn, p.D);
     const auto srd_k = head_srd(Kp, p.M, p.k_sm, p.D);
-    const int qrow = rb * 32 + l31, krow = kb * 32 + swap23(l31);
-    V8 qf[KS], kf[KS];
-    load_q_frags_buf<T, KS>(qf, srd_q, qrow < p.N ? (unsigned)((long)qrow * p.q_sn * 2) : OOB_OFF, hi, p.D);
-    load_q_frags_buf<T, KS>(kf, srd_k, krow < p.M ? (unsigned)((long)krow * p.k_sm * 2) : OOB_OFF, hi, p.D);
-    f32x16 s;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) s = mfma32(kf[ks], qf[ks], s);
-    // register r = key kb * 32 + 16 (r >> 3) + 8 hi + (r & 7) of row qrow. Rows past N / keys past M were loaded as zeros: their scores
-    // are exactly 0 and leave the sums alone; the extremes take them out with a select.
-    const bool rvalid = qrow < p.N;
-    float vmax = -INFINITY, vmin = INFINITY, vsum = 0.f, vsq = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const bool live = rvalid && kb * 32 + 16 * (r >> 3) + 8 * hi + (r & 7) < p.M;
-        const float x = s[r];
-        vmax = fmaxf(vmax, live ? x : -INFINITY);
-        vmin = fminf(vmin, live ? x : INFINITY);
-        vsum += x;
-        vsq = fmaf(x, x, vsq);
+    int rb, kb0;
+    if constexpr (COARSE) { rb = blockIdx.x * 4 + wave; kb0 = 0; }
+    else {
+        const int f = blockIdx.x * 4 + wave;          // (row block, key block), key blocks fastest; nkb <= 4: divisions by constants
+        rb = p.nkb == 3 ? f / 3 : p.nkb == 2 ? f >> 1 : p.nkb == 4 ? f >> 2 : f;
+        kb0 = f - rb * p.nkb;
+        if (rb >= p.nrb) return;                      // (wave-uniform; the fine form has no barrier)
     }
-    double dsum = (double)vsum, dsq = (double)vsq;
+    const int qrow = rb * 32 + l31;
+    const bool rvalid = qrow < p.N;                   // (COARSE: a row block past the last one only contributes neutral elements)
+    const unsigned k_lane = (unsigned)((long)swap23(l31) * p.k_sm * 2), k_blk = (unsigned)(32 * p.k_sm * 2);
+    // rows past N / keys past M lie beyond the descriptors: zeros, no memory traffic, no compare on the way to the load
+    V8 qf[KS], kf[2][KS];
+    load_q_frags_buf<T, KS>(qf, srd_q, (unsigned)((long)qrow * p.q_sn * 2), hi, p.D);
+    load_q_frags_buf<T, KS>(kf[0], srd_k, k_lane + (unsigned)kb0 * k_blk, hi, p.D);
+    float vmax = -INFINITY, vmin = INFINITY;
+    double dsum = 0.0, dsq = 0.0;
+    constexpr int NKB = COARSE ? 4 : 1;
+#pragma unroll
+    for (int i = 0; i < NKB; ++i) {
+        const int kb = kb0 + i;
+        if (COARSE && i + 1 < NKB) load_q_frags_buf<T, KS>(kf[(i + 1) & 1], srd_k, k_lane + (unsigned)(kb + 1) * k_blk, hi, p.D);
+        if (!COARSE || kb < p.nkb) {                  // (wave-uniform)
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) s = mfma32(kf[i & 1][ks], qf[ks], s);
+            // register r = key kb * 32 + 16 (r >> 3) + 8 hi + (r & 7) of row qrow. Rows past N / keys past M were loaded as zeros: their
+            // scores are exactly 0 and leave the sums alone; the extremes take them out with a select.
+            float usum = 0.f, usq = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool live = rvalid && kb * 32 + 16 * (r >> 3) + 8 * hi + (r & 7) < p.M;
+                const float x = s[r];
+                vmax = fmaxf(vmax, live ? x : -INFINITY);
+                vmin = fminf(vmin, live ? x : INFINITY);
+                usum += x;
+                usq = fmaf(x, x, usq);
+            }
+            dsum += (double)usum;
+            dsq += (double)usq;
+        }
+    }
     if (p.fields & 1) {
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off));
@@ -94,8 +118,21 @@ __global__ void __launch_bounds__(256) qk_parts_kernel(const QkPartsParams p) {
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) dsq += __shfl_xor(dsq, off);
     }
-    if (lane == 0 && gate != 0.f) {       // (a gated-out image's rows are left untouched, like pww_qproj_stat)
-        double *out = p.partials + ((long)b * p.nparts + u) * 4;
+    if constexpr (COARSE) {
+        __shared__ double red[4][4];
+        if (lane == 0) { red[wave][0] = (double)vmax; red[wave][1] = (double)vmin; red[wave][2] = dsum; red[wave][3] = dsq; }
+        __syncthreads();
+        if (threadIdx.x == 0 && gate != 0.f) {
+            double m = red[0][0], n = red[0][1], su = red[0][2], sq = red[0][3];
+            for (int w = 1; w < 4; ++w) { m = fmax(m, red[w][0]); n = fmin(n, red[w][1]); su += red[w][2]; sq += red[w][3]; }
+            double *out = p.partials + ((long)b * p.nparts + (long)h * gridDim.x + blockIdx.x) * 4;
+            out[0] = (p.fields & 1) ? m : -INFINITY;
+            out[1] = (p.fields & 2) ? n : INFINITY;
+            out[2] = (p.fields & 4) ? su : 0.0;
+            out[3] = (p.fields & 8) ? sq : 0.0;
+        }
+    } else if (lane == 0 && gate != 0.f) {       // (a gated-out image's rows are left untouched, like pww_qproj_stat)
+        double *out = p.partials + ((long)b * p.nparts + ((long)h * p.nrb + rb) * p.nkb + kb0) * 4;
         out[0] = (p.fields & 1) ? (double)vmax : -INFINITY;
         out[1] = (p.fields & 2) ? (double)vmin : INFINITY;
         out[2] = (p.fields & 4) ? dsum : 0.0;
@@ -103,9 +140,14 @@ __global__ void __launch_bounds__(256) qk_parts_kernel(const QkPartsParams p) {
     }
 }
 
+static bool qk_parts_coarse(const pww_attn_desc_t *d) {
+    return (long)d->H * ((d->N + 31) / 32) * ((d->M + 31) / 32) > QKP_MAX_FINE;
+}
+
 int qk_parts_count(const pww_attn_desc_t *d) {
-    if (!d || d->B <= 0 || d->H <= 0 || d->N <= 0 || d->M <= 0 || d->D <= 0 || d->D % 8 || d->D > PWW_MAX_HEAD_DIM) return 0;
-    const long n = (long)d->H * ((d->N + 31) / 32) * ((d->M + 31) / 32);
+    if (!d || d->B <= 0 || d->H <= 0 || d->N <= 0 || d->M <= 0 || d->M > 128 || d->D <= 0 || d->D % 8 || d->D > PWW_MAX_HEAD_DIM) return 0;
+    const long nrb = (d->N + 31) / 32;
+    const long n = qk_parts_coarse(d) ? (long)d->H * ((nrb + 3) / 4) : (long)d->H * nrb * ((d->M + 31) / 32);
     return n > 0x7fffffffL ? 0 : (int)n;
 }
 
@@ -128,7 +170,7 @@ int qk_parts(const void *q, const void *k, const float *gate, const pww_attn_des
     if (!arch_ok()) return PWW_ENOTSUP;
     if (d->dtype != PWW_DTYPE_F16 && d->dtype != PWW_DTYPE_BF16) { set_error("qk_parts: dtype %d unsupported", d->dtype); return PWW_ENOTSUP; }
     const int nparts = qk_parts_count(d);
-    if (nparts <= 0) { set_error("qk_parts: unsupported problem (B=%d H=%d N=%d M=%d D=%d; D a multiple of 8, <= %d)", d->B, d->H, d->N, d->M, d->D, PWW_MAX_HEAD_DIM); return PWW_ENOTSUP; }
+    if (nparts <= 0) { set_error("qk_parts: unsupported problem (B=%d H=%d N=%d M=%d D=%d; D a multiple of 8, <= %d; M <= 128)", d->B, d->H, d->N, d->M, d->D, PWW_MAX_HEAD_DIM); return PWW_ENOTSUP; }
     const int fields = stat_fields(stat_kind);
     if (fields <= 0) { set_error("qk_parts: bad statistic selector %d", stat_kind); return PWW_EINVAL; }
     if ((reinterpret_cast<uintptr_t>(q) & 15) || (reinterpret_cast<uintptr_t>(k) & 15) || (reinterpret_cast<uintptr_t>(partials) & 15)) {
@@ -150,20 +192,27 @@ int qk_parts(const void *q, const void *k, const float *gate, const pww_attn_des
     p.nrb = (d->N + 31) / 32; p.nkb = (d->M + 31) / 32; p.nparts = nparts;
     p.n_img = (gate && gated_images > 0 && gated_images < d->B) ? gated_images : d->B;
     p.fields = fields;
-    const long units = (long)p.n_img * nparts;
-    const dim3 grid((unsigned)((units + 3) / 4));
-#define PWW_QKP(T)                                                                                     \
-    do {                                                                                               \
-        const int ks = (d->D + 15) / 16;                                                               \
-        if (ks <= 3) launch_attn_kernel(qk_parts_kernel<T, 3>, grid, dim3(256), 0, stream, p);         \
-        else if (ks == 4) launch_attn_kernel(qk_parts_kernel<T, 4>, grid, dim3(256), 0, stream, p);    \
-        else if (ks == 5) launch_attn_kernel(qk_parts_kernel<T, 5>, grid, dim3(256), 0, stream, p);    \
-        else if (ks == 6) launch_attn_kernel(qk_parts_kernel<T, 6>, grid, dim3(256), 0, stream, p);    \
-        else if (ks <= 8) launch_attn_kernel(qk_parts_kernel<T, 8>, grid, dim3(256), 0, stream, p);    \
-        else launch_attn_kernel(qk_parts_kernel<T, 10>, grid, dim3(256), 0, stream, p);                \
+    if (d->H > 65535 || p.n_img > 65535) { set_error("qk_parts: more than 65535 heads or images"); return PWW_ENOTSUP; }
+    const bool coarse = qk_parts_coarse(d);
+    const dim3 grid(coarse ? (unsigned)((p.nrb + 3) / 4) : (unsigned)(((long)p.nrb * p.nkb + 3) / 4), (unsigned)d->H, (unsigned)p.n_img);
+#define PWW_QKP1(T, KSV)                                                                                          \
+    do {                                                                                                           \
+        if (coarse) launch_attn_kernel(qk_parts_kernel<T, KSV, true>, grid, dim3(256), 0, stream, p);             \
+        else launch_attn_kernel(qk_parts_kernel<T, KSV, false>, grid, dim3(256), 0, stream, p);                   \
+    } while (0)
+#define PWW_QKP(T)                                      \
+    do {                                                \
+        const int ks = (d->D + 15) / 16;                \
+        if (ks <= 3) PWW_QKP1(T, 3);                    \
+        else if (ks == 4) PWW_QKP1(T, 4);               \
+        else if (ks == 5) PWW_QKP1(T, 5);               \
+        else if (ks == 6) PWW_QKP1(T, 6);               \
+        else if (ks <= 8) PWW_QKP1(T, 8);               \
+        else PWW_QKP1(T, 10);                           \
     } while (0)
     if (d->dtype == PWW_DTYPE_F16) PWW_QKP(f16); else PWW_QKP(bf16);
 #undef PWW_QKP
+#undef PWW_QKP1
     return check_hip(hipGetLastError(), "qk_parts_kernel launch");
 }
 
@@ -181,7 +230,17 @@ struct LeanParams {
 
 constexpr int LEAN_PUNROLL = 4;        // partials per lane folded from the prologue's load batch (256 per image); more take the tail loop
 constexpr int LEAN_TILE_LOADS = 8;     // 16-byte pieces per lane of a wave's 32 bias rows: 64 columns at most
+constexpr int LEAN_ROWS = 2 * KVBLK;   // key rows the LDS image has room for (one stage of two 64-key tiles)
 
+// LDS image: [K rows 0 .. 127][V rows 0 .. 127][bias tile]: the 64-key tile t of K sits at t * KTile::BYTES, of V at 128 rows of K + t * VTile::BYTES
+// (row-linear, so a thread's chunk of pass i is its chunk of pass 0 plus a compile-time constant).
+//
+// The prologue is written for INSTRUCTION COUNT: at one wave per SIMD a wave issues one instruction every ~5 cycles, and round 5's first
+// version of this kernel spent 2.9 us (~1500 instructions of per-chunk index arithmetic, validity compares and exec-mask branches) before
+// its last load was issued (profiles/r05_timeline_call2.log). Here a thread moves the SAME 16-byte column of consecutive row groups: one
+// offset and one LDS address per operand, computed once; pass i adds a uniform step (global side) and an immediate (LDS side); rows past
+// M, the head-dim padding and idle threads are out of range of the buffer descriptor (zeros, no memory traffic) -- no compare, no select,
+// no branch per chunk. Grid = (query block, head, image): no integer division either.
 template <typename T, int KS, int DT, int NW>
 __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_lean_kernel(const LeanParams lp) {
     typedef typename Vec<T>::v8 V8;
@@ -189,29 +248,19 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_lean_kernel(
     typedef VTile<DT> VT;
     constexpr bool RSM = KS * 16 < DT * 32;      // padding channels in the V tile: channel D is a column of ones, the PV MFMAs deliver the row sums
     constexpr int NT = NW * 64;
-    constexpr int SUB_BYTES = KT::BYTES + VT::BYTES;
-    constexpr int STAGE_BYTES = 2 * SUB_BYTES;
-    constexpr int KPT = (2 * KT::NCHUNK + NT - 1) / NT;
-    constexpr int VPT = (2 * VT::NCHUNK + NT - 1) / NT;
+    constexpr int KRPP = NT / KT::CHK, VRPP = NT / VT::CHK;                   // key rows a pass of the workgroup covers
+    constexpr int KPASS = (LEAN_ROWS + KRPP - 1) / KRPP, VPASS = (LEAN_ROWS + VRPP - 1) / VRPP;
+    constexpr int K_BYTES = LEAN_ROWS * KT::STRIDE, V_BYTES = LEAN_ROWS * VT::STRIDE;
     const AttnParams &p = lp.a;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // [K|V stage: two 64-key sub-tiles][bias tile: NW x 32 rows]
-    char *tile = smem + STAGE_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *Kl = smem, *Vl = smem + K_BYTES, *tile = smem + K_BYTES + V_BYTES;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
-    const int BH = p.B * p.H;
+    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;      // query block c of every head on XCD c % 8 when there are 8 k blocks: the heads share its bias rows
     tl_stamp(p, 0);
-    // workgroup -> (image, head, query block): query block c on XCD c % 8 for every head (the heads of an image share the bias rows of a block)
-    // (readfirstlane: the integer divisions run on the vector ALU, and behind the debug stamp's divergent branch hipcc no longer proves their
-    // results uniform -- every buffer descriptor built from b / h would then be loaded through a waterfall loop)
-    int bh, qb;
-    if ((lp.nqb & 7) == 0) { const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3; bh = j % BH; qb = (j / BH) * 8 + xcd; }
-    else { bh = blockIdx.x % BH; qb = blockIdx.x / BH; }
-    bh = __builtin_amdgcn_readfirstlane(bh);
-    qb = __builtin_amdgcn_readfirstlane(qb);
-    const int b = __builtin_amdgcn_readfirstlane(bh / p.H), h = bh - b * p.H;
 
     // ---- every global load of the workgroup, before anything is waited for: gate, partials, Q fragments, K / V chunks, bias rows
     const float gate = p.bias_coeff ? p.bias_coeff[b] : 1.f;
@@ -229,11 +278,11 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_lean_kernel(
         // (without partials the descriptor covers zero bytes: the loads return zeros without touching memory)
         const unsigned bytes = (need_stat && lp.parts && maybe_biased) ? (unsigned)lp.nparts * 32u : 0u;
         const auto srd_e = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(lp.parts + (lp.parts ? (long)b * lp.nparts * 4 : 0)), 0, bytes, 0x00020000);
+        const unsigned lo0 = want_lo ? (unsigned)lane * 32u : OOB_OFF, hi0 = want_hi ? (unsigned)lane * 32u + 16u : OOB_OFF;
 #pragma unroll
         for (int j = 0; j < LEAN_PUNROLL; ++j) {
-            const unsigned off = (unsigned)(lane + j * 64) * 32u;
-            plo[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_e, want_lo ? off : OOB_OFF, 0, 0);
-            phi[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_e, want_hi ? off + 16u : OOB_OFF, 0, 0);
+            plo[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_e, lo0 + (unsigned)(j * 2048), 0, 0);
+            phi[j] = __builtin_amdgcn_raw_buffer_load_b128(srd_e, hi0 + (unsigned)(j * 2048), 0, 0);
         }
     }
     const T *Qp = reinterpret_cast<const T *>(p.q) + b * p.q_sb + h * p.q_sh;
@@ -243,48 +292,38 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_lean_kernel(
     const int qrow = (qb * NW + wave) * 32 + l31;
     const bool qvalid = qrow < p.N;
     V8 qf[KS];
-    load_q_frags_buf<T, KS>(qf, head_srd(Qp, p.N, p.q_sn, p.D), qvalid ? (unsigned)((long)qrow * p.q_sn * 2) : OOB_OFF, hi, p.D);
+    load_q_frags_buf<T, KS>(qf, head_srd(Qp, p.N, p.q_sn, p.D), (unsigned)((long)qrow * p.q_sn * 2), hi, p.D);      // (rows past N: beyond the descriptor)
 
-    // K / V: rows [0, ceil32(M)) of both tiles, EVERY 16-byte chunk of a row including the head-dim padding -- padding chunks and rows past
-    // M carry an out-of-range offset and arrive as zeros (no zero-fill pass, no barrier for it); rows nobody reads are not touched at all
-    u32x4 kreg[KPT], vreg[VPT];
-    int k_lds[KPT], v_lds[VPT];
-    bool k_ok[KPT], v_ok[VPT], v_one[VPT];
+    // K / V: thread -> (row kr of a pass, 16-byte column kc); pass i = rows i * KRPP .. of the head
+    u32x4 kreg[KPASS], vreg[VPASS];
+    const int kr = tid / KT::CHK, kc = tid - kr * KT::CHK;
+    const int vr = tid / VT::CHK, vc = tid - vr * VT::CHK;
+    const bool k_act = kr < KRPP, v_act = vr < VRPP;
     {
-        const int rows = min(2 * KVBLK, (p.M + 31) & ~31);
         const auto srd_k = head_srd(Kp, p.M, p.k_sm, p.D);
         const auto srd_v = head_srd(Vp, p.M, p.v_sm, p.D);
+        const unsigned k0 = (k_act && kc * 8 < p.D) ? (unsigned)((kr * p.k_sm + kc * 8) * 2) : OOB_OFF, kstep = (unsigned)(KRPP * p.k_sm * 2);
+        const unsigned v0 = (v_act && vc * 8 < p.D) ? (unsigned)((vr * p.v_sm + vc * 8) * 2) : OOB_OFF, vstep = (unsigned)(VRPP * p.v_sm * 2);
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const int c = tid + i * NT, key = c / KT::CHK, ch = c - key * KT::CHK;
-            k_ok[i] = key < rows;
-            k_lds[i] = (key >> 6) * SUB_BYTES + (key & 63) * KT::STRIDE + ch * 16;
-            kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_k, (k_ok[i] && ch * 8 < p.D) ? (unsigned)((key * p.k_sm + ch * 8) * 2) : OOB_OFF, 0, 0);
-        }
+        for (int i = 0; i < KPASS; ++i) kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_k, k0 + (unsigned)i * kstep, 0, 0);
 #pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            const int c = tid + i * NT, key = c / VT::CHK, ch = c - key * VT::CHK;
-            v_ok[i] = key < rows;
-            v_one[i] = RSM && ch * 8 == p.D;          // first padding chunk: channel D = 1.0 (the softmax denominator's column)
-            v_lds[i] = (key >> 6) * SUB_BYTES + KT::BYTES + (key & 63) * VT::STRIDE + ch * 16;
-            vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_v, (v_ok[i] && ch * 8 < p.D) ? (unsigned)((key * p.v_sm + ch * 8) * 2) : OOB_OFF, 0, 0);
-        }
+        for (int i = 0; i < VPASS; ++i) vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(srd_v, v0 + (unsigned)i * vstep, 0, 0);
     }
-    // bias rows of THIS WAVE's 32 query rows (wave-private piece of the tile: no barrier between its store and its reads)
+    // bias rows of THIS WAVE's 32 query rows (wave-private piece of the tile: no barrier between its store and its reads): lane -> (row
+    // rowl0 of a pass, 16-byte column pc); a pass covers 64 / cpr rows, cpr / 2 passes
     const int cprl = lp.tile_stride == 16 ? 2 : lp.tile_stride == 32 ? 3 : 4;      // log2 of the 16-byte chunks per tile row
+    const int pc = lane & ((1 << cprl) - 1), rowl0 = lane >> cprl, tile_passes = 1 << (cprl - 1), tile_rp = 64 >> cprl;
+    const bool t_col = pc * 4 < p.bias_cols;
     u32x4 treg[LEAN_TILE_LOADS];
     BiasRef bias;
-    if (maybe_biased) {
+    if (maybe_biased) {       // (uniform, from the kernel arguments)
         const float *bbase = p.bias + b * p.b_sb + h * p.b_sh;
         const unsigned bytes = (unsigned)((((long)(p.N - 1) * p.b_sn + (long)(p.M - 1) * p.b_sm) + 1) * 4);
         bias.srd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bbase), 0, bytes, 0x00020000);
-        const long row0 = (long)(qb * NW + wave) * 32;
+        // (rows past N lie beyond the descriptor for a dense map; a row-broadcast map returns in-range values that nobody stores)
+        const unsigned t0 = t_col ? (unsigned)((((long)(qb * NW + wave) * 32 + rowl0) * p.b_sn + pc * 4) * 4) : OOB_OFF, tstep = (unsigned)(tile_rp * p.b_sn * 4);
 #pragma unroll
-        for (int i = 0; i < LEAN_TILE_LOADS; ++i) {
-            const int g = lane + i * 64, rowl = g >> cprl, pc = g & ((1 << cprl) - 1);
-            const bool ok = rowl < 32 && pc * 4 < p.bias_cols && row0 + rowl < p.N;
-            treg[i] = __builtin_amdgcn_raw_buffer_load_b128(bias.srd, ok ? (unsigned)(((row0 + rowl) * p.b_sn + pc * 4) * 4) : OOB_OFF, 0, 0);
-        }
+        for (int i = 0; i < LEAN_TILE_LOADS; ++i) treg[i] = __builtin_amdgcn_raw_buffer_load_b128(bias.srd, i < tile_passes ? t0 + (unsigned)i * tstep : OOB_OFF, 0, 0);
     }
     tl_stamp(p, 6);
 
@@ -340,24 +379,34 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_lean_kernel(
     }
     tl_stamp(p, 3);
 
-    // ---- park K / V and the wave's bias rows, ONE barrier
+    // ---- park K / V (whole 32-key blocks up to M: rows past M arrived as zeros) and the wave's bias rows, ONE barrier
+    const int rows = min(LEAN_ROWS, (p.M + 31) & ~31);
+    if (k_act) {
+        char *kd = Kl + kr * KT::STRIDE + kc * 16;
 #pragma unroll
-    for (int i = 0; i < KPT; ++i)
-        if (k_ok[i]) *reinterpret_cast<u32x4 *>(smem + k_lds[i]) = kreg[i];
-    {
+        for (int i = 0; i < KPASS; ++i)
+            if (i * KRPP < rows && ((i + 1) * KRPP <= LEAN_ROWS || i * KRPP + kr < LEAN_ROWS))      // (first test uniform; the second is a constant except in the last pass)
+                *reinterpret_cast<u32x4 *>(kd + i * KRPP * KT::STRIDE) = kreg[i];
+    }
+    if (v_act) {
+        char *vd = Vl + vr * VT::STRIDE + vc * 16;
         const T one = (T)1.0f;
         unsigned short one_bits;
         __builtin_memcpy(&one_bits, &one, 2);
+        const bool v_one = RSM && vc * 8 == p.D;          // first padding chunk: channel D = 1.0 (the softmax denominator's column)
 #pragma unroll
-        for (int i = 0; i < VPT; ++i)
-            if (v_ok[i]) *reinterpret_cast<u32x4 *>(smem + v_lds[i]) = v_one[i] ? u32x4{(unsigned)one_bits, 0u, 0u, 0u} : vreg[i];
+        for (int i = 0; i < VPASS; ++i)
+            if (i * VRPP < rows && ((i + 1) * VRPP <= LEAN_ROWS || i * VRPP + vr < LEAN_ROWS))
+                *reinterpret_cast<u32x4 *>(vd + i * VRPP * VT::STRIDE) = v_one ? u32x4{(unsigned)one_bits, 0u, 0u, 0u} : vreg[i];
     }
     if (biased) {
+        if (t_col) {
 #pragma unroll
-        for (int i = 0; i < LEAN_TILE_LOADS; ++i) {
-            const int g = lane + i * 64, rowl = g >> cprl, pc = g & ((1 << cprl) - 1), row = wave * 32 + rowl;
-            if (rowl < 32 && pc * 4 < p.bias_cols)
-                *reinterpret_cast<u32x4 *>(tile + (long)row * lp.tile_stride * 4 + ((pc ^ tile_swz(row, 1 << cprl)) << 4)) = treg[i];
+            for (int i = 0; i < LEAN_TILE_LOADS; ++i)
+                if (i < tile_passes) {
+                    const int row = wave * 32 + rowl0 + i * tile_rp;
+                    *reinterpret_cast<u32x4 *>(tile + (long)row * lp.tile_stride * 4 + ((pc ^ tile_swz(row, 1 << cprl)) << 4)) = treg[i];
+                }
         }
         bias_ref_tile(bias, tile, wave * 32 + l31, lp.tile_stride, p.bias_cols, hi);
     }
@@ -370,13 +419,13 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_lean_kernel(
     f32x16 oacc[DT];
     float m_run = -INFINITY, l_run = 0.f;
     if (biased) {
-        attn_tile<T, KS, DT, 2, false, RSM, 1>(oacc, m_run, l_run, qf, smem, smem + KT::BYTES, 0, p.M, l31, hi, bias, coeff, c1);
+        attn_tile<T, KS, DT, 2, false, RSM, 1>(oacc, m_run, l_run, qf, Kl, Vl, 0, p.M, l31, hi, bias, coeff, c1);
         if (KVBLK < p.M)
-            attn_tile<T, KS, DT, 2, true, RSM, 2>(oacc, m_run, l_run, qf, smem + SUB_BYTES, smem + SUB_BYTES + KT::BYTES, KVBLK, p.M, l31, hi, bias, coeff, c1);
+            attn_tile<T, KS, DT, 2, true, RSM, 2>(oacc, m_run, l_run, qf, Kl + KT::BYTES, Vl + VT::BYTES, KVBLK, p.M, l31, hi, bias, coeff, c1);
     } else {
-        attn_tile<T, KS, DT, 0, false, RSM, 1>(oacc, m_run, l_run, qf, smem, smem + KT::BYTES, 0, p.M, l31, hi, bias, coeff, c1);
+        attn_tile<T, KS, DT, 0, false, RSM, 1>(oacc, m_run, l_run, qf, Kl, Vl, 0, p.M, l31, hi, bias, coeff, c1);
         if (KVBLK < p.M)
-            attn_tile<T, KS, DT, 0, true, RSM, 2>(oacc, m_run, l_run, qf, smem + SUB_BYTES, smem + SUB_BYTES + KT::BYTES, KVBLK, p.M, l31, hi, bias, coeff, c1);
+            attn_tile<T, KS, DT, 0, true, RSM, 2>(oacc, m_run, l_run, qf, Kl + KT::BYTES, Vl + VT::BYTES, KVBLK, p.M, l31, hi, bias, coeff, c1);
     }
     float l_tot;
     if (RSM) {      // row D of O^T: tile D / 32, register (D % 32) / 2, held by the hi == 0 half
@@ -405,7 +454,7 @@ static int lean_nw_knob() { return debug_knobs().cross_lean_nw; }
 
 template <typename T, int KS, int DT, int NW>
 static int launch_lean(LeanParams lp, hipStream_t stream) {
-    constexpr size_t stage = 2 * (KTile<KS>::BYTES + VTile<DT>::BYTES);
+    constexpr size_t stage = (size_t)LEAN_ROWS * (KTile<KS>::STRIDE + VTile<DT>::STRIDE);
     const size_t lds = stage + (size_t)NW * 32 * lp.tile_stride * 4;
     auto kern = cross_lean_kernel<T, KS, DT, NW>;
     if (lds > 64 * 1024) {
@@ -419,8 +468,8 @@ static int launch_lean(LeanParams lp, hipStream_t stream) {
         }
     }
     lp.nqb = (lp.a.N + NW * 32 - 1) / (NW * 32);
-    const long wgs = (long)lp.a.B * lp.a.H * lp.nqb;
-    launch_attn_kernel(kern, dim3((unsigned)wgs), dim3(NW * 64), lds, stream, lp);
+    if (lp.a.H > 65535 || lp.a.B > 65535) { set_error("cross_attn_lean: more than 65535 heads or images"); return PWW_EINVAL; }
+    launch_attn_kernel(kern, dim3((unsigned)lp.nqb, (unsigned)lp.a.H, (unsigned)lp.a.B), dim3(NW * 64), lds, stream, lp);
     return check_hip(hipGetLastError(), "cross_lean_kernel launch");
 }
 
@@ -453,6 +502,8 @@ int cross_attn_lean(const void *q, const void *k, const void *v, void *o, const 
     int bias_cols = op.bias_cols > 0 ? ((op.bias_cols + 15) & ~15) : m16;
     if (bias_cols > m16) bias_cols = m16;
     if (bias_cols > 64) return PWW_OK;
+    // (the kernel forms offsets of rows just past N / M before the descriptors cut them off: keep them below 2^31)
+    if (((long)(d->N + 128) * d->q_stride[2] + d->D) * 2 >= (1L << 31) || (long)(d->N + 128) * d->bias_stride[2] * 4 >= (1L << 31)) return PWW_OK;
     const long blocks128 = (long)d->B * d->H * ((d->N + 127) / 128);
     if (mode == 1 && blocks128 > LEAN_MAX_BLOCKS128) return PWW_OK;
     LeanParams lp;

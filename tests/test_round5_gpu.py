@@ -169,10 +169,12 @@ def test_default_path_has_no_handoff_state_on_any_layer(gpu_device):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("N,C,H", [(1024, 640, 8), (256, 1280, 8), (64, 1280, 8), (576, 1280, 20), (2304, 640, 10), (300, 768, 8)])
+@pytest.mark.parametrize("N,C,H", [(1024, 640, 8), (256, 1280, 8), (64, 1280, 8), (576, 1280, 20), (2304, 640, 10), (300, 768, 8),
+                                   (600, 640, 8), (200, 1280, 8), (256, 1024, 8), (512, 768, 8), (130, 1280, 8), (515, 640, 4)])
 def test_small_self_attention_vs_fp64_and_repeatable(gpu_device, dtype, N, C, H):
-    """Self-attention at the coarse UNet levels (the launches the K-fragment prefetch of round 5 is about): vs fp64 on the same rounded
-    q / k / v inside the per-call bar, and bit-identical from run to run."""
+    """Self-attention at the coarse UNet levels (round 5: K fragments prefetched; N >= 512 at d = 80 / 96 and N >= 128 at d = 128 / 160 on
+    the single-buffered key-split kernel -- ragged last stages, key groups that see no key at all): vs fp64 on the same rounded q / k / v
+    inside the per-call bar, and bit-identical from run to run."""
     from pww_hip import ops
     D = C // H
     g = torch.Generator().manual_seed(N + C)
