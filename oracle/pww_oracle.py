@@ -299,14 +299,17 @@ def cfg_combine(cond, uncond, guidance_scale):
 
 
 def sample_latents(unet, scheduler, cond, uncond, latents, num_inference_steps, guidance_scale, weight_function,
-                   extra_channels=None, on_step=None):
+                   extra_channels=None, on_step=None, t_start=None):
     """:431, :457, :471-506 (inpaint: paint_with_words_inpaint.py:230-266 with `extra_channels` =
     cat([mask, masked_image_latents]) appended to the latent input). Two batch-1 UNet calls per step
-    (cond dict, then uncond dict with a zero weight function), CFG, scheduler.step."""
+    (cond dict, then uncond dict with a zero weight function), CFG, scheduler.step. `t_start` (img2img, :434-441): the loop walks
+    scheduler.timesteps[t_start:] over latents that already carry their noise (no init_noise_sigma scaling, :459-468)."""
     scheduler.set_timesteps(num_inference_steps)
-    latents = latents * scheduler.init_noise_sigma
-    for i, t in enumerate(scheduler.timesteps):
-        sigma = scheduler.sigmas[i]
+    if t_start is None:
+        latents = latents * scheduler.init_noise_sigma
+    first = 0 if t_start is None else t_start
+    for i, t in enumerate(scheduler.timesteps[first:], first):
+        sigma = scheduler.sigmas[i]      # (:473-474: the step index of t in the FULL schedule)
         x = scheduler.scale_model_input(latents, t)
         if extra_channels is not None:
             x = torch.cat([x, extra_channels], dim=1)
@@ -332,6 +335,28 @@ def paint_with_words_latents(color_context, color_map_rgb, input_prompt, unet, t
     latents = initial_latents(seed, unet.in_channels, H, W, regions, extra_seeds)
     return sample_latents(unet, scheduler, cond, uncond, latents, num_inference_steps, guidance_scale,
                           weight_function)
+
+
+def paint_with_words_img2img_latents(color_context, color_map_rgb, input_prompt, init_rgb, vae, unet, text_encoder, tokenizer, scheduler,
+                                     num_inference_steps=30, guidance_scale=7.5, strength=0.5,
+                                     weight_function=lambda w, sigma, qk: 0.1 * w * math.log(sigma + 1) * qk.max(),
+                                     unconditional_input_prompt=""):
+    """:391-506, img2img branch, up to the final latent: the shortened schedule of :434-441 (strength -> t_start), the init image through
+    `preprocess` (:28-35; here for sides that are multiples of 32: no resampling) and the VAE encoder, x 0.18215, noise from the GLOBAL
+    torch generator (:464: `torch.randn(shape)` without a generator -- the caller seeds it), scheduler.add_noise at the first kept
+    timestep (:467), then the loop of :471-506 from t_start."""
+    H, W = init_rgb.shape[:2]
+    assert H % 32 == 0 and W % 32 == 0
+    _, _, cond, uncond = encode_text_color_inputs(text_encoder, tokenizer, color_map_rgb, color_context, input_prompt, unconditional_input_prompt)
+    scheduler.set_timesteps(num_inference_steps)
+    offset = scheduler.config.get("steps_offset", 0)
+    init_timestep = min(int(num_inference_steps * strength) + offset, num_inference_steps)
+    t_start = max(num_inference_steps - init_timestep + offset, 0)
+    image = 2.0 * torch.from_numpy((np.asarray(init_rgb, dtype=np.float32) / 255.0)[None].transpose(0, 3, 1, 2)) - 1.0
+    init_latents = 0.18215 * vae.encode(image).latent_dist.sample()
+    noise = torch.randn(init_latents.shape)
+    latents = scheduler.add_noise(init_latents, noise, scheduler.timesteps[t_start:t_start + 1])
+    return sample_latents(unet, scheduler, cond, uncond, latents, num_inference_steps, guidance_scale, weight_function, t_start=t_start)
 
 
 # --------------------------------------------------------------------------------------------

@@ -311,6 +311,8 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
 // between two barriers). The KG partial softmax states of a row group are merged once at the end through the then free stage buffer.
 // Staging as in pww_cross_lean.hip: a thread moves one 16-byte column of consecutive row groups (one offset per operand; a pass adds a
 // uniform step), rows past M and the head-dim padding are out of the descriptor's range (zeros: no fill pass), grid = (query block, head, image).
+// Row sums on the vector ALU (RSM = false in every instantiation): the ones-column form measured WRONG here for head dims with D % 32 == 24
+// (88, 120, 152: the denominator came out as channel D - 8's accumulator, tools/diag_rowsum_probe.py) and is not worth a second look at 4 tiles per wave.
 template <typename T, int KS, int DT, int NW, int KG, bool RSM>
 __global__ void __launch_bounds__(NW * KG * 64, (NW * KG >= 8 ? 2 : 1)) attn_ksplit1_kernel(const AttnParams p) {
     typedef typename Vec<T>::v8 V8;
@@ -956,7 +958,6 @@ static int launch_attn(const AttnParams &p, hipStream_t stream) {
         const long wgs = (long)((p.N + 63) / 64) * p.B * p.H;
         if (ksplit_mode() == 1 && debug_knobs().attn_ksplit1 && wgs <= 256 && p.M >= 512 && ksplit1_extent_ok(p)) {
             // (round 5) 2 row groups x 4 key groups on ONE stage buffer: two waves per SIMD, a quarter of the keys per wave
-            if ((p.D & 31) != 0) return launch_attn_ksplit1<T, KS, DT, 2, 4, true>(p, stream);
             return launch_attn_ksplit1<T, KS, DT, 2, 4, false>(p, stream);
         }
         if (ksplit_mode() == 1 && wgs <= 256 && p.M >= 512) {
@@ -973,7 +974,6 @@ static int launch_attn(const AttnParams &p, hipStream_t stream) {
         // workgroups of 2 row groups x 2 key groups -- twice the workgroups, half the tiles per wave
         const long wgs = (long)((p.N + 63) / 64) * p.B * p.H;
         if (ksplit_mode() == 1 && debug_knobs().attn_ksplit1 && wgs <= 256 && p.M >= 128 && ksplit1_extent_ok(p)) {
-            if ((p.D & 31) != 0) return launch_attn_ksplit1<T, KS, DT, 2, 2, true>(p, stream);
             return launch_attn_ksplit1<T, KS, DT, 2, 2, false>(p, stream);
         }
     }

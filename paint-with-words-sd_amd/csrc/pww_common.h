@@ -61,7 +61,7 @@ struct DebugKnobs {
     int cross_bias_lds = 2;        // bias rows: 0 per lane from global memory / 1 LDS tile in single-block launches only / 2 LDS tile everywhere
     int cross_lean = 1;            // pass-2-only launches on the small kernel (pww_cross_lean.hip): 0 never / 1 where it fits (default) / 2 also for large batches
     int cross_lean_nw = 0;         // waves per workgroup of that kernel: 0 by problem size / 2 / 4
-    int attn_ksplit1 = 1;          // 0: the small self-attention launches keep the double-buffered key-split / plain kernels of round 4
+    int attn_ksplit1 = 0;          // 1: the small self-attention launches (N >= 512 at d = 80 / 96, N >= 128 at d = 128 / 160) on the single-buffered key-split kernel of round 5 (measured slower: default off)
     int attn_ksplit_nw = 2;        // row groups of the key-split d = 80 / 96 self-attention workgroup: 2 (x 2 key groups) or 4 (x 2)
 };
 const DebugKnobs &debug_knobs();
