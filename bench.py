@@ -331,6 +331,51 @@ HARNESS_CASES = {(4096, 40, 2, "bf16"): "sd15_self_n4096_d40_bf16_b2", (4096, 40
                  (9216, 64, 4, "bf16"): "sd21_self_n9216_d64_b4", (9216, 64, 8, "bf16"): "sd21_self_n9216_d64_b8"}
 
 
+CROSS_COUNTER_CASE = ("qproj_sd15_n256_b2", "cross N=256 d=160, 2 rows: pww_qk_parts + pww_cross_attn_fwd_parts (the C = 1280 layers' route)")
+
+
+def live_counters(case, kernel_keys, flags=()):
+    """rocprofv3 --pmc passes over tests/native/attn_check --only <case> (separate passes with --kernel-trace only, as MI355X_MICROARCH.md
+    prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ_VALU_MFMA_BUSY_CYCLES with GRBM_GUI_ACTIVE for the kernel's cycles): per
+    kernel whose name contains one of `kernel_keys`: {"hbm_bytes": (FETCH_SIZE + WRITE_SIZE) KiB -> bytes per dispatch, "mfma_busy":
+    SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), "kernel_cycles", "dispatches"}. None when rocprofv3 or the harness
+    is missing, {} when a pass produced nothing."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = os.path.join(REPO, "tests", "native", "attn_check")
+    if not os.path.isfile(exe) or shutil.which("rocprofv3") is None:
+        return None
+    acc = {}
+    for counters in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"):
+        out = tempfile.mkdtemp(prefix="pww_pmc_")
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            subprocess.run(["rocprofv3", "--pmc"] + counters.split() + ["--kernel-trace", "--output-format", "csv", "-d", out, "-o", "pmc", "--", exe] + list(flags) + ["--only", case],
+                           cwd="/tmp", env=env, capture_output=True, timeout=300)
+            for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    for key in kernel_keys:
+                        if key in row["Kernel_Name"]:
+                            acc.setdefault(key, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+        except (subprocess.TimeoutExpired, OSError):
+            pass
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    res = {}
+    for key, c in acc.items():
+        m = {k: sum(v) / len(v) for k, v in c.items()}
+        r = {"dispatches": max(len(v) for v in c.values())}
+        if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+            r["hbm_bytes"] = int((m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0)
+        if m.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
+            r["kernel_cycles"] = int(m["GRBM_GUI_ACTIVE"] / 8.0)
+            r["mfma_busy"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
+        res[key] = r
+    return res
+
+
 def live_traffic(n_tok, d, b_rows, dtype):
     """rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one pass each; they do not fit one pass) over tests/native/attn_check --only <case>:
     mean per dispatch of the attention kernel, KiB -> bytes. None if rocprofv3 or a harness case for the shape is missing."""
@@ -500,6 +545,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=1, help="denoise steps timed for the CPU baseline after the thread sweep (0 = skip)")
     ap.add_argument("--live-traffic", action="store_true", help="measure roofline.traffic NOW: two extra rocprofv3 --pmc passes (FETCH_SIZE, "
                     "WRITE_SIZE) over the dominant launch through tests/native/attn_check (default: the committed PMC pass of this kernel under profiles/)")
+    ap.add_argument("--no-live-counters", action="store_true", help="skip the rocprofv3 --pmc passes (HBM-side bytes and matrix-pipe busy of the dominant launch and of "
+                    "the C = 1280 cross-attention route, ~1 min through tests/native/attn_check); the line then carries the labelled constants of the committed pass")
     ap.add_argument("--no-roofline-pass", action="store_true")
     ap.add_argument("--no-reference-ops", action="store_true", help="skip the unfused-torch-ops-on-this-GPU pass")
     ap.add_argument("--memory-format", default="auto", choices=["auto", "nchw", "channels_last"],
@@ -700,16 +747,40 @@ def main():
                                   "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
                                   "attainable": ATTAINABLE.get(d), "attainable_model": "issue-bound: MFMA and VALU issue cycles of a SIMD add up (448 vs ~500 per "
                                   "64-key tile and wave), times the algorithmic share of the padded MFMA rows; see DESIGN section 4",
-                                  "mfma_busy": measured_mfma_busy(n_dom, d, b_rows, cfg["dtype"]), "mfma_busy_source": "committed PMC pass (profiles/r04_pmc.json): "
+                                  "mfma_busy": measured_mfma_busy(n_dom, d, b_rows, cfg["dtype"]), "mfma_busy_source": "CONSTANT: committed PMC pass (profiles/r04_pmc.json): "
                                   "SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), back-to-back launches of this shape",
                                   "traffic": measured_traffic(n_dom, d, b_rows, cfg["dtype"], live=args.live_traffic),
                                   "traffic_source": "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes" if args.live_traffic else "CONSTANT from the committed PMC pass of the shipped kernel "
-                                  "(profiles/r04_pmc.json), not measured in this run; --live-traffic measures it now",
+                                  "(profiles/r04_pmc.json), not measured in this run",
                                   "algorithmic_bytes": 2 * (2 * b_rows * n_dom * heads * d) * 2,
                                   "avg_us": round(us, 2), "avg_us_method": "kernel-only HIP event timestamps (hipExtLaunchKernelGGL start/stop events) of every launch of this "
                                   "class in an eager pass of the same workload, on the launch stream",
                                   "avg_us_back_to_back_graph_replay": round(us_b2b, 2), "avg_us_event_bracket_eager": round(us_situ, 2),
                                   "launches": n_launch, "flops_per_launch": flops}
+        # counters measured NOW: a kernel change that doubles the traffic shows in the driver's own line
+        if us and not args.no_live_counters and not args.live_traffic and not args.tiny:
+            t_pmc = time.perf_counter()
+            case = HARNESS_CASES.get((n_dom, d, b_rows, cfg["dtype"]))
+            live = live_counters(case, ["attn_fwd"]) if case else None
+            lv = (live or {}).get("attn_fwd")
+            if lv and "hbm_bytes" in lv:
+                result["roofline"]["traffic"] = lv["hbm_bytes"]
+                result["roofline"]["traffic_source"] = "LIVE: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run over tests/native/attn_check --only %s (%d dispatches)" % (case, lv["dispatches"])
+            if lv and "mfma_busy" in lv:
+                result["roofline"]["mfma_busy"] = lv["mfma_busy"]
+                result["roofline"]["mfma_busy_source"] = "LIVE: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), same passes"
+            cross = live_counters(CROSS_COUNTER_CASE[0], ["cross_lean_kernel", "qk_parts_kernel", "cross_fused_kernel"], flags=("--product-only",))
+            if cross:
+                # algorithmic bytes of the two launches at 2 rows, N = 256, C = 1280, M = 77: attention 2 (2 B N C + 2 B M C) + the cond row's
+                # [N, 32] bias span; partials: Q of the conditional row + K
+                alg = {"cross_lean_kernel": 2 * (2 * 2 * 256 * 1280 + 2 * 2 * 77 * 1280) + 256 * 32 * 4, "qk_parts_kernel": 2 * (256 * 1280 + 77 * 1280)}
+                for k, r in cross.items():
+                    if k in alg and "hbm_bytes" in r:
+                        r["algorithmic_bytes"] = alg[k]
+                        r["traffic_over_algorithmic"] = round(r["hbm_bytes"] / alg[k], 2)
+                result["counters_cross_route"] = {"case": CROSS_COUNTER_CASE[1], "kernels": cross,
+                                                  "source": "LIVE: rocprofv3 --pmc passes of this run over tests/native/attn_check --product-only --only %s" % CROSS_COUNTER_CASE[0]}
+            log("live counters done in %.1f s" % (time.perf_counter() - t_pmc), lv, cross)
         from pww_hip import _lib as _pww_lib
         _pww_lib.load().pww_profile_reset()
     if rank == 0 and world == 1 and not args.no_reference_ops and cfg["kind"] == "txt2img":

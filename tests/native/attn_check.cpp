@@ -623,12 +623,24 @@ static void run_qproj(const QCase &c, bool timing) {
         d.scale = 1.0f / sqrtf((float)D); d.bias_stride[2] = M; d.bias_stride[3] = 1;
         pww_cross_opts_t op; memset(&op, 0, sizeof(op)); op.size = sizeof(op); op.bias_cols = 32; op.gated_images = B > 1 ? B / 2 : 0;
         int r = 0;
+        // the product's route for this layer (pww_hip/attention.py qproj_route): to_q with the statistic in its epilogue where that wins
+        // (C = 320, and C = 640 when 160 % D == 0); elsewhere the stock to_q GEMM + pww_qk_parts over the finished Q
+        const bool k1_route = C <= 320 || (C <= 640 && 160 % D == 0);
+        const int np2 = pww_qk_parts_count(&d);
+        double *dp2 = dalloc<double>((size_t)B * std::max(np2, 1) * 4);
+        if (!k1_route) r = pww_qproj_stat(dx, dw, dq, dk, dgate, &qd, PWW_STAT_MAX, dparts, (size_t)B * nparts * 32, nullptr);      // (stands in for the stock GEMM: Q once)
         for (int i = 0; i < 20 && !r; ++i) {
-            r = pww_qproj_stat(dx, dw, dq, dk, dgate, &qd, PWW_STAT_MAX, dparts, (size_t)B * nparts * 32, nullptr);
-            if (!r) r = pww_cross_attn_fwd_parts(dq, dk, dv, o2, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, dparts, nparts, nullptr, &op, nullptr);
+            if (k1_route) {
+                r = pww_qproj_stat(dx, dw, dq, dk, dgate, &qd, PWW_STAT_MAX, dparts, (size_t)B * nparts * 32, nullptr);
+                if (!r) r = pww_cross_attn_fwd_parts(dq, dk, dv, o2, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, dparts, nparts, nullptr, &op, nullptr);
+            } else {
+                r = pww_qk_parts(dq, dk, dgate, &d, PWW_STAT_MAX, op.gated_images, dp2, (size_t)B * np2 * 32, nullptr);
+                if (!r) r = pww_cross_attn_fwd_parts(dq, dk, dv, o2, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, dp2, np2, nullptr, &op, nullptr);
+            }
         }
         HIPCHECK(hipDeviceSynchronize());
-        printf("%s %-30s product-only: 20 x (qproj_stat, cross_attn_fwd_parts) rc=%d %s\n", r ? "FAIL" : "PASS", c.name, r, r ? pww_last_error() : "");
+        (void)hipFree(dp2);
+        printf("%s %-30s product-only: 20 x (%s, cross_attn_fwd_parts) rc=%d %s\n", r ? "FAIL" : "PASS", c.name, k1_route ? "qproj_stat" : "qk_parts", r, r ? pww_last_error() : "");
         if (r) g_fail++;
         return;
     }

@@ -76,6 +76,7 @@ def _worker(rank, world, port, out_dir):
     gathered = pdist.gather_latents(lat, dst=0)
     t = pdist.max_over_ranks(1.0 + rank, dev)
     assert t == float(world)
+    assert pdist.all_ranks(10.0 + rank, dev) == [10.0 + r for r in range(world)]        # per-rank timings of a bench line (bench.py config.per_rank)
     if rank == 0:
         allv = torch.cat(gathered)[:, 0, 0, 0].tolist()
         assert allv == [100.0, 101.0, 102.0, 103.0, 104.0]

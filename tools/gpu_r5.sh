@@ -24,7 +24,7 @@ timeline)
   (cd tests/native && for c in qproj_sd15_n256_b2 qproj_sd15_n4096_b2; do timeout 120 ./attn_check --timeline --only $c 2>&1 | grep "^TIMELINE"; done; for c in sd15_self_n1024_d80 sd15_self_n256_d160; do timeout 120 ./attn_check --timeline --only $c 2>&1 | grep "^TIMELINE"; done) > $O/r5_timeline.log 2>&1; tail -60 $O/r5_timeline.log | cut -c1-200
   ;;
 subset)
-  timeout 900 python -m pytest tests/test_attention_gpu.py tests/test_qproj_gpu.py tests/test_round3_gpu.py tests/test_round5_gpu.py -m gpu -q -x 2>&1 | tail -15 | tee $O/r5_subset.log
+  timeout 900 python -m pytest tests/test_attention_gpu.py tests/test_qproj_gpu.py tests/test_round3_gpu.py tests/test_round5_gpu.py -m gpu -q -x 2>&1 | tail -40 | tee $O/r5_subset.log
   ;;
 pytest)
   timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -12 | tee $O/r5_pytest.log
