@@ -258,7 +258,7 @@ int pww_cross_attn_fwd_parts(const void *q, const void *k, const void *v, void *
  * block, 32-key block) and a partial per wave -- loads -> MFMAs -> one fp64 partial, no LDS, no barrier -- while that gives at most 256
  * partials per image; beyond, one wave per (head, 32-row block) walks the key blocks and a workgroup's four waves share one partial.
  * No atomics, nothing waits for another workgroup.
- *   q, k      as in pww_attn_desc_t (only dtype, B / H / N / M / D and the q / k strides of the descriptor are read), M <= 128
+ *   q, k      as described by the attention descriptor: only dtype, B / H / N / M / D and the q / k strides are read; M <= 128
  *   gate      fp32 [B] or NULL: images with gate[b] == 0 get no partials (their rows of `partials` are left untouched)
  *   stat_kind PWW_STAT_* (PWW_STAT_ALL: all four fields): only the fields that statistic is made of are formed, the others hold the
  *             neutral element
@@ -328,6 +328,11 @@ typedef struct pww_ln_desc {
     int32_t _pad;
 } pww_ln_desc_t;
 int pww_add_layer_norm(const void *a, const void *x, const void *gamma, const void *beta, void *s, void *y, const pww_ln_desc_t *desc, void *stream);
+/* (version >= 124) pww_add_layer_norm whose sum output also carries a per-channel addend: s = T(T(a + x) + post_bias[c]), y = LayerNorm(T(a + x)) as
+   before. The caller adds the NEXT GEMM's output to s with that GEMM's C operand (beta = 1) and hands the GEMM's bias over here -- the `ff(norm3(h)) + h`
+   of diffusers' BasicTransformerBlock then costs no add launch (one rounding of the bias moves from the GEMM's epilogue to this sum). a, s required. */
+int pww_add_layer_norm_bias(const void *a, const void *x, const void *gamma, const void *beta, const void *post_bias, void *s, void *y,
+                            const pww_ln_desc_t *desc, void *stream);
 int pww_geglu(const void *h, void *y, int64_t rows, int32_t D, int64_t h_stride, int64_t y_stride, int32_t dtype, void *stream);
 int pww_bias_residual(const void *r, const void *v, const void *bias, void *y, int32_t B, int32_t C, int32_t HW, int32_t layout, int32_t dtype, void *stream);
 

@@ -188,7 +188,7 @@ int store_f32(float *dst, const float *values, int n, hipStream_t stream);
 size_t group_norm_workspace_bytes(const pww_gn_desc_t *d);
 int group_norm_fwd(const void *x, const void *pre_c, const void *add_bc, const void *gamma, const void *beta, void *y, const pww_gn_desc_t *d,
                    void *workspace, size_t workspace_bytes, hipStream_t stream);
-int add_layer_norm(const void *a, const void *x, const void *gamma, const void *beta, void *s, void *y, const pww_ln_desc_t *d, hipStream_t stream);
+int add_layer_norm(const void *a, const void *x, const void *gamma, const void *beta, void *s, void *y, const pww_ln_desc_t *d, hipStream_t stream, const void *post_bias = nullptr);
 int geglu(const void *h, void *y, int64_t rows, int32_t D, int64_t h_stride, int64_t y_stride, int32_t dtype, hipStream_t stream);
 int bias_residual(const void *r, const void *v, const void *bias, void *y, int32_t B, int32_t C, int32_t HW, int32_t layout, int32_t dtype, hipStream_t stream);
 
@@ -343,6 +343,9 @@ int pww_group_norm_fwd(const void *x, const void *pre_c, const void *add_bc, con
 }
 int pww_add_layer_norm(const void *a, const void *x, const void *gamma, const void *beta, void *s, void *y, const pww_ln_desc_t *desc, void *stream) {
     return pww::add_layer_norm(a, x, gamma, beta, s, y, desc, static_cast<hipStream_t>(stream));
+}
+int pww_add_layer_norm_bias(const void *a, const void *x, const void *gamma, const void *beta, const void *post_bias, void *s, void *y, const pww_ln_desc_t *desc, void *stream) {
+    return pww::add_layer_norm(a, x, gamma, beta, s, y, desc, static_cast<hipStream_t>(stream), post_bias);
 }
 int pww_geglu(const void *h, void *y, int64_t rows, int32_t D, int64_t h_stride, int64_t y_stride, int32_t dtype, void *stream) {
     return pww::geglu(h, y, rows, D, h_stride, y_stride, dtype, static_cast<hipStream_t>(stream));

@@ -25,6 +25,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 constexpr int LN_MAXK = 4;          // 16-byte chunks per lane: C <= 2048
 struct LnParams {
     const void *a, *x, *gamma, *beta;
+    const void *post_bias;      // ADD only, optional [C]: s = T(T(a + x) + post_bias) -- the bias of the GEMM whose output will be added to s next
+                                // (pww_add_layer_norm_bias); y is the LayerNorm of T(a + x), without it
     void *s, *y;
     long rows;
     int C;
@@ -50,6 +52,14 @@ __global__ void __launch_bounds__(256) add_layer_norm_kernel(const LnParams p) {
         if (ADD) av[k] = *reinterpret_cast<const V8 *>(a + cc);
         gv[k] = p.gamma ? *reinterpret_cast<const V8 *>(reinterpret_cast<const T *>(p.gamma) + cc) : zero8<V8>();
         bv[k] = p.beta ? *reinterpret_cast<const V8 *>(reinterpret_cast<const T *>(p.beta) + cc) : zero8<V8>();
+    }
+    V8 pv[K];
+    if (ADD && p.post_bias) {       // (uniform)
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int ch = lane + k * 64;
+            pv[k] = *reinterpret_cast<const V8 *>(reinterpret_cast<const T *>(p.post_bias) + (ch < nch ? ch : 0) * 8);
+        }
     }
     float v[K][8];
     float sum = 0.f;
@@ -87,7 +97,7 @@ __global__ void __launch_bounds__(256) add_layer_norm_kernel(const LnParams p) {
             for (int j = 0; j < 8; ++j) {
                 const float g = p.gamma ? (float)gv[k][j] : 1.f, b = p.beta ? (float)bv[k][j] : 0.f;
                 o[j] = (T)fmaf((v[k][j] - mean) * rstd, g, b);
-                so[j] = (T)v[k][j];
+                so[j] = (ADD && p.post_bias) ? (T)(v[k][j] + (float)pv[k][j]) : (T)v[k][j];
             }
             *reinterpret_cast<V8 *>(y + ch * 8) = o;
             if (ADD) *reinterpret_cast<V8 *>(s + ch * 8) = so;
@@ -195,8 +205,9 @@ bool aligned16(const void *a, const void *b = nullptr, const void *c = nullptr, 
 
 }  // namespace
 
-int add_layer_norm(const void *a, const void *x, const void *gamma, const void *beta, void *s, void *y, const pww_ln_desc_t *d, hipStream_t stream) {
+int add_layer_norm(const void *a, const void *x, const void *gamma, const void *beta, void *s, void *y, const pww_ln_desc_t *d, hipStream_t stream, const void *post_bias) {
     if (!x || !y || !d || (a != nullptr) != (s != nullptr)) { set_error("add_layer_norm: x, y and desc are required; a and s come together"); return PWW_EINVAL; }
+    if (post_bias && (!a || (reinterpret_cast<uintptr_t>(post_bias) & 15))) { set_error("add_layer_norm: post_bias needs the add form (a, s) and 16-byte alignment"); return PWW_EINVAL; }
     if (d->rows < 1 || d->C < 8 || d->C % 8 != 0 || d->C > 64 * 8 * LN_MAXK || (d->dtype != PWW_DTYPE_F16 && d->dtype != PWW_DTYPE_BF16)) {
         set_error("add_layer_norm: unsupported description (rows %lld C %d dtype %d): C a multiple of 8, <= %d", (long long)d->rows, d->C, d->dtype, 64 * 8 * LN_MAXK);
         return PWW_ENOTSUP;
@@ -205,7 +216,7 @@ int add_layer_norm(const void *a, const void *x, const void *gamma, const void *
     if (!aligned16(a, x, gamma, beta, s, y) || ((xs | as | ss | ys) & 7)) { set_error("add_layer_norm: pointers must be 16-byte aligned, row strides multiples of 8"); return PWW_EINVAL; }
     if (!arch_ok()) return PWW_ENOTSUP;
     LnParams p;
-    p.a = a; p.x = x; p.gamma = gamma; p.beta = beta; p.s = s; p.y = y; p.rows = d->rows; p.C = d->C;
+    p.a = a; p.x = x; p.gamma = gamma; p.beta = beta; p.post_bias = post_bias; p.s = s; p.y = y; p.rows = d->rows; p.C = d->C;
     p.a_stride = as; p.x_stride = xs; p.s_stride = ss; p.y_stride = ys; p.eps = d->eps;
     if (d->dtype == PWW_DTYPE_F16) return a ? ln_launch<f16, true>(p, stream) : ln_launch<f16, false>(p, stream);
     return a ? ln_launch<bf16, true>(p, stream) : ln_launch<bf16, false>(p, stream);

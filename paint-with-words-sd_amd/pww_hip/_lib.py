@@ -22,7 +22,7 @@ EXPORTS = ("pww_version", "pww_last_error", "pww_device_arch", "pww_self_attn_fw
            "pww_qk_reduce", "pww_mask_build", "pww_mask_build_rgb", "pww_mask_build_f32", "pww_resize_tokens", "pww_gauss_blur", "pww_inpaint_prep", "pww_cfg_combine", "pww_store_f32",
            "pww_workspace_bytes", "pww_profile_arm", "pww_profile_elapsed_us", "pww_profile_reset", "pww_debug_timeline",
            "pww_qproj_stat", "pww_qproj_parts", "pww_cross_attn_fwd_parts", "pww_mask_build_f32_levels", "pww_qk_parts", "pww_qk_parts_count",
-           "pww_group_norm_fwd", "pww_group_norm_workspace_bytes", "pww_add_layer_norm", "pww_geglu", "pww_bias_residual")
+           "pww_group_norm_fwd", "pww_group_norm_workspace_bytes", "pww_add_layer_norm", "pww_add_layer_norm_bias", "pww_geglu", "pww_bias_residual")
 
 
 class AttnDesc(ctypes.Structure):
@@ -114,6 +114,8 @@ def load():
     lib.pww_group_norm_fwd.restype = ctypes.c_int
     lib.pww_add_layer_norm.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.POINTER(LnDesc), vp]
     lib.pww_add_layer_norm.restype = ctypes.c_int
+    lib.pww_add_layer_norm_bias.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.POINTER(LnDesc), vp]
+    lib.pww_add_layer_norm_bias.restype = ctypes.c_int
     lib.pww_geglu.argtypes = [vp, vp, ctypes.c_int64, i32, ctypes.c_int64, ctypes.c_int64, i32, vp]
     lib.pww_geglu.restype = ctypes.c_int
     lib.pww_bias_residual.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]

@@ -38,6 +38,7 @@ FUSED_NORM = os.environ.get("PWW_FUSED_NORM", "1") != "0"      # A/B switch (ben
 BATCHED_TEMB = os.environ.get("PWW_BATCHED_TEMB", "1") != "0"  # A/B switch: one time-embedding projection GEMM per forward for all blocks
 FOLD_CONV_BIAS = os.environ.get("PWW_FOLD_CONV_BIAS", "1") != "0"      # A/B: conv1 / conv2 biases of a ResnetBlock2D ride in the next fused op
 CONV1X1_AS_LINEAR = os.environ.get("PWW_CONV1X1_AS_LINEAR", "1") != "0"  # A/B: 1 x 1 convolutions on channels_last tensors as GEMMs
+FUSE_FF_RESIDUAL = os.environ.get("PWW_FUSE_FF_RESIDUAL", "1") != "0"    # A/B: `ff(norm3(h)) + h` through the output GEMM's C operand (no add launch)
 
 
 # ---- what the plug did with the calls it saw (a call the kernels decline must not go unnoticed) ----------------
@@ -266,8 +267,29 @@ def _transformer_block_forward(self, *args, **kwargs):
     h = hidden_states
     n = ops.add_layer_norm(h, self.norm1.weight, self.norm1.bias, self.norm1.eps)
     h, n = ops.add_layer_norm(h, self.norm2.weight, self.norm2.bias, self.norm2.eps, a=self.attn1(n))
+    lin = _ff_output_linear(self.ff) if FUSE_FF_RESIDUAL else None
+    if lin is not None and lin.weight.dtype == h.dtype:
+        # `ff(norm3(h)) + h` without an add launch (round 5; 16 of the 32 residual adds of a forward): the sum that feeds norm3 leaves its
+        # launch already carrying the output GEMM's bias, and that GEMM adds it as its C operand (beta = 1)
+        h, n = ops.add_layer_norm(h, self.norm3.weight, self.norm3.bias, self.norm3.eps, a=self.attn2(n, context=context), post_bias=lin.bias)
+        g = self.ff.net[0](n)
+        return torch.addmm(h.reshape(-1, h.shape[-1]), g.reshape(-1, g.shape[-1]), lin.weight.t()).view(h.shape)
     h, n = ops.add_layer_norm(h, self.norm3.weight, self.norm3.bias, self.norm3.eps, a=self.attn2(n, context=context))
     return self.ff(n) + h
+
+
+def _ff_output_linear(ff):
+    """The output projection of a diffusers FeedForward `net = [GEGLU, Dropout, Linear]` when the block's tail can run as GEGLU -> one GEMM
+    with the residual as its C operand (a dropout that does nothing, a plain biased nn.Linear without hooks), else None."""
+    net = getattr(ff, "net", None)
+    if net is None or len(net) != 3 or type(ff).forward is not getattr(type(ff), "forward", None) or "forward" in ff.__dict__:
+        return None
+    act, drop, lin = net[0], net[1], net[2]
+    if act.__class__.__name__ != "GEGLU" or not isinstance(drop, nn.Dropout) or (drop.training and drop.p > 0):
+        return None
+    if type(lin) is not nn.Linear or lin.bias is None or lin._forward_hooks or lin._forward_pre_hooks or "forward" in lin.__dict__ or ff._forward_hooks or ff._forward_pre_hooks:
+        return None
+    return lin
 
 
 def _geglu_forward(self, x, *args, **kwargs):

@@ -638,9 +638,11 @@ def _rows(t, name):
     return rows, C, stride
 
 
-def add_layer_norm(x, weight, bias, eps, a=None):
+def add_layer_norm(x, weight, bias, eps, a=None, post_bias=None):
     """LayerNorm over the last dim of x ([..., C]); with `a` (same shape): s = a + x, returns (s, LayerNorm(s)) from ONE launch -- the
-    `attn(norm(h)) + h` of diffusers' BasicTransformerBlock together with the block's next norm. Without `a`: returns LayerNorm(x)."""
+    `attn(norm(h)) + h` of diffusers' BasicTransformerBlock together with the block's next norm. Without `a`: returns LayerNorm(x).
+    post_bias ([C], with `a`): the returned sum is s + post_bias (the LayerNorm still is that of s): the bias of the GEMM whose output the
+    caller adds to it next, through that GEMM's C operand."""
     _require_gpu(x)
     rx = _rows(x, "add_layer_norm")
     if rx is None:
@@ -655,16 +657,22 @@ def add_layer_norm(x, weight, bias, eps, a=None):
         if ra is None:
             a = a.contiguous()
             ra = _rows(a, "add_layer_norm")
-    for name, t in (("weight", weight), ("bias", bias)):
+    for name, t in (("weight", weight), ("bias", bias), ("post_bias", post_bias)):
         if t is not None and (t.dtype != x.dtype or tuple(t.shape) != (C,) or not t.is_contiguous()):
             raise PwwHipError("add_layer_norm: `%s` must be a contiguous %s [%d]" % (name, x.dtype, C))
+    if post_bias is not None and a is None:
+        raise PwwHipError("add_layer_norm: post_bias needs the add form (a)")
     y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     s = torch.empty(x.shape, dtype=x.dtype, device=x.device) if a is not None else None
     d = _lib.LnDesc(_DT[x.dtype], C, rows, ra[2] if ra else 0, xs, C, C, float(eps), 0)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().pww_add_layer_norm(_ptr(a) if a is not None else None, _ptr(x), _ptr(weight) if weight is not None else None,
-                                                  _ptr(bias) if bias is not None else None, _ptr(s) if s is not None else None, _ptr(y),
-                                                  ctypes.byref(d), _stream()), "pww_add_layer_norm")
+        if post_bias is not None:
+            _lib.check(_lib.load().pww_add_layer_norm_bias(_ptr(a), _ptr(x), _ptr(weight) if weight is not None else None, _ptr(bias) if bias is not None else None,
+                                                           _ptr(post_bias), _ptr(s), _ptr(y), ctypes.byref(d), _stream()), "pww_add_layer_norm_bias")
+        else:
+            _lib.check(_lib.load().pww_add_layer_norm(_ptr(a) if a is not None else None, _ptr(x), _ptr(weight) if weight is not None else None,
+                                                      _ptr(bias) if bias is not None else None, _ptr(s) if s is not None else None, _ptr(y),
+                                                      ctypes.byref(d), _stream()), "pww_add_layer_norm")
     return (s, y) if a is not None else y
 
 

@@ -7,6 +7,8 @@
 #   pytest     the whole GPU suite
 #   bench      python bench.py (short) -> r5_bench.json
 #   benchfull  python bench.py with its defaults
+#   prof       rocprofv3 --kernel-trace --stats of a short bench run -> r5_bench_c2_kernel_stats.md (pww kernels of the whole process + every kernel of the TIMED steps)
+#   configs    bench lines of BASELINE configs 3 / 4 / 5
 export TMPDIR=/tmp
 mkdir -p gpurun_out; O=gpurun_out
 for stage in "$@"; do
@@ -40,6 +42,20 @@ PY
   ;;
 benchfull)
   timeout 900 python bench.py > $O/r5_bench_default.json 2> $O/r5_bench_default.log; tail -2 $O/r5_bench_default.log; tail -1 $O/r5_bench_default.json | cut -c1-300
+  ;;
+prof)
+  OUT=/tmp/pww_prof_r05; rm -rf $OUT; R=$PWD
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT -o run -- python $R/bench.py --steps 2 --warmup 1 --cpu-steps 0 --no-reference-ops --no-live-counters > $R/$O/r5_bench_c2_prof.json 2> $R/$O/r5_bench_c2_prof.log) || true
+  DB=$(find $OUT -name "*.db" | head -1)
+  W=$(grep "timed region CLOCK_MONOTONIC" $O/r5_bench_c2_prof.log | sed 's/.*ns //')
+  { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --cpu-steps 0 --no-reference-ops --no-live-counters (round 5)"; echo; echo "## pww kernels, whole process (workload + roofline pass)";
+    python tools/rocpd_stats.py "$DB" --top 60 --grid --match pww --split-b2b attn_fwd_fold_kernel; echo; echo "## every kernel of the TIMED steps"; python tools/rocpd_stats.py "$DB" --top 45 --grid --window $W; } > $O/r5_bench_c2_kernel_stats.md 2>&1
+  tail -1 $O/r5_bench_c2_prof.json | cut -c1-200; grep -c "" $O/r5_bench_c2_kernel_stats.md
+  ;;
+configs)
+  for c in 3 4 5; do
+    timeout 900 python bench.py --config $c --steps 1 --warmup 1 --cpu-steps 0 --no-reference-ops --no-live-counters > $O/r5_bench_c$c.json 2> $O/r5_bench_c$c.log; tail -1 $O/r5_bench_c$c.json | cut -c1-200
+  done
   ;;
 *) echo "unknown stage $stage";;
 esac
