@@ -38,7 +38,9 @@ FUSED_NORM = os.environ.get("PWW_FUSED_NORM", "1") != "0"      # A/B switch (ben
 BATCHED_TEMB = os.environ.get("PWW_BATCHED_TEMB", "1") != "0"  # A/B switch: one time-embedding projection GEMM per forward for all blocks
 FOLD_CONV_BIAS = os.environ.get("PWW_FOLD_CONV_BIAS", "1") != "0"      # A/B: conv1 / conv2 biases of a ResnetBlock2D ride in the next fused op
 CONV1X1_AS_LINEAR = os.environ.get("PWW_CONV1X1_AS_LINEAR", "1") != "0"  # A/B: 1 x 1 convolutions on channels_last tensors as GEMMs
-FUSE_FF_RESIDUAL = os.environ.get("PWW_FUSE_FF_RESIDUAL", "1") != "0"    # A/B: `ff(norm3(h)) + h` through the output GEMM's C operand (no add launch)
+# `ff(norm3(h)) + h` through the output GEMM's C operand (no add launch): built in round 5, measured NEUTRAL on the headline (4.04 / 4.06 vs 4.08 /
+# 4.06 images/s, profiles/r05_blocks_ab.md: hipBLASLt's beta = 1 kernels cost what the add launch saves) -> opt-in, off by default
+FUSE_FF_RESIDUAL = os.environ.get("PWW_FUSE_FF_RESIDUAL", "0") == "1"
 
 
 # ---- what the plug did with the calls it saw (a call the kernels decline must not go unnoticed) ----------------

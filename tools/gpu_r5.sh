@@ -20,7 +20,8 @@ native)
 small)
   rm -f $O/r5_small.md
   for v in "" "cross_lean=0"; do PWW_DEBUG="$v" timeout 300 python tools/time_small_attn.py cross --out $O/r5_small.md 2>&1 | grep -v amdgpu.ids | tail -6; done
-  for v in "" "attn_ksplit1=0"; do PWW_DEBUG="$v" timeout 300 python tools/time_small_attn.py self --out $O/r5_small.md 2>&1 | grep -v amdgpu.ids | tail -6; done
+  for v in "" "attn_ksplit1=1"; do PWW_DEBUG="$v" timeout 300 python tools/time_small_attn.py self --out $O/r5_small.md 2>&1 | grep -v amdgpu.ids | tail -6; done
+  timeout 300 python tools/time_small_attn.py toout --out $O/r5_small.md 2>&1 | grep -v amdgpu.ids | tail -6
   ;;
 timeline)
   (cd tests/native && for c in qproj_sd15_n256_b2 qproj_sd15_n4096_b2; do timeout 120 ./attn_check --timeline --only $c 2>&1 | grep "^TIMELINE"; done; for c in sd15_self_n1024_d80 sd15_self_n256_d160; do timeout 120 ./attn_check --timeline --only $c 2>&1 | grep "^TIMELINE"; done) > $O/r5_timeline.log 2>&1; tail -60 $O/r5_timeline.log | cut -c1-200

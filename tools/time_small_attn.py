@@ -112,6 +112,21 @@ def main():
             lines.append("| N=%d C=%d d=%d | %.2f | %.2f | %.2f | %.2f | %.2f | %.2f | %.2f | **%.2f** | %.1e |" % (N, C, D, t_lin, t_qp, t_qkp, t_parts, t_fused, t_r3, t_r4, t_r5, diff))
             print(lines[-1], flush=True)
         lines.append("")
+    if not what or "toout" in what:
+        # f-1: what an in-kernel `to_out` epilogue could save at most = the stock GEMM's launch (it cannot run faster inside another kernel) minus
+        # nothing: bias rides the GEMM's epilogue, the residual add rides pww_add_layer_norm
+        lines += ["| to_out (stock nn.Linear with bias, B = %d rows) | GEMM + bias epilogue | + residual add launch (not issued by the product: fused into pww_add_layer_norm) |" % B, "|---|---|---|"]
+        for N, C in ((4096, 320), (1024, 640), (256, 1280), (64, 1280)):
+            g = torch.Generator().manual_seed(2)
+            o = torch.randn(B, N, C, generator=g).to(dev, dtype)
+            r = torch.randn(B, N, C, generator=g).to(dev, dtype)
+            w = (torch.randn(C, C, generator=g) / math.sqrt(C)).to(dev, dtype)
+            bias = torch.randn(C, generator=g).to(dev, dtype)
+            t1 = replay_us(lambda: F.linear(o, w, bias))
+            t2 = replay_us(lambda: F.linear(o, w, bias) + r)
+            lines.append("| N=%d C=%d | %.2f | %.2f |" % (N, C, t1, t2))
+            print(lines[-1], flush=True)
+        lines.append("")
     text = "\n".join(lines) + "\n"
     if out:
         with open(out, "a") as f:
