@@ -172,6 +172,9 @@ size_t pww_cross_fused_workspace_bytes(const pww_attn_desc_t *desc);
  *                     paint_with_words.py:402-405 / runner.py:104) before each replay. NULL = use the by-value argument.
  *   bias_cols         the caller's promise that columns >= bias_cols of the bias map are zero (the map of a prompt is zero past
  *                     its last region phrase, paint_with_words.py:257-268): only those columns are moved and added. 0 = unknown.
+ *                     A hint (this one, bias_compact, gated_images) selects another form of the same kernel -- the same mathematics in
+ *                     another rounding order (first-tile / lazy softmax steps): outputs may differ from the unhinted call's in the last
+ *                     bit or two of the storage type; the hinted forms agree with each other bit for bit.
  *   bias_compact      compact bias: fp32 [B?][N][R] with bias[b][h][n][col_idx[b?][r]] = bias_compact[b][n][r] and
  *                     every other column zero; addressed  bias_compact + b*compact_stride[0] + n*compact_stride[1] + r.
  *                     5 - 17 of the 77 columns of a Paint-with-Words map are non-zero. R <= 32. When given it is what the fused

@@ -364,7 +364,7 @@ def test_bias_hints_do_not_change_a_bit(gpu_device, shape, dtype, B):
                                      scratch=ops.FusedScratch(), **kw)
     plain = run()
     base = run(bias_cols=32)
-    last_bits = lambda a, b: (a.float() - b.float()).abs().max().item() <= (2.0 ** -9 if dtype == torch.float16 else 2.0 ** -6) * b.float().abs().max().item()    # noqa: E731
+    last_bits = lambda a, b: (a.float() - b.float()).abs().max().item() <= (2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7) * b.float().abs().max().item()    # noqa: E731  (two steps of the storage type at the largest outputs)
     assert last_bits(base, plain)
     idx = torch.cat([cols.to(torch.int32), torch.full((8 - cols.numel() % 8,), -1, dtype=torch.int32, device=gpu_device)])
     wc = torch.zeros((N, idx.numel()), device=gpu_device)

@@ -114,6 +114,31 @@ def main():
             check(bool(waits) and all("vmcnt(0)" not in w for w in waits), "pass-1 loop header waits with a counted vmcnt (ring of 3 blocks in flight): %s" % waits)
             break
     check(found, "pass-1 loop located")
+    # ---- 3. (round 5) the small cross-attention kernels: what their short chains rest on -------------------------------------------------
+    lean_src = os.path.join(CSRC, "pww_cross_lean.hip")
+    lean = resource_usage(lean_src)
+    for name, r in lean.items():
+        if "cross_lean_kernel" in name or "qk_parts_kernel" in name:
+            check(int(r["ScratchSize [bytes/lane]"]) == 0, "%s: %s VGPRs, %s B scratch (no scratch)" % (name[:60], r["VGPRs"], r["ScratchSize [bytes/lane]"]))
+    isa = kernel_isa(lean_src, r"_ZN3pww17cross_lean_kernelIDF16bLi10ELi5ELi4EEEvNS_10LeanParamsE")
+    lines = [l.strip() for l in next(iter(isa.values()))]
+    nbar = sum(1 for l in lines if l.startswith("s_barrier"))
+    check(nbar == 1, "cross_lean_kernel (bf16, d = 160): %d barrier(s) in the kernel (one)" % nbar)
+    # every buffer load of the prologue sits in front of the barrier and none of them is behind a waterfall loop (a descriptor built from a
+    # value hipcc cannot prove uniform is loaded through v_readfirstlane + s_cbranch_execnz per load: 185 readfirstlanes in the first version)
+    bar = next(i for i, l in enumerate(lines) if l.startswith("s_barrier"))
+    loads = [i for i, l in enumerate(lines) if l.startswith("buffer_load_dwordx4")]
+    rfl = sum(1 for l in lines[:bar] if l.startswith("v_readfirstlane"))
+    check(loads and max(loads) < bar and rfl <= 16, "cross_lean_kernel: %d buffer loads, all in front of the barrier; %d v_readfirstlane in the prologue (no waterfall loops)" % (len(loads), rfl))
+    # the last prologue load is issued within ~600 instructions of the kernel's entry (1500 in the first version: per-chunk index arithmetic)
+    check(max(loads) < 700, "cross_lean_kernel: last prologue load at instruction %d (< 700)" % max(loads))
+    # the score MFMAs of a tile run behind counted LDS waits (pww_tile.h score_tile requests all K fragments first)
+    mf = [i for i, l in enumerate(lines) if l.startswith("v_mfma")]
+    gated = sum(1 for i in mf if any(lines[j].startswith("s_waitcnt") and "lgkmcnt(0)" in lines[j] for j in range(max(0, i - 1), i)))
+    check(gated * 4 <= len(mf), "cross_lean_kernel: %d of %d MFMAs directly behind a full LDS wait (at most a quarter)" % (gated, len(mf)))
+    isa = kernel_isa(lean_src, r"_ZN3pww15qk_parts_kernelIDF16bLi10ELb0EEEvNS_13QkPartsParamsE")
+    lines = [l.strip() for l in next(iter(isa.values()))]
+    check(not any(l.startswith(("s_barrier", "ds_write", "ds_read")) for l in lines), "qk_parts_kernel (fine form): no barrier, no LDS traffic besides the shuffles' ds_bpermute")
     print("%d violation(s)" % len(bad))
     return 1 if bad else 0
 

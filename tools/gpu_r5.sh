@@ -50,7 +50,7 @@ prof)
   DB=$(find $OUT -name "*.db" | head -1)
   W=$(grep "timed region CLOCK_MONOTONIC" $O/r5_bench_c2_prof.log | sed 's/.*ns //')
   { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --cpu-steps 0 --no-reference-ops --no-live-counters (round 5)"; echo; echo "## pww kernels, whole process (workload + roofline pass)";
-    python tools/rocpd_stats.py "$DB" --top 60 --grid --match pww --split-b2b attn_fwd_fold_kernel; echo; echo "## every kernel of the TIMED steps"; python tools/rocpd_stats.py "$DB" --top 45 --grid --window $W; } > $O/r5_bench_c2_kernel_stats.md 2>&1
+    python tools/rocpd_stats.py "$DB" --top 60 --grid --match pww --split-b2b attn_fwd_fold_kernel; echo; echo "## pww kernels of the TIMED steps (hipGraph replay: what the product pays per launch)"; python tools/rocpd_stats.py "$DB" --top 60 --grid --match pww --window $W; echo; echo "## every kernel of the TIMED steps"; python tools/rocpd_stats.py "$DB" --top 45 --grid --window $W; } > $O/r5_bench_c2_kernel_stats.md 2>&1
   tail -1 $O/r5_bench_c2_prof.json | cut -c1-200; grep -c "" $O/r5_bench_c2_kernel_stats.md
   ;;
 configs)
