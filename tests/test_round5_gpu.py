@@ -37,6 +37,11 @@ QKP_SHAPES = [
     ("d16_n700_m33", 7, 700, 10, 16, 33, False),
     ("d96_n90_m100", 2, 90, 4, 96, 100, False),
     ("d128_n200_m77", 2, 200, 3, 128, 77, False),
+    ("d24_n200_m77", 2, 200, 4, 24, 77, False),      # head dims whose ones column (the softmax denominator from the PV MFMA) sits in the last padding chunk
+    ("d8_n96_m77", 2, 96, 8, 8, 77, True),
+    ("d56_n130_m90", 2, 130, 4, 56, 90, False),
+    ("d72_n260_m77", 2, 260, 4, 72, 77, False),
+    ("d104_n70_m128", 1, 70, 2, 104, 128, False),
 ]
 
 
