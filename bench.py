@@ -199,7 +199,7 @@ class EventTimer:
     def wrap_stream(self, kind, fn, nbytes_of):
         """HBM-streaming helpers (mask build, CFG combine): key carries the algorithmic byte count."""
         def wrapped(*a, **kw):
-            return self._timed((kind, int(nbytes_of(*a, **kw)), 0, 0, 0, 0, 0), fn, a, kw)
+            return self._timed((kind, int(nbytes_of(*a, **kw)), 0, 0, 0, 0, 0), fn, a, kw, kernel_only=True)
         return wrapped
 
     def _replay_us(self, key, reps=40):
@@ -215,9 +215,12 @@ class EventTimer:
         rows = []
         for key, pairs in self.pairs.items():
             kind, B, N, M, D, Hh, Bk = key
-            if kind in ("mask_build", "cfg_combine"):   # in situ (includes host launch latency: an upper bound)
-                us = sum(a.elapsed_time(b) for a, b in pairs) * 1e3 / len(pairs)
-                rows.append({"kernel": kind + " (in situ, eager)", "launches": len(pairs), "avg_us": round(us, 2), "algorithmic_bytes": B,
+            if kind in ("mask_build", "cfg_combine"):   # streaming helpers: kernel-only like the attention launches (round 5); the event bracket around the
+                us_bracket = sum(a.elapsed_time(b) for a, b in pairs) * 1e3 / len(pairs)      # eager call (host launch latency included) beside it
+                k_us = self.kernel_us(key)
+                us = k_us if k_us is not None else us_bracket
+                rows.append({"kernel": kind + (" (kernel-only, in the workload)" if k_us is not None else " (event bracket around the eager call)"), "launches": len(pairs),
+                             "avg_us": round(us, 2), "avg_us_event_bracket_eager": round(us_bracket, 2), "algorithmic_bytes": B,
                              "gbs": round(B / us / 1e3, 1), "bound": "hbm", "frac": round(B / us / 1e3 / HBM_PEAK_GBS, 4)})
                 continue
             us = self._replay_us(key)
@@ -494,7 +497,7 @@ def cpu_baseline(args, cfg, request):
     per_step = float(np.mean(times))
     unet_evals = n_denoise_steps + (1 if cfg["scheduler"] == "plms" else 0)
     out = {"value": round(1.0 / (per_step * unet_evals), 6), "unit": "images/s", "cores": best,
-           "kind": "port",
+           "kind": "port", "host": "gpu_box_port",       # measured NOW on this box's host cores (the other leg below is a different machine)
            "sample": "%d of %d denoise steps (2 fp32 UNet forwards each, oracle attention) of the same %dx%d workload at the best of the swept "
                      "torch thread counts (%d of %d logical CPUs), %.2f s/step, extrapolated to %d steps"
                      % (len(times), unet_evals, cfg["size"], cfg["size"], best, ncpu, per_step, unet_evals),
@@ -504,6 +507,7 @@ def cpu_baseline(args, cfg, request):
         rec = json.load(open(ref_path))   # /root/reference does not exist on the GPU box, so this figure travels as a fixture
         out["reference_on_build_box"] = {
             "value": rec["images_per_s_30_steps"], "unit": "images/s", "cores": rec["threads"], "kind": "reference",
+            "host": "build_box_reference",     # NOT this machine: a fixture recorded where /root/reference exists
             "sample": rec["what"] + ": %.1f s wall, %.2f s per UNet forward, %.1f s inside the reference's inj_forward; extrapolated to 30 steps"
                       % (rec["wall_s"], rec["s_per_unet_forward"], rec["s_inside_inj_forward"])}
     return out

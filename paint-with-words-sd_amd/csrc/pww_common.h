@@ -87,4 +87,12 @@ static inline void launch_attn_kernel(K kern, dim3 grid, dim3 block, size_t lds,
     else hipLaunchKernelGGL(kern, grid, block, lds, stream, params);
 }
 
+// The same for kernels that take their arguments one by one (mask build, CFG combine: the streaming helpers of the path).
+template <typename K, typename... A>
+static inline void launch_timed(K kern, dim3 grid, dim3 block, size_t lds, hipStream_t stream, A... args) {
+    hipEvent_t e0, e1;
+    if (profile_take(&e0, &e1, stream)) hipExtLaunchKernelGGL(kern, grid, block, (unsigned)lds, stream, e0, e1, 0, args...);
+    else hipLaunchKernelGGL(kern, grid, block, lds, stream, args...);
+}
+
 }  // namespace pww

@@ -108,7 +108,7 @@ static int launch_mask_levels(Tap tap, int H, int W, int n, const int *ratios, f
     if (!lv.n) return PWW_OK;
     for (int i = lv.n; i < 4; ++i) { lv.Hr[i] = lv.Wr[i] = 1; lv.out[i] = nullptr; }
     for (int i = lv.n; i < 5; ++i) lv.blk0[i] = blocks;
-    hipLaunchKernelGGL((mask_build_kernel<Tap>), dim3(blocks), dim3(MASK_THREADS), 0, stream, tap, H, W, lv, R, col_ptr, col_reg, T);
+    launch_timed(mask_build_kernel<Tap>, dim3(blocks), dim3(MASK_THREADS), 0, stream, tap, H, W, lv, R, col_ptr, col_reg, T);      // (armable: bench.py times it kernel-only)
     return check_hip(hipGetLastError(), "mask_build_kernel launch");
 }
 
@@ -292,9 +292,9 @@ int cfg_combine(const void *cond, const void *uncond, float g, float *out, long 
     const int threads = 256;
     const int blocks = (int)((n + threads - 1) / threads < 2048 ? (n + threads - 1) / threads : 2048);
     if (dtype == PWW_DTYPE_F16)
-        hipLaunchKernelGGL(cfg_combine_kernel<f16>, dim3(blocks), dim3(threads), 0, stream, (const f16 *)cond, (const f16 *)uncond, g, out, n);
+        launch_timed(cfg_combine_kernel<f16>, dim3(blocks), dim3(threads), 0, stream, (const f16 *)cond, (const f16 *)uncond, g, out, n);
     else if (dtype == PWW_DTYPE_BF16)
-        hipLaunchKernelGGL(cfg_combine_kernel<bf16>, dim3(blocks), dim3(threads), 0, stream, (const bf16 *)cond, (const bf16 *)uncond, g, out, n);
+        launch_timed(cfg_combine_kernel<bf16>, dim3(blocks), dim3(threads), 0, stream, (const bf16 *)cond, (const bf16 *)uncond, g, out, n);
     else { set_error("cfg_combine: dtype %d unsupported", dtype); return PWW_ENOTSUP; }
     return check_hip(hipGetLastError(), "cfg_combine_kernel launch");
 }

@@ -258,12 +258,15 @@ def test_bench_under_torchrun_with_rccl(gpu_device):
 def test_results_do_not_depend_on_the_rank_count(gpu_device, tmp_path):
     """image i of the global batch is the same image whatever the number of ranks (seeds by global index, CPU generator:
     paint_with_words.py:446 / gradio_pww.py:24-45). bench.py --dump-latents with 1 rank (4 images) and with 2 ranks sharing this
-    GPU (gloo, 2 images each): the same 4 final latents up to the batch-size dependence of the stock conv / GEMM kernels."""
+    GPU (gloo, 2 images each): the same 4 final latents up to the batch-size dependence of the stock conv / GEMM kernels. Since round 5 both
+    runs take the DEFAULT cross-attention route (no launch needs its workgroups resident at once: two ranks may share a device), and the
+    2-rank line carries every rank's seconds / images per second (`config.per_rank`)."""
     args = ["--config", "3", "--denoise-steps", "3", "--steps", "1", "--warmup", "0", "--no-roofline-pass", "--no-reference-ops", "--cpu-steps", "0",
             "--tiny"]
     one = _run_bench(["--gpus", "1", "--batch", "4", "--dump-latents", str(tmp_path / "r1")] + args)
     two = _run_bench(["--gpus", "2", "--batch", "2", "--dump-latents", str(tmp_path / "r2")] + args, env_extra={"PWW_DIST_ONE_DEVICE": "1"})
     assert one["config"]["images_per_step"] == two["config"]["images_per_step"] == 4
+    assert len(two["config"]["per_rank"]["seconds"]) == 2 and len(one["config"]["per_rank"]["images_per_s"]) == 1
     a = np.load(str(tmp_path / "r1") + "_rank0.npy")
     b = np.concatenate([np.load(str(tmp_path / "r2") + "_rank%d.npy" % r) for r in (0, 1)])
     assert a.shape == b.shape == (4, 4, 64, 64)
