@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define PWW_VERSION 124 /* 0.1.24: pww_qk_parts / pww_qk_parts_count (statistic partials over a finished Q; pww_cross_attn_fwd_parts takes the small one-block-per-workgroup kernel where it fits); 0.1.23: pww_group_norm_fwd / pww_group_norm_workspace_bytes, pww_add_layer_norm, pww_geglu, pww_bias_residual (norms and elementwise glue of the blocks that call the attention path); 0.1.22: pww_qproj_stat / pww_qproj_parts / pww_cross_attn_fwd_parts (score statistic formed in the to_q GEMM's epilogue), pww_mask_build_f32_levels, PWW_STAT_ALL; 0.1.21: pww_cross_opts_t.gated_images (was padding); 0.1.20: + pww_cross_attn_fwd_fused_ex / pww_cross_attn_fwd_stat_ex (pww_cross_opts_t: device-side coefficient word, bias column bound,
+#define PWW_VERSION 125 /* 0.1.25: pww_cross_attn_fwd_parts_out / pww_cross_attn_out_supported (the C = 320 cross-attention layers with to_out + bias [+ residual] in the attention launch); 0.1.24: pww_qk_parts / pww_qk_parts_count (statistic partials over a finished Q; pww_cross_attn_fwd_parts takes the small one-block-per-workgroup kernel where it fits); 0.1.23: pww_group_norm_fwd / pww_group_norm_workspace_bytes, pww_add_layer_norm, pww_geglu, pww_bias_residual (norms and elementwise glue of the blocks that call the attention path); 0.1.22: pww_qproj_stat / pww_qproj_parts / pww_cross_attn_fwd_parts (score statistic formed in the to_q GEMM's epilogue), pww_mask_build_f32_levels, PWW_STAT_ALL; 0.1.21: pww_cross_opts_t.gated_images (was padding); 0.1.20: + pww_cross_attn_fwd_fused_ex / pww_cross_attn_fwd_stat_ex (pww_cross_opts_t: device-side coefficient word, bias column bound,
                            compact bias), pww_debug_timeline (0.1.11: pww_profile_*; 0.1.10: fused cross-attention, blur, resize, inpaint prep) */
 
 #define PWW_OK 0
@@ -273,6 +273,29 @@ int pww_cross_attn_fwd_parts(const void *q, const void *k, const void *v, void *
 int pww_qk_parts(const void *q, const void *k, const float *gate, const pww_attn_desc_t *desc, int32_t stat_kind, int32_t gated_images,
                  double *partials, size_t partials_bytes, void *stream);
 int32_t pww_qk_parts_count(const pww_attn_desc_t *desc);
+
+/*
+ * pww_cross_attn_fwd_parts WITH the layer's output projection in the launch (version >= 125):
+ *     out[b][n][:] = to_out[0]( merge_heads(O) )[b][n][:] (+ residual[b][n][:])        paint_with_words.py:118-123
+ *       = sum over heads h of  W[:, h*D .. h*D+D) . O_h[b][n][:]  + w_bias
+ * One workgroup owns 128 query rows of an image and walks ALL heads (O_h is rounded to the storage type where the two-launch path stores
+ * it, then multiplied from registers; the sum over heads and the bias add run in fp32, one rounding; the residual add is a second
+ * rounding, like the stock `linear(...) + residual`). O is never written. Differences to pww_cross_attn_fwd_parts + a library GEMM: the
+ * fp32 summation order of the 320-term dot products (results agree to the last bit or two of the storage type).
+ *   out        [B][N][C]   addressed out + b*desc->o_stride[0] + n*desc->o_stride[2] + c   (o_stride[1] is not read), 16-byte aligned rows
+ *   w          [C][H*D]    row-major nn.Linear weight (contiguous), storage type of q;  w_bias [C] same type, or NULL
+ *   residual   [B][N][C]   same type or NULL;  residual_stride = { b, n } in elements (read only with a residual)
+ *   bias       required, dense rows (bias_stride[3] == 1) shared by the heads (bias_stride[1] == 0), at most 64 non-zero columns
+ *              (opts->bias_cols or M <= 64)
+ * Supported (pww_cross_attn_out_supported returns 1): C = H*D = 320 with D <= 64 (SD1.5: 8 x 40, SD2.1: 5 x 64), 64 <= M <= 128; anything
+ * else returns PWW_ENOTSUP and the caller keeps pww_cross_attn_fwd_parts + its own GEMM. A launch has B * ceil(N / 128) workgroups (heads
+ * are sequential inside one): worth taking from ~8 images per launch on, measured slower below (profiles/r05_to_out_epilogue.md).
+ */
+int pww_cross_attn_fwd_parts_out(const void *q, const void *k, const void *v, void *out, const float *bias, int32_t stat_kind, float coeff_scalar,
+                                 const float *gate, const pww_attn_desc_t *desc, const double *partials, int32_t nparts, double *stats_out,
+                                 const pww_cross_opts_t *opts, const void *w, const void *w_bias, const void *residual,
+                                 const int64_t *residual_stride, void *stream);
+int32_t pww_cross_attn_out_supported(const pww_attn_desc_t *desc, int32_t c_out, int32_t bias_cols);
 
 /*
  * GroupNorm of the UNet blocks that call the attention path, fused with the elementwise neighbours those callers put around it

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "pww_hip", "libpww_hip.so")
-SOURCES = ["pww_api.hip", "pww_attn.hip", "pww_cross.hip", "pww_cross_lean.hip", "pww_reduce.hip", "pww_mask.hip", "pww_qproj.hip", "pww_norm.hip", "pww_blocks.hip"]
+SOURCES = ["pww_api.hip", "pww_attn.hip", "pww_cross.hip", "pww_cross_lean.hip", "pww_cross_out.hip", "pww_reduce.hip", "pww_mask.hip", "pww_qproj.hip", "pww_norm.hip", "pww_blocks.hip"]
 HEADERS = ["pww_common.h", "pww_tile.h", "pww_attn_core.h", "pww_cross_tile.h", os.path.join(REPO, "include", "pww_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",

@@ -168,6 +168,10 @@ int qproj_parts(const pww_qproj_desc_t *d);
 int qk_parts(const void *q, const void *k, const float *gate, const pww_attn_desc_t *d, int stat_kind, int gated_images, double *partials,
              size_t partials_bytes, hipStream_t stream);
 int qk_parts_count(const pww_attn_desc_t *d);
+int cross_attn_out(const void *q, const void *k, const void *v, void *out, const float *bias, int stat_kind, float coeff_scalar, const float *gate,
+                   const pww_attn_desc_t *d, const double *parts, int nparts, double *stats_out, const pww_cross_opts_t *opts, const void *w,
+                   const void *w_bias, const void *residual, const int64_t *residual_stride, hipStream_t stream);
+int cross_attn_out_supported(const pww_attn_desc_t *d, int C, int bias_cols);
 int mask_build_f32_levels(const float *masks, int H, int W, int R, const int32_t *col_ptr, const int32_t *col_reg, int T,
                           float *out8, float *out16, float *out32, float *out64, hipStream_t stream);
 size_t cross_fused_workspace_bytes(const pww_attn_desc_t *d);
@@ -265,6 +269,18 @@ int pww_qk_parts(const void *q, const void *k, const float *gate, const pww_attn
 }
 
 int32_t pww_qk_parts_count(const pww_attn_desc_t *desc) { return pww::qk_parts_count(desc); }
+
+int pww_cross_attn_fwd_parts_out(const void *q, const void *k, const void *v, void *out, const float *bias, int32_t stat_kind, float coeff_scalar,
+                                 const float *gate, const pww_attn_desc_t *desc, const double *partials, int32_t nparts, double *stats_out,
+                                 const pww_cross_opts_t *opts, const void *w, const void *w_bias, const void *residual,
+                                 const int64_t *residual_stride, void *stream) {
+    return pww::cross_attn_out(q, k, v, out, bias, stat_kind, coeff_scalar, gate, desc, partials, partials ? nparts : 0, stats_out, opts, w, w_bias,
+                               residual, residual_stride, static_cast<hipStream_t>(stream));
+}
+
+int32_t pww_cross_attn_out_supported(const pww_attn_desc_t *desc, int32_t c_out, int32_t bias_cols) {
+    return pww::cross_attn_out_supported(desc, c_out, bias_cols);
+}
 
 int pww_cross_attn_fwd_parts(const void *q, const void *k, const void *v, void *o, const float *bias, int32_t stat_kind,
                              float coeff_scalar, const float *gate, const pww_attn_desc_t *desc, const double *partials,

@@ -21,7 +21,7 @@ EXPORTS = ("pww_version", "pww_last_error", "pww_device_arch", "pww_self_attn_fw
            "pww_cross_fused_workspace_bytes", "pww_cross_fused_state_bytes",
            "pww_qk_reduce", "pww_mask_build", "pww_mask_build_rgb", "pww_mask_build_f32", "pww_resize_tokens", "pww_gauss_blur", "pww_inpaint_prep", "pww_cfg_combine", "pww_store_f32",
            "pww_workspace_bytes", "pww_profile_arm", "pww_profile_elapsed_us", "pww_profile_reset", "pww_debug_timeline",
-           "pww_qproj_stat", "pww_qproj_parts", "pww_cross_attn_fwd_parts", "pww_mask_build_f32_levels", "pww_qk_parts", "pww_qk_parts_count",
+           "pww_qproj_stat", "pww_qproj_parts", "pww_cross_attn_fwd_parts", "pww_mask_build_f32_levels", "pww_qk_parts", "pww_qk_parts_count", "pww_cross_attn_fwd_parts_out", "pww_cross_attn_out_supported",
            "pww_group_norm_fwd", "pww_group_norm_workspace_bytes", "pww_add_layer_norm", "pww_add_layer_norm_bias", "pww_geglu", "pww_bias_residual")
 
 
@@ -106,6 +106,11 @@ def load():
     lib.pww_qk_parts.restype = ctypes.c_int
     lib.pww_qk_parts_count.argtypes = [ctypes.POINTER(AttnDesc)]
     lib.pww_qk_parts_count.restype = ctypes.c_int32
+    lib.pww_cross_attn_fwd_parts_out.argtypes = [vp, vp, vp, vp, vp, i32, f32, vp, ctypes.POINTER(AttnDesc), vp, i32, vp, ctypes.POINTER(CrossOpts),
+                                                 vp, vp, vp, ctypes.POINTER(ctypes.c_int64), vp]
+    lib.pww_cross_attn_fwd_parts_out.restype = ctypes.c_int
+    lib.pww_cross_attn_out_supported.argtypes = [ctypes.POINTER(AttnDesc), ctypes.c_int32, ctypes.c_int32]
+    lib.pww_cross_attn_out_supported.restype = ctypes.c_int32
     lib.pww_mask_build_f32_levels.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.pww_mask_build_f32_levels.restype = ctypes.c_int
     lib.pww_group_norm_workspace_bytes.argtypes = [ctypes.POINTER(GnDesc)]
@@ -148,7 +153,7 @@ def load():
                  "pww_cross_attn_fwd_stat_ex", "pww_cross_attn_fwd_fused_ex", "pww_qk_reduce", "pww_mask_build",
                  "pww_mask_build_rgb", "pww_mask_build_f32", "pww_resize_tokens", "pww_gauss_blur", "pww_inpaint_prep", "pww_cfg_combine"):
         getattr(lib, name).restype = ctypes.c_int
-    if lib.pww_version() // 100 != 1 or lib.pww_version() < 124:
+    if lib.pww_version() // 100 != 1 or lib.pww_version() < 125:
         raise PwwHipError("libpww_hip ABI version %d is not 1.x >= 1.24 (rebuild: python paint-with-words-sd_amd/build.py)" % lib.pww_version())
     _lib = lib
     return lib

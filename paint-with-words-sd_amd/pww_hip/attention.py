@@ -35,6 +35,13 @@ GATED_ROWS = "_PWW_GATED_ROWS"     # private context key: int, _PWW_ROW_GATE is 
 # over the finished Q of the stock GEMM (pww_qk_parts: the C = 1280 layers). PWW_FUSED_CROSS=1 selects round 3's form instead (statistic
 # + device-scope hand-off inside the attention launch, pww_cross_attn_fwd_fused: needs every workgroup resident at once): TEST / A-B only.
 FUSED_CROSS = os.environ.get("PWW_FUSED_CROSS", "0") == "1"
+# the C = 320 cross-attention layers with to_out (+ bias) applied INSIDE the attention launch
+# (pww_cross_attn_fwd_parts_out: one workgroup per 128 query rows walks all heads, then multiplies its O image with W_o). Built, pinned
+# to the two-launch route bit for bit on the test shapes, and measured: 34 us against 18 us (small kernel + the stock GEMM with its bias
+# epilogue) at the 2 folded rows of a batch-1 request, 38 against 41 at 8 rows, 71 against 73 at 16 (profiles/r05_to_out_epilogue.md) --
+# heads run one after the other inside a workgroup where the two-launch route runs them on eight CUs. Off by default; PWW_FUSE_TO_OUT=1
+# takes it wherever the kernel covers the layer.
+FUSE_TO_OUT = os.environ.get("PWW_FUSE_TO_OUT", "0") == "1"
 QPROJ_STAT = os.environ.get("PWW_QPROJ_STAT", "1")       # "1" where it wins (default) | "0" never | "all" wherever the kernel supports the shape
 
 
@@ -565,6 +572,19 @@ def refresh_kv_cache(context):
 def pww_attention(attn, hidden_states, context=None):
     """Core of inj_forward (:63-118): projections -> [optional bias] -> fused attention, returning the
     merged-head [B, N, heads*D] tensor BEFORE the output projection."""
+    return _attention(attn, hidden_states, context, None)[0]
+
+
+def _attention_and_out(attn, hidden_states, context):
+    """inj_forward's :63-123: the attention and to_out[0] (to_out[1], the dropout, is the caller's)."""
+    lin = attn.to_out[0]
+    out, projected = _attention(attn, hidden_states, context, lin if FUSE_TO_OUT else None)
+    return out if projected else lin(out.to(lin.weight.dtype))
+
+
+def _attention(attn, hidden_states, context, out_linear):
+    """-> (tensor, projected): with `out_linear` (the layer's to_out[0]) and a layer pww_cross_attn_fwd_parts_out covers, the
+    projection is applied inside the attention launch and `projected` is True."""
     is_dict = True
     if context is not None:
         if isinstance(context, dict) or hasattr(context, "keys"):
@@ -721,17 +741,22 @@ def pww_attention(attn, hidden_states, context=None):
     elif slots is not None and stat is None:
         slots.unsupported = True       # a materialised bias tensor depends on sigma through torch ops
     if bias is None:
-        return ops.attention(query, key, value, attn.heads, attn.scale)
+        return ops.attention(query, key, value, attn.heads, attn.scale), False
+    if (out_linear is not None and stat is not None and stat[0] is None and scratch is None and key.shape[1] <= ops.FUSED_MAX_KEYS
+            and out_linear.weight.dtype == query.dtype and ops.attention_out_supported(query, key, attn.heads, bias, out_linear.weight, bias_cols)):
+        # row f-1 (opt-in, FUSE_TO_OUT): attention + to_out[0] in one launch; the dense map serves (the compact form is the general kernel's)
+        wb = out_linear.bias
+        return ops.attention_out(query, key, value, attn.heads, attn.scale, bias, out_linear.weight, wb if wb is None else wb.to(query.dtype),
+                                 bias_coeff=gate, stat=stat, parts=parts, coeff_dev=coeff_dev, bias_cols=bias_cols, gated=gated), True
     return ops.attention(query, key, value, attn.heads, attn.scale, bias=bias, bias_coeff=gate, stat=stat, scratch=scratch,
-                         coeff_dev=coeff_dev, bias_cols=bias_cols, compact=compact, gated=gated, parts=parts)
+                         coeff_dev=coeff_dev, bias_cols=bias_cols, compact=compact, gated=gated, parts=parts), False
 
 
 def inj_forward(self, hidden_states, context=None, mask=None):
     """Drop-in for the reference's ``inj_forward`` (:60-125): same signature, same context protocol
     ({None | Tensor | dict with CONTEXT_TENSOR / CROSS_ATTENTION_WEIGHT_* / SIGMA / WEIGHT_FUNCTION}),
     ``mask`` accepted and ignored like the reference (:61)."""
-    out = pww_attention(self, hidden_states, context)
-    out = self.to_out[0](out.to(self.to_out[0].weight.dtype))
+    out = _attention_and_out(self, hidden_states, context)
     out = self.to_out[1](out)
     return out
 
@@ -777,8 +802,7 @@ class PwWAttnProcessor:
                 ctx["CONTEXT_TENSOR"] = normed
             else:
                 ctx = attn.norm_encoder_hidden_states(ctx)
-        out = pww_attention(attn, hidden_states, ctx)
-        out = attn.to_out[0](out.to(attn.to_out[0].weight.dtype))
+        out = _attention_and_out(attn, hidden_states, ctx)
         out = attn.to_out[1](out)
         if spatial:
             out = out.transpose(-1, -2).reshape(b, c, h, w)

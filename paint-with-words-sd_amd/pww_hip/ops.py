@@ -311,6 +311,84 @@ def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None, scra
     return out
 
 
+def _bias_view(bias, B, heads, N, M):
+    if bias.dtype != torch.float32:
+        bias = bias.float()
+    if bias.dim() == 3 and bias.shape[0] == B * heads and B * heads != 1:
+        bias = bias.reshape(B, heads, bias.shape[1], bias.shape[2])
+    return torch.broadcast_to(bias, (B, heads, N, M))  # view: broadcast axes get stride 0
+
+
+def attention_out_supported(q, k, heads, bias, weight, bias_cols=0):
+    """True if attention_out (cross-attention + to_out in one launch) takes this problem: C = heads * D = 320 with D <= 64, 64 <= M <= 128,
+    a dense fp32 map shared by the heads with at most 64 non-zero columns, weight [C, C] of q's dtype."""
+    if q.dtype not in _DT or q.dim() != 3 or k.dim() != 3 or bias is None or not torch.is_tensor(weight):
+        return False
+    B, N, C = q.shape
+    M = k.shape[1]
+    if tuple(weight.shape) != (C, C) or weight.dtype != q.dtype or not weight.is_contiguous() or C % heads:
+        return False
+    try:
+        bv = _bias_view(bias, B, heads, N, M)
+    except RuntimeError:
+        return False
+    d = AttnDesc()
+    d.dtype = _DT[q.dtype]
+    d.B, d.H, d.N, d.M, d.D = B, heads, N, M, C // heads
+    d.q_stride[:] = [q.stride(0), C // heads, q.stride(1)]
+    d.bias_stride[:] = list(bv.stride())
+    return bool(_lib.load().pww_cross_attn_out_supported(ctypes.byref(d), C, int(bias_cols)))
+
+
+def attention_out(q, k, v, heads, scale, bias, weight, weight_bias=None, residual=None, bias_coeff=None, stat=None, parts=None, stats_out=None,
+                  coeff_dev=None, bias_cols=0, gated=0):
+    """linear(attention(q, k, v, ...), weight, weight_bias) [+ residual] in ONE launch (pww_cross_attn_fwd_parts_out: reference
+    paint_with_words.py:106-123): the pass-2-only cross-attention of `attention(..., stat=(None, kind, scalar), parts=parts)` with the
+    layer's to_out projection applied to the heads' outputs while they are still in registers. stat = (None, kind, scalar) or None
+    (= a plain `bias_coeff * bias`). Ask attention_out_supported first; anything else raises."""
+    _require_gpu(q, k, v, bias, bias_coeff, weight, weight_bias, residual)
+    if not (q.dtype == k.dtype == v.dtype == weight.dtype):
+        raise PwwHipError("q/k/v/weight dtypes differ: %s %s %s %s" % (q.dtype, k.dtype, v.dtype, weight.dtype))
+    q, k, v = _prep(q), _prep(k), _prep(v)
+    B, N, C = q.shape
+    M = k.shape[1]
+    if tuple(weight.shape) != (C, C) or not weight.is_contiguous():
+        raise PwwHipError("attention_out: weight must be a contiguous [%d, %d] tensor" % (C, C))
+    if weight_bias is not None and (weight_bias.dtype != q.dtype or tuple(weight_bias.shape) != (C,) or not weight_bias.is_contiguous()):
+        raise PwwHipError("attention_out: weight_bias must be a contiguous [%d] tensor of q's dtype" % C)
+    if residual is not None and (residual.dtype != q.dtype or tuple(residual.shape) != (B, N, C) or residual.stride(2) != 1):
+        raise PwwHipError("attention_out: residual must be a [B, N, C] tensor of q's dtype with unit channel stride")
+    out = torch.empty((B, N, C), dtype=q.dtype, device=q.device)
+    d = _desc(q, k, v, out, heads, scale)
+    bias = _bias_view(bias, B, heads, N, M)
+    d.bias_stride[:] = list(bias.stride())
+    if bias_coeff is not None:
+        bias_coeff = bias_coeff.to(torch.float32).reshape(-1).contiguous()
+        if bias_coeff.numel() == 1 and B > 1:
+            bias_coeff = bias_coeff.expand(B).contiguous()
+        if bias_coeff.numel() != B:
+            raise PwwHipError("bias_coeff must have B=%d elements" % B)
+    kind, scalar = (STAT_NONE, 1.0) if stat is None else (stat[1], stat[2])
+    if stat is not None and stat[0] is not None:
+        raise PwwHipError("attention_out folds partials (stat = (None, kind, scalar), parts = qproj_stat / qk_parts output)")
+    if kind != STAT_NONE and parts is None:
+        raise PwwHipError("attention_out: a statistic needs its partials (qproj_stat / qk_parts)")
+    if parts is not None and (parts.dtype != torch.float64 or parts.dim() != 3 or parts.shape[0] != B or parts.shape[2] != 4 or not parts.is_contiguous()):
+        raise PwwHipError("parts must be a contiguous float64 [B, nparts, 4] tensor")
+    if stats_out is not None and (stats_out.dtype != torch.float64 or tuple(stats_out.shape) != (B, 4) or not stats_out.is_contiguous()):
+        raise PwwHipError("stats_out must be a contiguous float64 [B, 4] tensor")
+    keep = []
+    op = _cross_opts(B, N, coeff_dev, bias_cols, None, keep, gated)
+    rs = (ctypes.c_int64 * 2)(residual.stride(0), residual.stride(1)) if residual is not None else None
+    lib = _lib.load()
+    with torch.cuda.device(q.device):
+        rc = lib.pww_cross_attn_fwd_parts_out(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(bias), int(kind), float(scalar), _ptr(bias_coeff), ctypes.byref(d),
+                                              _ptr(parts), int(parts.shape[1]) if parts is not None else 0, _ptr(stats_out),
+                                              ctypes.byref(op) if op is not None else None, _ptr(weight), _ptr(weight_bias), _ptr(residual), rs, _stream())
+    _lib.check(rc, "pww_cross_attn_fwd_parts_out")
+    return out
+
+
 def _qproj_desc(x, weight, k, heads):
     if x.dim() != 3 or k.dim() != 3 or weight.dim() != 2:
         raise PwwHipError("qproj: x [B, N, Cin], weight [C, Cin], k [B or 1, M, C]")

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol(built_lib):
     raw = ctypes.CDLL(built_lib)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.pww_version() == 124
+    assert lib.pww_version() == 125
     assert lib.pww_last_error() == b"" or isinstance(lib.pww_last_error(), bytes)
     assert lib.pww_workspace_bytes(None) == 0
 

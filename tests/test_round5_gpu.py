@@ -142,6 +142,85 @@ def test_pass2_only_launch_vs_fp64(gpu_device, dtype, name, B, N, H, D, M, share
     assert err3 <= TOL[dtype], err3
 
 
+OUT_SHAPES = [
+    # name, B, N, heads, D, M, shared prompt          (C = heads * D = 320: the layers pww_cross_attn_fwd_parts_out takes)
+    ("sd15_n4096", 2, 4096, 8, 40, 77, False),
+    ("sd15_n4096_b5", 5, 4096, 8, 40, 77, True),
+    ("sd21_n9216", 2, 9216, 5, 64, 77, False),
+    ("ragged_n333_m128", 3, 333, 8, 40, 128, False),
+    ("d32_n200_m64", 2, 200, 10, 32, 64, True),
+    ("d48_n100_m90", 1, 100, 5, 64, 90, False),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name,B,N,H,D,M,shared", OUT_SHAPES)
+def test_cross_attention_with_to_out_in_the_launch(gpu_device, dtype, name, B, N, H, D, M, shared):
+    """pww_cross_attn_fwd_parts_out (row f-1: attention + to_out + bias [+ residual] in one launch) against the two-launch route it
+    replaces -- `linear(pww_cross_attn_fwd_parts(...), W, b) [+ residual]` in fp64 ON THE KERNEL'S OWN rounded O (the projection must see
+    exactly the O the two-launch path stores) -- and against the fp64 reference of the whole expression (paint_with_words.py:106-123).
+    Bitwise repeatable; the statistic kinds rotate; the last image is gated out where there are several."""
+    from pww_hip import ops
+    q, k, v = _qkv(name, B, N, H, D, M, shared, dtype, gpu_device)
+    C = H * D
+    g = torch.Generator().manual_seed(len(name) + N)
+    cols = [16, 32, 48, 64][N % 4]
+    bias = ((torch.rand(N, M, generator=g) < 0.3).float() * torch.rand(N, M, generator=g) * 1.5)
+    bias[:, cols:] = 0
+    bias = bias.to(gpu_device)
+    w = (torch.randn(C, C, generator=g) / math.sqrt(C)).to(dtype).to(gpu_device)
+    wb = (torch.randn(C, generator=g) * 0.1).to(dtype).to(gpu_device)
+    res = torch.randn(B, N, C, generator=g).to(dtype).to(gpu_device)
+    gate = torch.ones(B, device=gpu_device)
+    if B > 1:
+        gate[B - 1] = 0.0
+    gated = B - 1 if B > 1 else 0
+    kind = [ops.STAT_MAX, ops.STAT_STD, ops.STAT_NONE, ops.STAT_MEAN][(N + H) % 4]
+    scale, c0 = D ** -0.5, 0.37
+    assert ops.attention_out_supported(q, k, H, bias, w, cols)
+    parts = ops.qk_parts(q, k, H, kind, gate=gate, gated=gated) if kind != ops.STAT_NONE else None
+    kw = dict(bias_coeff=gate, stat=(None, kind, c0), parts=parts, bias_cols=cols, gated=gated)
+    o = ops.attention(q, k, v, H, scale, bias=bias, **kw)                       # the two-launch route's O (rounded to the storage type)
+    out = ops.attention_out(q, k, v, H, scale, bias, w, wb, **kw)
+    two = o.double() @ w.double().t() + wb.double()
+    ulp = 2.0 ** (-8 if dtype == torch.bfloat16 else -11)
+    # one rounding of an fp32 sum that differs from the fp64 one by summation order only: within an ulp of the result's magnitude
+    err = ((out.double() - two).abs() / (two.abs() + two.abs().max() * 2 ** -6)).max().item()
+    print(f"attention_out {name} {dtype} cols {cols} kind {kind}: max err vs the two-launch route {err / ulp:.2f} ulp")
+    assert torch.isfinite(out).all() and err <= 1.5 * ulp, err / ulp      # (half a spacing of the storage type + the fp32 summation order; the O of a large batch comes from the general kernel: last-bit differences)
+    # the whole expression in fp64 (BASELINE.md's bar per attention call, through the projection)
+    _, s = _reference(q, k, v, H, scale, bias, torch.zeros(B, device=q.device))
+    sb = s.reshape(B, -1)
+    stat = {ops.STAT_MAX: sb.max(1).values, ops.STAT_STD: sb.std(1), ops.STAT_MEAN: sb.mean(1), ops.STAT_NONE: torch.ones(B, dtype=torch.float64, device=q.device)}[kind]
+    ref_o, _ = _reference(q, k, v, H, scale, bias, c0 * stat * gate.double())
+    ref = ref_o @ w.double().t() + wb.double()
+    e64 = (out.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert e64 <= TOL[dtype], e64
+    # with the residual: a second rounding, like `linear(...) + residual`
+    out_r = ops.attention_out(q, k, v, H, scale, bias, w, wb, residual=res, **kw)
+    assert torch.equal(out_r, out + res)
+    # without a bias vector; bitwise repeatable
+    out_nb = ops.attention_out(q, k, v, H, scale, bias, w, None, **kw)
+    two_nb = o.double() @ w.double().t()
+    assert ((out_nb.double() - two_nb).abs() / (two_nb.abs() + two_nb.abs().max() * 2 ** -6)).max().item() <= 1.5 * ulp
+    assert torch.equal(out, ops.attention_out(q, k, v, H, scale, bias, w, wb, **kw))
+
+
+def test_cross_attention_with_to_out_declines_what_it_does_not_take(gpu_device):
+    from pww_hip import ops
+    dev, dt = gpu_device, torch.bfloat16
+    q, k, v = _qkv("decl", 2, 256, 8, 80, 77, False, dt, dev)          # C = 640
+    bias = torch.rand(256, 77, device=dev)
+    w = torch.randn(640, 640, device=dev).to(dt)
+    assert not ops.attention_out_supported(q, k, 8, bias, w, 32)
+    with pytest.raises(ops.PwwHipError):
+        ops.attention_out(q, k, v, 8, 80 ** -0.5, bias, w, None, stat=(None, ops.STAT_NONE, 1.0))
+    q, k, v = _qkv("decl2", 2, 256, 8, 40, 40, False, dt, dev)         # M < 64
+    assert not ops.attention_out_supported(q, k, 8, torch.rand(256, 40, device=dev), torch.randn(320, 320, device=dev).to(dt), 32)
+    q, k, v = _qkv("decl3", 2, 256, 8, 40, 77, False, dt, dev)         # a map per head
+    assert not ops.attention_out_supported(q, k, 8, torch.rand(2, 8, 256, 77, device=dev), torch.randn(320, 320, device=dev).to(dt), 32)
+
+
 def test_default_path_has_no_handoff_state_on_any_layer(gpu_device):
     """VERDICT round 4 item 1a "done" criterion: pww_cross_attn_fwd_fused is not reachable with default settings -- after full requests
     through the SD1.5 topology (1/8 width: no pww_qproj_stat tile on any layer -> every layer takes pww_qk_parts) and through the
@@ -172,6 +251,43 @@ def test_default_path_has_no_handoff_state_on_any_layer(gpu_device):
                "SIGMA": torch.tensor(7.84), "WEIGHT_FUNCTION": cases.weight_fn_runner}
         y = pww_hip.inj_forward(mod, case["hidden"].to(gpu_device, torch.bfloat16), ctx)
         assert torch.isfinite(y).all() and "_pww_fused_scratch" not in mod.__dict__, shape
+
+
+@pytest.mark.parametrize("shape", ["sd15_n4096", "sd21_n2304"])
+def test_plug_with_to_out_inside_the_launch(gpu_device, monkeypatch, shape):
+    """PWW_FUSE_TO_OUT (row f-1, opt-in): inj_forward of a C = 320 cross-attention layer with the projection inside the attention launch
+    against the default two-launch route -- the same module, the same PwW dict; eager and with a CFG-folded row gate. A layer the kernel
+    does not cover (C = 640) silently keeps the two-launch route."""
+    import pww_hip
+    from pww_hip import attention
+    monkeypatch.setitem(cases.ATTN_SHAPES, "sd21_n2304", (2304, 320, 5, 1024))      # SD2.1's finest level at 384 x 384: 5 heads x 64
+    case = cases.make_attention_case(shape)
+    mod = case["attn_cross"].to(gpu_device, torch.bfloat16)
+    hidden = case["hidden"].to(gpu_device, torch.bfloat16)
+    ctx = {"CONTEXT_TENSOR": case["ctx"].to(gpu_device, torch.bfloat16), f"CROSS_ATTENTION_WEIGHT_{case['N']}": case["w"].to(gpu_device),
+           "SIGMA": torch.tensor(7.84), "WEIGHT_FUNCTION": cases.weight_fn_runner,
+           attention.BIAS_COLS: 32}      # (the pipeline's hint: columns >= 32 of the map are zero -- the kernel takes maps of at most 64 columns)
+    seen = []
+    orig = attention.ops.attention_out
+    monkeypatch.setattr(attention.ops, "attention_out", lambda *a, **kw: (seen.append(1), orig(*a, **kw))[1])
+    two = pww_hip.inj_forward(mod, hidden, dict(ctx))
+    assert not seen
+    monkeypatch.setattr(attention, "FUSE_TO_OUT", True)
+    one = pww_hip.inj_forward(mod, hidden, dict(ctx))
+    assert seen, "the fused-projection launch was not taken"
+    d = (one.double() - two.double()).abs()
+    print(f"to_out inside the launch, {shape}: max |diff| {d.max().item():.2e} of max |y| {two.abs().max().item():.2e}, {int((d > 0).sum())} elements differ")
+    assert torch.isfinite(one).all() and d.max().item() <= 2.0 ** -7 * two.abs().max().item()
+    # uncovered layer: same route as before, same bits
+    case2 = cases.make_attention_case("sd15_n1024")
+    mod2 = case2["attn_cross"].to(gpu_device, torch.bfloat16)
+    ctx2 = {"CONTEXT_TENSOR": case2["ctx"].to(gpu_device, torch.bfloat16), f"CROSS_ATTENTION_WEIGHT_{case2['N']}": case2["w"].to(gpu_device),
+            "SIGMA": torch.tensor(7.84), "WEIGHT_FUNCTION": cases.weight_fn_runner}
+    n = len(seen)
+    y_on = pww_hip.inj_forward(mod2, case2["hidden"].to(gpu_device, torch.bfloat16), dict(ctx2))
+    monkeypatch.setattr(attention, "FUSE_TO_OUT", False)
+    y_off = pww_hip.inj_forward(mod2, case2["hidden"].to(gpu_device, torch.bfloat16), dict(ctx2))
+    assert len(seen) == n and torch.equal(y_on, y_off)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

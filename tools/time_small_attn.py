@@ -127,6 +127,35 @@ def main():
             lines.append("| N=%d C=%d | %.2f | %.2f |" % (N, C, t1, t2))
             print(lines[-1], flush=True)
         lines.append("")
+    if not what or "outproj" in what:
+        # f-1 measured: cross-attention + to_out in ONE launch (pww_cross_attn_fwd_parts_out: heads sequential in a workgroup of 128 rows) against
+        # the two-launch route (pass-2-only attention + the stock GEMM with its bias epilogue), per number of folded rows
+        lines += ["| C = 320 cross-attention + to_out (N = 4096, 8 x 40, M = 77, gate = first half) | rows | attention | stock to_out | both back to back | attention_out (one launch) | max diff / max |",
+                  "|---|---|---|---|---|---|---|"]
+        N, C, H = 4096, 320, 8
+        D = C // H
+        for B in (2, 4, 8, 16, 32):
+            g = torch.Generator().manual_seed(3)
+            q = (torch.randn(B, N, C, generator=g) * 0.6).to(dev, dtype)
+            k = torch.randn(B, 77, C, generator=g).to(dev, dtype)
+            v = torch.randn(B, 77, C, generator=g).to(dev, dtype)
+            w = (torch.randn(C, C, generator=g) / math.sqrt(C)).to(dev, dtype)
+            wb = torch.randn(C, generator=g).to(dev, dtype)
+            bias = ((torch.rand(N, 77, generator=g) < 0.3).float() * torch.rand(N, 77, generator=g) * 1.5)
+            bias[:, 32:] = 0
+            bias = bias.to(dev)
+            gate = torch.tensor([1.0] * (B // 2) + [0.0] * (B - B // 2)).to(dev)
+            parts = ops.qk_parts(q, k, H, ops.STAT_MAX, gate=gate, gated=B // 2)
+            kw = dict(bias_coeff=gate, stat=(None, ops.STAT_MAX, 0.37), parts=parts, bias_cols=32, gated=B // 2)
+            t_a = replay_us(lambda: ops.attention(q, k, v, H, D ** -0.5, bias=bias, **kw))
+            o = ops.attention(q, k, v, H, D ** -0.5, bias=bias, **kw)
+            t_l = replay_us(lambda: F.linear(o, w, wb))
+            t_2 = replay_us(lambda: F.linear(ops.attention(q, k, v, H, D ** -0.5, bias=bias, **kw), w, wb))
+            t_1 = replay_us(lambda: ops.attention_out(q, k, v, H, D ** -0.5, bias, w, wb, **kw))
+            a, b2 = ops.attention_out(q, k, v, H, D ** -0.5, bias, w, wb, **kw).float(), F.linear(o, w, wb).float()
+            lines.append("| | %d | %.2f | %.2f | %.2f | **%.2f** | %.1e |" % (B, t_a, t_l, t_2, t_1, (a - b2).abs().max().item() / b2.abs().max().item()))
+            print(lines[-1], flush=True)
+        lines.append("")
     text = "\n".join(lines) + "\n"
     if out:
         with open(out, "a") as f:
