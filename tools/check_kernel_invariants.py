@@ -139,6 +139,18 @@ def main():
     isa = kernel_isa(lean_src, r"_ZN3pww15qk_parts_kernelIDF16bLi10ELb0EEEvNS_13QkPartsParamsE")
     lines = [l.strip() for l in next(iter(isa.values()))]
     check(not any(l.startswith(("s_barrier", "ds_write", "ds_read")) for l in lines), "qk_parts_kernel (fine form): no barrier, no LDS traffic besides the shuffles' ds_bpermute")
+    # ---- 4. (round 5) cross-attention + to_out in one launch: the two-phase form must stay inside the 256 architectural registers (past them
+    # hipcc selects the accumulator-file form of every MFMA and copies each score / O tile to and from it: 1136 v_accvgpr moves and 40 us per
+    # workgroup in the one-phase version), with no scratch and no waterfall loop around a buffer load
+    out_src = os.path.join(CSRC, "pww_cross_out.hip")
+    for name, r in resource_usage(out_src).items():
+        if "cross_out_kernel" in name:
+            check(int(r["ScratchSize [bytes/lane]"]) == 0 and int(r["VGPRs"]) <= 256, "%s: %s VGPRs (<= 256), %s B scratch (none)" % (name[:60], r["VGPRs"], r["ScratchSize [bytes/lane]"]))
+    isa = kernel_isa(out_src, r"_ZN3pww16cross_out_kernelIDF16bLi3ELi10EEEvNS_9OutParamsE")
+    lines = [l.strip() for l in next(iter(isa.values()))]
+    acc = sum(1 for l in lines if l.startswith("v_accvgpr"))
+    wf = sum(1 for i, l in enumerate(lines) if l.startswith("buffer_load") and any(x.startswith("s_cbranch_execnz") for x in lines[i + 1:i + 4]))      # (load; s_xor exec; s_cbranch_execnz = a waterfall loop)
+    check(acc == 0 and wf == 0, "cross_out_kernel (bf16, d = 40): %d accumulator-file moves, %d buffer loads inside a waterfall loop (none)" % (acc, wf))
     print("%d violation(s)" % len(bad))
     return 1 if bad else 0
 
