@@ -565,6 +565,9 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn_under_launcher(args.gpus))
+    # stdout carries the ONE JSON line and nothing else: whatever the path prints on its way (the reference's own "Use region based
+    # seeding" line of the region-seeded configs, paint_with_words.py:449) goes to stderr with the bench log
+    json_out, sys.stdout = sys.stdout, sys.stderr
 
     cfg = dict(CONFIGS[args.config])
     for k_arg, k_cfg in (("batch", "batch"), ("dtype", "dtype"), ("scheduler", "scheduler"), ("denoise_steps", "denoise_steps")):
@@ -649,7 +652,7 @@ def main():
         pdist.barrier(device)
         result.update({"dry_run": True, "dtype": "fp32", "data": "synthetic (1/8-width model, nothing timed)"})
         if rank == 0:
-            print(json.dumps(result), flush=True)
+            print(json.dumps(result), file=json_out, flush=True)
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         return
@@ -793,7 +796,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_steps > 0 and cfg["kind"] == "txt2img":
         result["cpu_baseline"] = cpu_baseline(args, cfg, request)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        print(json.dumps(result), file=json_out, flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
