@@ -25,13 +25,21 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
                  an instrumented (eager) pass of the same workload: every launch stamps its own start / end device
                  timestamps into a HIP event pair on the launch stream (pww_profile_arm -> hipExtLaunchKernelGGL), i.e.
                  the kernel duration rocprofv3 reports, without host latency or dispatch gaps; the 40-launch back-to-back
-                 hipGraph replay number (event interval / 40) is kept beside it;
+                 hipGraph replay number (event interval / 40) is kept beside it; `traffic` (HBM-side bytes per launch) and
+                 `mfma_busy` are measured LIVE by three rocprofv3 --pmc passes over the native harness's launch of the same
+                 shape (~4 s; the committed constant, labelled as such, when rocprofv3 is absent or with --no-live-counters);
+  "counters_cross_route"  the same two counters for the C = 1280 cross-attention pair (pww_qk_parts + the small kernel);
+  "attention_path"  per UNet forward: the dominant launches, and every other pww launch class summed (kernel-only in the
+                 workload, and back to back);
   "kernels"      the same pass's table for EVERY pww launch class: average duration, algorithmic TFLOP/s and GB/s,
                  bounding roofline and fraction; plus a hot-logit run of the dominant shape;
   "cpu_baseline" the CPU oracle (port of the reference path) timed on this box's host cores on a bounded sample
                  (rank 0, N=1 only): torch thread counts 8 / 16 / 32 / 64 / 128 are swept on one UNet forward each and the
                  BEST one is used for the timed denoise step(s) -- the 256-vCPU bench box is slower oversubscribed --, with the
-                 AST-loaded reference's own timing from the build box beside it.
+                 AST-loaded reference's own timing from the build box beside it (`host`: gpu_box_port / build_box_reference);
+  "config"       the workload, plus block_norms_calls (fused / declined calls of the block plug; the run asserts hit rate
+                 1.0), per_rank (every rank's seconds and images/s), the weight / request broadcast seconds.
+stdout carries that line and nothing else; the log and whatever the path prints go to stderr.
 
 Test infrastructure used as bench infrastructure (deliberately, so that bench and parity tests see the same inputs):
 `tests/pww_cases.py` (workload definitions: color maps, color_contexts, prompts, weight functions, stand-in builders) and
