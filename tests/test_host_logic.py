@@ -752,3 +752,33 @@ def test_qproj_route_follows_the_measured_table(monkeypatch):
     assert A.qproj_route(1280, 64)
     monkeypatch.setattr(A, "QPROJ_STAT", "0")
     assert not A.qproj_route(320, 40)
+
+
+def test_fused_projection_entry_point_says_what_it_takes(built_lib):
+    """pww_cross_attn_out_supported is host logic (no GPU): the shapes pww_cross_attn_fwd_parts_out takes -- H * D = 320 with D <= 64,
+    64 <= M <= 128, dense bias rows shared by the heads, at most 64 non-zero map columns -- and nothing else; the Python op refuses CPU
+    tensors like every other op; the route is opt-in."""
+    import ctypes
+    import pww_hip
+    from pww_hip import _lib, ops, attention
+    lib = _lib.load()
+
+    def desc(H, D, N=4096, M=77, bias_stride=(0, 0, 77, 1), dtype=1):
+        d = _lib.AttnDesc()
+        d.dtype, d.B, d.H, d.N, d.M, d.D = dtype, 2, H, N, M, D
+        d.q_stride[:] = [N * H * D, D, H * D]
+        d.bias_stride[:] = list(bias_stride)
+        return d
+    ok = lambda d, C=320, cols=32: bool(lib.pww_cross_attn_out_supported(ctypes.byref(d), C, cols))      # noqa: E731
+    assert ok(desc(8, 40)) and ok(desc(5, 64)) and ok(desc(10, 32)) and ok(desc(8, 40, dtype=0))
+    assert ok(desc(8, 40, M=64), cols=0) and ok(desc(8, 40, M=128))
+    assert not ok(desc(8, 80), C=640) and not ok(desc(8, 160), C=1280) and not ok(desc(4, 80))           # other widths, D > 64
+    assert not ok(desc(8, 40), C=640)                                                                     # C must be H * D
+    assert not ok(desc(8, 40, M=40)) and not ok(desc(8, 40, M=129))
+    assert not ok(desc(8, 40), cols=0)                                                                    # 77 keys without a column bound: 80 > 64 columns
+    assert not ok(desc(8, 40, bias_stride=(0, 4096 * 77, 77, 1))) and not ok(desc(8, 40, bias_stride=(0, 0, 1, 4096)))      # a map per head / transposed rows
+    assert not lib.pww_cross_attn_out_supported(None, 320, 32)
+    x = torch.randn(1, 128, 320).half()
+    with pytest.raises(pww_hip.PwwHipError):
+        ops.attention_out(x, x[:, :77], x[:, :77], 8, 1.0, torch.rand(128, 77), torch.randn(320, 320).half())
+    assert attention.FUSE_TO_OUT is (os.environ.get("PWW_FUSE_TO_OUT", "0") == "1")
