@@ -764,6 +764,42 @@ static void run_qproj(const QCase &c, bool timing) {
         printf("%s %-30s qk_parts + parts-attention kind=%d: max diff %.3e vs two-step path (nan=%ld, rc %d %s)\n", ok3 ? "PASS" : "FAIL", c.name, kind, dmax3, nan3, r3, r3 ? pww_last_error() : "");
         if (!ok3) g_fail++;
     }
+    // (4) the same attention WITH the layer's output projection in the launch (pww_cross_attn_fwd_parts_out, the C = 320 layers): against the
+    // fp64 projection of the O the two-launch route just stored (sampled rows, every output channel) -- one rounding of the storage type
+    if (pww_cross_attn_out_supported(&d, C, op.bias_cols)) {
+        std::vector<uint16_t> wo((size_t)C * C), wob(C);
+        std::vector<float> wof(wo.size()), wobf(C);
+        for (size_t i = 0; i < wo.size(); ++i) { wo[i] = to_t(rng_normal() / sqrtf((float)C), c.dtype); wof[i] = from_t(wo[i], c.dtype); }
+        for (int i = 0; i < C; ++i) { wob[i] = to_t(rng_normal() * 0.1f, c.dtype); wobf[i] = from_t(wob[i], c.dtype); }
+        uint16_t *dwo = dalloc<uint16_t>(wo.size()), *dwob = dalloc<uint16_t>(C);
+        HIPCHECK(hipMemcpy(dwo, wo.data(), wo.size() * 2, hipMemcpyHostToDevice)); HIPCHECK(hipMemcpy(dwob, wob.data(), C * 2, hipMemcpyHostToDevice));
+        HIPCHECK(hipMemset(o1, 0xff, (size_t)B * N * C * 2)); HIPCHECK(hipMemset(o2, 0xee, (size_t)B * N * C * 2));
+        int r1 = pww_cross_attn_fwd_parts(dq, dk, dv, o2, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, dparts, nparts, nullptr, &op, nullptr);
+        int r2 = pww_cross_attn_fwd_parts_out(dq, dk, dv, o1, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, dparts, nparts, nullptr, &op, dwo, dwob, nullptr, nullptr, nullptr);
+        HIPCHECK(hipDeviceSynchronize());
+        std::vector<uint16_t> ho((size_t)B * N * C), hout(ho.size());
+        HIPCHECK(hipMemcpy(ho.data(), o2, ho.size() * 2, hipMemcpyDeviceToHost)); HIPCHECK(hipMemcpy(hout.data(), o1, hout.size() * 2, hipMemcpyDeviceToHost));
+        double pmax = 0; std::vector<double> pref; std::vector<size_t> pidx;
+        for (int b = 0; b < B; ++b) for (int n = 0; n < N; ++n) {
+            if (n % rstep && n != N - 1) continue;
+            for (int ch = 0; ch < C; ++ch) {
+                double sacc = wobf[ch];
+                for (int i = 0; i < C; ++i) sacc += (double)from_t(ho[((size_t)b * N + n) * C + i], c.dtype) * wof[(size_t)ch * C + i];
+                pref.push_back(sacc); pidx.push_back(((size_t)b * N + n) * C + ch); pmax = std::max(pmax, fabs(sacc));
+            }
+        }
+        double perr = 0; long pnan = 0;
+        for (size_t i = 0; i < pref.size(); ++i) {
+            const double g = from_t(hout[pidx[i]], c.dtype);
+            if (!(g == g)) ++pnan;
+            perr = std::max(perr, fabs(g - pref[i]) / (fabs(pref[i]) + pmax / 64));
+        }
+        const bool okp = r1 == 0 && r2 == 0 && pnan == 0 && perr <= 1.5 * ulp;
+        printf("%s %-30s attention + to_out in one launch: max err %.2f half-spacings vs the fp64 projection of the two-launch O (%zu samples, nan=%ld, rc %d %d%s%s)\n",
+               okp ? "PASS" : "FAIL", c.name, perr / ulp, pref.size(), pnan, r1, r2, r2 ? " " : "", r2 ? pww_last_error() : "");
+        if (!okp) g_fail++;
+        (void)hipFree(dwo); (void)hipFree(dwob);
+    }
     if (timing && g_timeline) {
         std::vector<float> g2(B, 1.f); if (B > 1) for (int b = B / 2; b < B; ++b) g2[b] = 0.f;
         HIPCHECK(hipMemcpy(dgate, g2.data(), B * 4, hipMemcpyHostToDevice));
