@@ -3,6 +3,7 @@
 #   native     tests/native/attn_check --quick (PASS count, FAIL lines) + TIME lines of the product shapes
 #   small      tools/time_small_attn.py under the library variants (one process per PWW_DEBUG setting)
 #   timeline   phase time stamps of the small launches
+#   outproj    row f-1: tests, timing table and in-kernel time line of pww_cross_attn_fwd_parts_out
 #   subset     the GPU tests that touch the attention path
 #   pytest     the whole GPU suite
 #   bench      python bench.py (short) -> r5_bench.json
@@ -22,6 +23,12 @@ small)
   for v in "" "cross_lean=0"; do PWW_DEBUG="$v" timeout 300 python tools/time_small_attn.py cross --out $O/r5_small.md 2>&1 | grep -v amdgpu.ids | tail -6; done
   for v in "" "attn_ksplit1=1"; do PWW_DEBUG="$v" timeout 300 python tools/time_small_attn.py self --out $O/r5_small.md 2>&1 | grep -v amdgpu.ids | tail -6; done
   timeout 300 python tools/time_small_attn.py toout --out $O/r5_small.md 2>&1 | grep -v amdgpu.ids | tail -6
+  ;;
+outproj)
+  # row f-1: attention + to_out in one launch against the two-launch route (profiles/r05_to_out_epilogue.md)
+  timeout 300 python -m pytest tests/test_round5_gpu.py -m gpu -q -k "to_out" 2>&1 | tail -3
+  timeout 300 python tools/time_small_attn.py outproj --out $O/r5_outproj.md 2>&1 | grep -v amdgpu.ids | tail -8
+  timeout 120 python tools/timeline_out.py 2 8 16 2>&1 | grep TIMELINE | tee $O/r5_outproj_timeline.log
   ;;
 timeline)
   (cd tests/native && for c in qproj_sd15_n256_b2 qproj_sd15_n4096_b2; do timeout 120 ./attn_check --timeline --only $c 2>&1 | grep "^TIMELINE"; done; for c in sd15_self_n1024_d80 sd15_self_n256_d160; do timeout 120 ./attn_check --timeline --only $c 2>&1 | grep "^TIMELINE"; done) > $O/r5_timeline.log 2>&1; tail -60 $O/r5_timeline.log | cut -c1-200
