@@ -773,7 +773,7 @@ def main():
                                   "avg_us_back_to_back_graph_replay": round(us_b2b, 2), "avg_us_event_bracket_eager": round(us_situ, 2),
                                   "launches": n_launch, "flops_per_launch": flops}
         # counters measured NOW: a kernel change that doubles the traffic shows in the driver's own line
-        if us and not args.no_live_counters and not args.live_traffic and not args.tiny:
+        if us and world == 1 and not args.no_live_counters and not args.live_traffic and not args.tiny:      # (N > 1: the labelled constant; the scaling runs need no second profiler process next to seven other ranks)
             t_pmc = time.perf_counter()
             case = HARNESS_CASES.get((n_dom, d, b_rows, cfg["dtype"]))
             live = live_counters(case, ["attn_fwd"]) if case else None
