@@ -34,11 +34,16 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
   "kernels"      the same pass's table for EVERY pww launch class: average duration, algorithmic TFLOP/s and GB/s,
                  bounding roofline and fraction; plus a hot-logit run of the dominant shape;
   "cpu_baseline" the CPU oracle (port of the reference path) timed on this box's host cores on a bounded sample
-                 (rank 0, N=1 only): torch thread counts 8 / 16 / 32 / 64 / 128 are swept on one UNet forward each and the
+                 (rank 0, N=1 only): torch thread counts 8 / 16 / 32 / 64 / 128 are swept (median of three UNet forwards each) and the
                  BEST one is used for the timed denoise step(s) -- the 256-vCPU bench box is slower oversubscribed --, with the
                  AST-loaded reference's own timing from the build box beside it (`host`: gpu_box_port / build_box_reference);
-  "config"       the workload, plus block_norms_calls (fused / declined calls of the block plug; the run asserts hit rate
-                 1.0), per_rank (every rank's seconds and images/s), the weight / request broadcast seconds.
+  "parity"       rel-L2 of THIS run's final latents of global step 0 (its first warm-up step: the timed configuration itself -- hipGraph,
+                 channels_last, MIOpen find mode) against the committed fixture of the workload under tests/golden/ (final latents of the
+                 reference's own loop, fp32 CPU; config 2: the oracle's PLMS loop), with the bar (bf16 5e-2 / fp16 1e-2: BASELINE.md section 4);
+                 the run FAILS above the bar. null when the run is not the fixture's workload (overridden dtype / steps / guidance, --tiny);
+  "config"       the workload, plus block_norms_calls (fused / declined calls of the block plug; the run fails on a hit rate below
+                 1.0), per_rank (every rank's seconds and images/s), shards, warmup_s (N > 1: warmup_s_per_rank -- rank 0 warms up first and
+                 the other ranks adopt its MIOpen user db, `miopen_db`), the weight / request broadcast seconds.
 stdout carries that line and nothing else; the log and whatever the path prints go to stderr.
 
 Test infrastructure used as bench infrastructure (deliberately, so that bench and parity tests see the same inputs):
@@ -89,6 +94,45 @@ CONFIGS = {
     5: dict(model="sd21", size=768, dtype="bf16", scheduler="lms", denoise_steps=30, batch=4, wf="std", kind="txt2img",
             name="BASELINE configs[4]: SD2.1 UNet topology (head dim 64, linear projections) random-init, 768x768, 12-region grid with per-region seeds"),
 }
+
+
+# Final-latent parity of the benchmarked configuration: the fixture of each BASELINE workload under tests/golden/
+# (final latents of the reference's own loop on the same request and seeds, fp32 CPU; config 2: the oracle's PLMS loop -- the reference cannot
+# run PLMS) and which images of global step 0 it holds. The bars are BASELINE.md section 4's: rel-L2 <= 5e-2 (bf16) / 1e-2 (fp16).
+PARITY_FIXTURES = {
+    2: ("loop_sd15_example_plms30_oracle.npz", {0: "latents"}),
+    3: ("loop_sd15_stripes8_lms50.npz", {0: "latents_0"}),          # (image 5 of the fixture has a rotated map: the bench's request is shared)
+    4: ("loop_sd15_inpaint_lms30.npz", {0: "latents_81", 5: "latents_86"}),
+    5: ("loop_sd21_grid768_lms30.npz", {0: "latents_0"}),
+}
+PARITY_BARS = {"bf16": 5e-2, "fp16": 1e-2}
+
+
+def parity_check(args, cfg, lat0, lo):
+    """rel-L2 of this rank's final latents of GLOBAL step 0 (seeds base + global index, the fixture's) against the committed fixture, in the
+    EXACT mode the timed steps run in (hipGraph / channels_last / MIOpen find as selected). `lo` = global index of lat0[0]. None when the run
+    is not the fixture's workload (overridden dtype / scheduler / step count / guidance, 1/8-width model) or holds none of its images."""
+    base = CONFIGS[args.config]
+    if args.tiny or lat0 is None or abs(args.guidance - 7.5) > 1e-9 or any(cfg[k] != base[k] for k in ("dtype", "scheduler", "denoise_steps")):
+        return None
+    name, images = PARITY_FIXTURES[args.config]
+    path = os.path.join(REPO, "tests", "golden", name)
+    if not os.path.isfile(path):
+        return None
+    g = np.load(path)
+    got = lat0.detach().float().cpu().numpy()
+    per_image = {}
+    for gi, key in images.items():
+        if lo <= gi < lo + got.shape[0]:
+            ref = g[key].astype(np.float64)
+            per_image[str(gi)] = float(np.linalg.norm(got[gi - lo:gi - lo + 1].astype(np.float64) - ref) / np.linalg.norm(ref))
+    if not per_image:
+        return None
+    worst = max(per_image.values())
+    bar = args.parity_bar if getattr(args, "parity_bar", None) is not None else PARITY_BARS[cfg["dtype"]]
+    return {"rel_l2": round(worst, 6), "bar": bar, "ok": bool(worst <= bar), "fixture": "tests/golden/" + name, "per_image": {k: round(v, 6) for k, v in per_image.items()},
+            "reference": "oracle PLMS loop (the reference cannot run PLMS), fp32 CPU" if args.config == 2 else "the reference's own loop, fp32 CPU (oracle/make_golden.py)",
+            "mode": "the timed configuration itself: global step 0 (the first warm-up step, or the first timed step with --warmup 0)"}
 
 
 def weight_functions():
@@ -455,7 +499,7 @@ def reference_ops_same_gpu(cfg, tools, request, device, dtype, guidance):
 def cpu_baseline(args, cfg, request):
     """The oracle (CPU port of the reference path, fp32) on the host cores: a bounded sample of the same workload --
     `--cpu-steps` denoise steps (2 UNet forwards each) of the full-size loop at the BEST torch thread count of a sweep
-    (one conditional UNet forward per candidate: 8 / 16 / 32 / 64 / 128 threads, capped by the box)."""
+    (median of three conditional UNet forwards per candidate: 8 / 16 / 32 / 64 / 128 threads, capped by the box)."""
     from oracle import pww_oracle as O
     import pww_cases as cases
     log("cpu baseline: building fp32 UNet")
@@ -479,10 +523,13 @@ def cpu_baseline(args, cfg, request):
         unet(x, t, encoder_hidden_states=cond)                       # one-time costs (primitive creation, page faults) stay out of the sweep
         for n in cands:
             torch.set_num_threads(n)
-            t0 = time.perf_counter()
-            unet(x, t, encoder_hidden_states=cond)
-            sweep[n] = round(time.perf_counter() - t0, 3)
-            log("cpu baseline sweep: %d threads %.2f s per conditional UNet forward" % (n, sweep[n]))
+            ts = []
+            for _ in range(3):        # three forwards per candidate, the median counts (one forward moved the pick -- and the figure by 20 % -- from run to run)
+                t0 = time.perf_counter()
+                unet(x, t, encoder_hidden_states=cond)
+                ts.append(time.perf_counter() - t0)
+            sweep[n] = round(sorted(ts)[1], 3)
+            log("cpu baseline sweep: %d threads %.2f s per conditional UNet forward (median of %s)" % (n, sweep[n], ["%.2f" % v for v in ts]))
         best = min(sweep, key=sweep.get)
         torch.set_num_threads(best)
         times = []
@@ -549,6 +596,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.md section 2 workload number")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default: the workload's)")
+    ap.add_argument("--global-batch", type=int, default=None, help="images per step over ALL ranks (default: --batch x ranks); need not divide by the rank count: "
+                    "the contiguous split gives the first (global batch mod ranks) ranks one image more, a rank without images idles")
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp16"])
     ap.add_argument("--mode", default="graph", choices=["eager", "folded", "graph"])
     ap.add_argument("--scheduler", default=None, choices=["plms", "lms"])
@@ -567,6 +616,8 @@ def main():
                          "batch 8), NCHW for SD2.1 at 768x768 (channels_last measured -6 %% there)")
     ap.add_argument("--no-fused-norm", action="store_true", help="A/B: the UNet blocks' GroupNorm (+ addend, + SiLU) as stock PyTorch ops instead of pww_group_norm_fwd")
     ap.add_argument("--tiny", action="store_true", help="1/8-width stand-in of the workload's topology (tests of the launcher / sharding plumbing on a GPU; the line says so)")
+    ap.add_argument("--parity-bar", type=float, default=None, help="rel-L2 bar of the final-latent parity check (default: BASELINE.md section 4's 5e-2 for bf16, "
+                    "1e-2 for fp16); the run fails above it")
     ap.add_argument("--dump-latents", default=None, metavar="PREFIX", help="save this rank's final latents of the last timed step to PREFIX_rank<r>.npy")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: spawn / rendezvous (gloo) / broadcast a 1/8-width model and the request, print the line with value null")
     args = ap.parse_args()
@@ -575,7 +626,11 @@ def main():
         sys.exit(respawn_under_launcher(args.gpus))
     # stdout carries the ONE JSON line and nothing else: whatever the path prints on its way (the reference's own "Use region based
     # seeding" line of the region-seeded configs, paint_with_words.py:449) goes to stderr with the bench log
-    json_out, sys.stdout = sys.stdout, sys.stderr
+    # -- at the file-descriptor level: gloo and RCCL print their banners from C++ straight to fd 1
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
 
     cfg = dict(CONFIGS[args.config])
     for k_arg, k_cfg in (("batch", "batch"), ("dtype", "dtype"), ("scheduler", "scheduler"), ("denoise_steps", "denoise_steps")):
@@ -624,13 +679,19 @@ def main():
     req_bcast_s = time.time() - t0
     wf = weight_functions()[cfg["wf"]]
     color_map = Image.fromarray(request["rgb"])
-    n_global = cfg["batch"] * world
+    n_global = args.global_batch if args.global_batch is not None else cfg["batch"] * world
+    if n_global < 1:
+        raise SystemExit("--global-batch must be at least 1")
     base_seed = 81 if cfg["kind"] == "inpaint" else 0
+    shards = [pdist.shard_range(n_global, r, world) for r in range(world)]
+    my_lo, my_hi = shards[rank]
 
     def one_step(step_idx):
         """mask build + conditioning + full denoise loop for this rank's images of global step `step_idx`, through the
         public batched entry points."""
         seeds = pdist.image_seeds(base_seed + step_idx * n_global, n_global, rank, world)
+        if not seeds:             # more ranks than images (--global-batch): this rank idles through the step
+            return None
         common = dict(num_inference_steps=cfg["denoise_steps"], guidance_scale=args.guidance, device=str(device), weight_function=wf,
                       preloaded_utils=tools, return_latents=True)
         if cfg["kind"] == "inpaint":
@@ -645,8 +706,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
         "config": {"workload": "%s, %d %s steps (%d UNet evaluations x {cond,uncond}), CFG %.1f, weight function '%s', batch %d per GPU, "
                                "final latent (VAE decode excluded)" % (cfg["name"], cfg["denoise_steps"], cfg["scheduler"].upper(), n_unet_evals,
-                                                                        args.guidance, cfg["wf"], cfg["batch"]),
-                   "baseline_config": args.config, "mode": args.mode, "images_per_step": n_global,
+                                                                        args.guidance, cfg["wf"], my_hi - my_lo),
+                   "baseline_config": args.config, "mode": args.mode, "images_per_step": n_global, "shards": [list(sh) for sh in shards],
                    "stock_op_settings": "MIOpen find mode%s" % (", UNet in channels_last memory format" if channels_last else ""),
                    "parallelism": "image-sharded x%d, no data-path collective" % world, "backend": pdist.backend_name(),
                    "block_norms": "pww_group_norm_fwd (GroupNorm + time-embedding addend + SiLU of the ResnetBlock2D / Transformer2DModel blocks)" if pww_hip.blocks.FUSED_NORM else "stock PyTorch ops",
@@ -659,27 +720,64 @@ def main():
     if args.dry_run:
         pdist.barrier(device)
         result.update({"dry_run": True, "dtype": "fp32", "data": "synthetic (1/8-width model, nothing timed)"})
+        # what every rank would generate in global step 0, gathered from the ranks themselves: image counts and first seeds of a split that need
+        # not be even (--global-batch 8 over 3 ranks: 3 / 3 / 2)
+        mine = pdist.image_seeds(base_seed, n_global, rank, world)
+        result["config"]["per_rank_images"] = [int(v) for v in pdist.all_ranks(len(mine), device)]
+        result["config"]["per_rank_first_seed"] = [int(v) for v in pdist.all_ranks(mine[0] if mine else -1, device)]
         if rank == 0:
             print(json.dumps(result), file=json_out, flush=True)
         if torch.distributed.is_initialized():
             torch.distributed.destroy_process_group()
         return
 
+    def fail_together(message):
+        """Raise on EVERY rank if any rank has a message (a rank that raises alone leaves the others blocked in the next collective)."""
+        bad = pdist.max_over_ranks(1.0 if message else 0.0, device)
+        if bad:
+            raise SystemExit("bench.py: " + (message or "another rank failed its check (see its log)"))
+
     warm_s = []
+    lat0 = None        # this rank's final latents of GLOBAL step 0: what the parity fixtures hold
     pww_hip.blocks.reset_stats()
-    for w in range(args.warmup):
-        t0 = time.perf_counter()
-        one_step(w)
-        torch.cuda.synchronize()
-        warm_s.append(round(time.perf_counter() - t0, 2))
-        log("warmup step", w, "done in %.2f s" % warm_s[-1])
-    result["config"]["warmup_s"] = warm_s      # the first one holds MIOpen's solver search and the ONE hipGraph capture of the geometry
+    # N > 1: rank 0 warms up FIRST (MIOpen's find search for every convolution shape of the UNet: ~25 s), then every other rank copies rank 0's
+    # MIOpen user db into its own (one db directory per local rank, pww_hip.dist.init_from_env) and warms up against the recorded answers
+    # instead of repeating the search N times side by side. One node: the ranks share a file system.
+    staged = world > 1 and args.warmup > 0 and on_gpu and os.environ.get("PWW_MIOPEN_FIND", "1") != "0"
+    db_files = 0
+    for phase in ((0, 1) if staged else (None,)):
+        mine = phase is None or (phase == 0) == (rank == 0)
+        if mine:
+            if phase == 1:
+                db_files = pdist.adopt_miopen_db(0)
+            for w in range(args.warmup):
+                t0 = time.perf_counter()
+                out = one_step(w)
+                torch.cuda.synchronize()
+                warm_s.append(round(time.perf_counter() - t0, 2))
+                log("warmup step", w, "done in %.2f s" % warm_s[-1])
+                if w == 0:
+                    lat0 = out
+        if phase is not None:
+            pdist.barrier(device)
+    # every rank's warm-up seconds (the first holds MIOpen's solver search -- or, on ranks > 0, the look-ups in rank 0's db -- and the ONE
+    # hipGraph capture of the geometry)
+    result["config"]["warmup_s"] = warm_s
+    if world > 1:
+        result["config"]["warmup_s_per_rank"] = [[round(v, 2) for v in row] for row in zip(*[pdist.all_ranks(v, device) for v in warm_s])] if warm_s else []
+        result["config"]["miopen_db"] = {"staged_warmup": bool(staged), "files_adopted_from_rank0": [int(v) for v in pdist.all_ranks(db_files, device)],
+                                         "user_db_path": os.environ.get("MIOPEN_USER_DB_PATH")}
     # what the block plug did with the calls of the warm-up passes (in graph mode: the discovery pass and the capture the timed steps replay).
     # A call the kernels declined ran the stock op: the line must say so, and the default configuration must not have any.
     bst = pww_hip.blocks.stats()
     result["config"]["block_norms_calls"] = bst
-    if pww_hip.blocks.FUSED_NORM and args.warmup > 0 and not args.tiny:
-        assert bst["hit_rate"] == 1.0, "the block plug handed calls to the stock ops: %s" % bst
+    verdict = None
+    if pww_hip.blocks.FUSED_NORM and args.warmup > 0 and not args.tiny and my_hi > my_lo:
+        if bst["hit_rate"] is None:
+            verdict = "the block plug saw no calls in the warm-up (rank %d): is it installed?" % rank
+        elif bst["hit_rate"] != 1.0:
+            verdict = "the block plug handed calls to the stock ops (rank %d): %s" % (rank, bst)
+    fail_together(verdict)
     if args.mode == "graph":
         smp = getattr(unet, "_pww_samplers", {}).get((id(sched), "graph"))
         if smp is not None and smp._graphed is not None:
@@ -688,8 +786,11 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     mono0 = time.monotonic_ns()
+    lat = None
     for s in range(args.steps):
         lat = one_step(args.warmup + s)
+        if args.warmup == 0 and s == 0:
+            lat0 = lat
     pdist.barrier(device)
     torch.cuda.synchronize()
     elapsed_local = time.perf_counter() - t0
@@ -698,8 +799,18 @@ def main():
     log("timed region CLOCK_MONOTONIC ns %d %d" % (mono0, time.monotonic_ns()))      # (tools/rocpd_stats.py --window: the kernels of the timed steps only)
     for smp in getattr(unet, "_pww_samplers", {}).values():
         smp.check_errors()            # fused hand-off time-outs of any timed request (raises; the requests are complete: synchronised above)
-    assert torch.isfinite(lat).all(), "non-finite latents"
-    if args.dump_latents:
+    verdict = None if lat is None or bool(torch.isfinite(lat).all()) else "non-finite latents on rank %d" % rank
+    # final-latent parity of THIS run's configuration against the committed fixture of the workload (rank 0 holds global images 0..: the fixture's)
+    par = parity_check(args, cfg, lat0, my_lo) if rank == 0 else None
+    if par is not None:
+        result["parity"] = par
+        log("parity of the timed configuration: rel-L2 %.3e (bar %.0e) vs %s" % (par["rel_l2"], par["bar"], par["fixture"]))
+        if not par["ok"] and verdict is None:
+            verdict = "final latents of global step 0 are %.3e (rel-L2) away from %s: above the %.0e bar" % (par["rel_l2"], par["fixture"], par["bar"])
+    elif rank == 0:
+        result["parity"] = None       # (not the fixture's workload: overridden dtype / scheduler / steps / guidance, or --tiny)
+    fail_together(verdict)
+    if args.dump_latents and lat is not None:
         np.save("%s_rank%d.npy" % (args.dump_latents, rank), lat.float().cpu().numpy())
     if args.tiny:
         result["data"] = "synthetic (1/8-width model: plumbing test, not a measurement)"
@@ -709,7 +820,7 @@ def main():
     result["ms_per_step"] = round(elapsed / args.steps * 1e3, 2)
     # per-rank view of the same timed region (the line's value is the job's: total images / the slowest rank's time): a rank that lags --
     # a slower box slot, a MIOpen search that did not finish in the warm-up -- shows here instead of hiding behind the max
-    lo_hi = [pdist.shard_range(n_global, r, world) for r in range(world)]
+    lo_hi = shards
     result["config"]["per_rank"] = {"seconds": [round(t, 4) for t in per_rank_s],
                                     "images_per_s": [round(args.steps * (hi - lo) / t, 4) for (lo, hi), t in zip(lo_hi, per_rank_s)]}
 

@@ -344,10 +344,19 @@ int cross_attn_out(const void *q, const void *k, const void *v, void *out, const
     if (!w || !out) { set_error("cross_attn_out: null weight or output"); return PWW_EINVAL; }
     if (int rc = attn_validate(q, k, v, out, bias, d)) return rc;
     if (!bias) { set_error("cross_attn_out: needs the bias map (a bias-free layer keeps pww_attn_fwd + the stock GEMM)"); return PWW_ENOTSUP; }
+    if (stat_kind < PWW_STAT_NONE || stat_kind > PWW_STAT_ABSMAX) { set_error("cross_attn_out: bad statistic selector %d", stat_kind); return PWW_EINVAL; }
     if (stat_kind != PWW_STAT_NONE && !parts) { set_error("cross_attn_out: null partials"); return PWW_EINVAL; }
+    // the same rules as pww_cross_attn_fwd_parts: the partials are addressed through a 32-bit buffer descriptor of nparts * 32 bytes
+    if (stat_kind != PWW_STAT_NONE && (nparts < 1 || (reinterpret_cast<uintptr_t>(parts) & 15) || (long)nparts * 32 >= (1L << 31))) {
+        set_error("cross_attn_out: partials must be 16-byte aligned, 1 <= nparts (got %d)", nparts);
+        return PWW_EINVAL;
+    }
     pww_cross_opts_t o;
     memset(&o, 0, sizeof(o));
-    if (opts) memcpy(&o, opts, opts->size < sizeof(o) ? opts->size : sizeof(o));
+    if (opts) {
+        if (opts->size < 16 || opts->size > sizeof(o)) { set_error("cross_attn_out: pww_cross_opts_t.size = %u is not a known layout", opts->size); return PWW_EINVAL; }
+        memcpy(&o, opts, opts->size);
+    }
     if (o.bias_compact) { set_error("cross_attn_out: the compact bias form is not taken here"); return PWW_ENOTSUP; }
     const int C = d->H * d->D;
     if (!cross_attn_out_supported(d, C, o.bias_cols)) {

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PWW_HIP_LIB", os.path.join(_HERE, "libpww_hip.so"))
 
 PWW_OK, PWW_EINVAL, PWW_ENOTSUP, PWW_EHIP = 0, -22, -95, -5
+MIN_VERSION = 125        # oldest libpww_hip ABI (pww_version(): major * 100 + minor) this package drives
 DTYPE_F16, DTYPE_BF16 = 0, 1
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 ACT_NONE, ACT_SILU = 0, 1
@@ -153,8 +154,9 @@ def load():
                  "pww_cross_attn_fwd_stat_ex", "pww_cross_attn_fwd_fused_ex", "pww_qk_reduce", "pww_mask_build",
                  "pww_mask_build_rgb", "pww_mask_build_f32", "pww_resize_tokens", "pww_gauss_blur", "pww_inpaint_prep", "pww_cfg_combine"):
         getattr(lib, name).restype = ctypes.c_int
-    if lib.pww_version() // 100 != 1 or lib.pww_version() < 125:
-        raise PwwHipError("libpww_hip ABI version %d is not 1.x >= 1.24 (rebuild: python paint-with-words-sd_amd/build.py)" % lib.pww_version())
+    if lib.pww_version() // 100 != 1 or lib.pww_version() < MIN_VERSION:
+        raise PwwHipError("libpww_hip ABI version %d.%02d is not 1.x >= 1.%02d (rebuild: python paint-with-words-sd_amd/build.py)"
+                          % (lib.pww_version() // 100, lib.pww_version() % 100, MIN_VERSION % 100))
     _lib = lib
     return lib
 

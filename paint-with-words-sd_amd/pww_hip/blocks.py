@@ -284,7 +284,11 @@ def _ff_output_linear(ff):
     """The output projection of a diffusers FeedForward `net = [GEGLU, Dropout, Linear]` when the block's tail can run as GEGLU -> one GEMM
     with the residual as its C operand (a dropout that does nothing, a plain biased nn.Linear without hooks), else None."""
     net = getattr(ff, "net", None)
-    if net is None or len(net) != 3 or type(ff).forward is not getattr(type(ff), "forward", None) or "forward" in ff.__dict__:
+    # the stock class only: a subclass (or a patched class) that brings its own `forward` -- LoRA-scaled, chunked -- keeps it
+    if net is None or len(net) != 3 or type(ff).__name__ != "FeedForward" or "forward" in ff.__dict__:
+        return None
+    owner = next((c for c in type(ff).__mro__ if "forward" in c.__dict__), None)
+    if owner is None or owner.__name__ != "FeedForward":
         return None
     act, drop, lin = net[0], net[1], net[2]
     if act.__class__.__name__ != "GEGLU" or not isinstance(drop, nn.Dropout) or (drop.training and drop.p > 0):

@@ -62,6 +62,36 @@ def init_from_env(device_type="cuda"):
     return rank, world, local
 
 
+def miopen_db_path(local_rank):
+    """The MIOpen user-db directory init_from_env gives local rank `local_rank` of a multi-rank job (None when the user set
+    MIOPEN_USER_DB_PATH themselves: every rank then shares that one)."""
+    own = os.environ.get("MIOPEN_USER_DB_PATH")
+    if own and os.path.basename(os.path.normpath(own)).startswith("pww_rank"):
+        return os.path.join(os.path.dirname(os.path.normpath(own)), "pww_rank%d" % local_rank)
+    return None
+
+
+def adopt_miopen_db(src_local_rank=0):
+    """Copy local rank `src_local_rank`'s MIOpen user db (find-db and perf-db records of its warm-up) into this rank's own directory: the
+    convolutions of this rank's warm-up then find their answers on disk instead of repeating the find-mode search (~25 s for the SD1.5
+    UNet) on every rank of the node. Call it BEFORE this process's first convolution and after a barrier behind the source rank's warm-up.
+    Same node only (a shared file system is assumed); returns the number of files copied (0: nothing to adopt, the rank searches itself)."""
+    import shutil
+    src, dst = miopen_db_path(src_local_rank), os.environ.get("MIOPEN_USER_DB_PATH")
+    if not src or not dst or not os.path.isdir(src) or os.path.normpath(src) == os.path.normpath(dst):
+        return 0
+    n = 0
+    for name in os.listdir(src):
+        f = os.path.join(src, name)
+        if os.path.isfile(f) and not name.endswith(".lock"):
+            try:
+                shutil.copy2(f, os.path.join(dst, name))
+                n += 1
+            except OSError:
+                pass
+    return n
+
+
 def backend_name():
     """"nccl" (= RCCL on ROCm) / "gloo" of the default process group, or "none" without one."""
     return dist.get_backend() if (dist.is_available() and dist.is_initialized()) else "none"

@@ -260,7 +260,16 @@ def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None, scra
                     bias_coeff = bias_coeff.expand(B).contiguous()
                 if bias_coeff.numel() != B:
                     raise PwwHipError("bias_coeff must have B=%d elements" % B)
-            if stat is not None and stat[0] is None and scratch is None:
+            if stat is not None and stat[0] is None and stat[1] == STAT_NONE and parts is None and M > FUSED_MAX_KEYS:
+                # a statistic-free weight function over a context longer than one K/V stage: nothing to fold, nothing to form -- the
+                # general launch (no key limit) with its scalar (or the hipGraph mode's device word) as the coefficient
+                _, kind, scalar = stat
+                op = _cross_opts(B, N, coeff_dev, 0, None, [])
+                rc = lib.pww_cross_attn_fwd_stat_ex(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(bias), None, int(STAT_NONE),
+                                                    float(heads * N * M), float(scalar), _ptr(bias_coeff), ctypes.byref(d),
+                                                    ctypes.byref(op) if op is not None else None, _stream())
+                _lib.check(rc, "pww_cross_attn_fwd_stat_ex")
+            elif stat is not None and stat[0] is None and scratch is None:
                 # pass-2-only launch: the statistic's partials came from qproj_stat / qk_parts (none needed for STAT_NONE); nothing in it
                 # waits for another workgroup
                 _, kind, scalar = stat
@@ -269,7 +278,8 @@ def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None, scra
                 if parts is not None and (parts.dtype != torch.float64 or parts.dim() != 3 or parts.shape[0] != B or parts.shape[2] != 4 or not parts.is_contiguous()):
                     raise PwwHipError("parts must be a contiguous float64 [B, nparts, 4] tensor")
                 if M > FUSED_MAX_KEYS:
-                    raise PwwHipError("the pass-2-only cross-attention launch takes at most %d keys" % FUSED_MAX_KEYS)
+                    raise PwwHipError("the pass-2-only cross-attention launch takes at most %d keys (partials over more keys: fold them with "
+                                      "fold_parts and pass stat=(stats, kind, scalar))" % FUSED_MAX_KEYS)
                 if stats_out is not None and (stats_out.dtype != torch.float64 or tuple(stats_out.shape) != (B, 4) or not stats_out.is_contiguous()):
                     raise PwwHipError("stats_out must be a contiguous float64 [B, 4] tensor")
                 keep = []

@@ -430,6 +430,71 @@ def test_bench_spawns_its_own_ranks_dry_run(gpus, tmp_path):
         assert out.returncode != 0 and "needs a HIP device" in (out.stderr + out.stdout)
 
 
+def test_bench_uneven_split_dry_run(tmp_path):
+    """a global batch that does not divide by the rank count. `bench.py --dry-run --gpus 3 --global-batch 8`:
+    three gloo ranks report -- each for itself, gathered -- 3 / 3 / 2 images and first seeds 0 / 3 / 6 (contiguous split, seeds by global
+    index); stdout carries the ONE json line even though gloo prints its banners from C++ (fd 1 is redirected at the descriptor level)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PWW_BENCH_VERBOSE="0", PWW_MIOPEN_DB_BASE=str(tmp_path / "miopen"))
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("MIOPEN_USER_DB_PATH", None)
+    out = subprocess.run([sys.executable, os.path.join(cases.REPO, "bench.py"), "--gpus", "3", "--global-batch", "8", "--dry-run"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout)                       # nothing but the line
+    assert rec["n_gpus"] == 3 and rec["config"]["images_per_step"] == 8
+    assert rec["config"]["shards"] == [[0, 3], [3, 6], [6, 8]]
+    assert rec["config"]["per_rank_images"] == [3, 3, 2] and rec["config"]["per_rank_first_seed"] == [0, 3, 6]
+
+
+def test_adopt_miopen_db(tmp_path, monkeypatch):
+    """bench.py --gpus N: rank 0 warms up first, the other ranks copy its MIOpen user db into their own directory before their first
+    convolution (pww_hip.dist.adopt_miopen_db): files are copied, lock files are not, a user-chosen MIOPEN_USER_DB_PATH is left alone."""
+    from pww_hip import dist as pdist
+    base = tmp_path / "miopen"
+    (base / "pww_rank0").mkdir(parents=True), (base / "pww_rank1").mkdir()
+    (base / "pww_rank0" / "gfx950_256.HIP.ufdb.txt").write_text("record")
+    (base / "pww_rank0" / "gfx950_256.HIP.udb.txt").write_text("perf")
+    (base / "pww_rank0" / "gfx950_256.HIP.ufdb.txt.lock").write_text("")
+    monkeypatch.setenv("MIOPEN_USER_DB_PATH", str(base / "pww_rank1"))
+    assert pdist.miopen_db_path(0) == str(base / "pww_rank0")
+    assert pdist.adopt_miopen_db(0) == 2
+    assert sorted(os.listdir(base / "pww_rank1")) == ["gfx950_256.HIP.udb.txt", "gfx950_256.HIP.ufdb.txt"]
+    assert (base / "pww_rank1" / "gfx950_256.HIP.ufdb.txt").read_text() == "record"
+    monkeypatch.setenv("MIOPEN_USER_DB_PATH", str(base / "pww_rank0"))
+    assert pdist.adopt_miopen_db(0) == 0                                   # the source rank itself
+    monkeypatch.setenv("MIOPEN_USER_DB_PATH", str(tmp_path / "users_own"))
+    assert pdist.miopen_db_path(0) is None and pdist.adopt_miopen_db(0) == 0
+
+
+def test_bench_parity_check_helper():
+    """bench.py's `parity` object: the fixture itself passes with rel-L2 0, a perturbed latent fails above the bar,
+    a run that is not the fixture's workload (other step count, --tiny) reports None, and only the images a rank holds are compared."""
+    import argparse
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pww_bench", os.path.join(cases.REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    args = argparse.Namespace(config=2, tiny=False, guidance=7.5)
+    cfg = dict(bench.CONFIGS[2])
+    g = np.load(os.path.join(cases.GOLDEN, "loop_sd15_example_plms30_oracle.npz"))
+    lat = torch.from_numpy(g["latents"])
+    par = bench.parity_check(args, cfg, lat, 0)
+    assert par["ok"] and par["rel_l2"] == 0.0 and par["bar"] == 5e-2 and par["fixture"].endswith("loop_sd15_example_plms30_oracle.npz")
+    bad = bench.parity_check(args, cfg, lat * 1.1, 0)
+    assert not bad["ok"] and abs(bad["rel_l2"] - 0.1) < 1e-3
+    assert bench.parity_check(args, dict(cfg, denoise_steps=4), lat, 0) is None
+    assert bench.parity_check(argparse.Namespace(config=2, tiny=True, guidance=7.5), cfg, lat, 0) is None
+    assert bench.parity_check(args, cfg, lat, 1) is None                     # this rank's shard starts behind the fixture's image
+    # config 4: images 0 and 5 of the rank's eight (seeds 81, 86); fp16 config 3: the 1e-2 bar
+    g4 = np.load(os.path.join(cases.GOLDEN, "loop_sd15_inpaint_lms30.npz"))
+    lat4 = torch.zeros(8, 4, 64, 64)
+    lat4[0], lat4[5] = torch.from_numpy(g4["latents_81"][0]), torch.from_numpy(g4["latents_86"][0])
+    par4 = bench.parity_check(argparse.Namespace(config=4, tiny=False, guidance=7.5), dict(bench.CONFIGS[4]), lat4, 0)
+    assert par4["ok"] and sorted(par4["per_image"]) == ["0", "5"]
+    assert bench.PARITY_BARS == {"bf16": 5e-2, "fp16": 1e-2} and sorted(bench.PARITY_FIXTURES) == [2, 3, 4, 5]
+
+
 def test_bench_workloads_build():
     """Every BASELINE workload of bench.py builds its request (arrays + color_context + prompt) and names its phrases."""
     import importlib.util

@@ -1,0 +1,108 @@
+"""Round-6 GPU tests.
+  * the configuration bench.py TIMES (hipGraph + channels_last + MIOpen find mode) carries a final-latent check of its
+    own -- bench.py's `parity` object -- and it holds for configs 2 and 4 against the committed fixtures of the reference's loop;
+  * item 7a: with two ranks rank 0 warms up first and rank 1 adopts its MIOpen user db;
+  * a statistic-free weight function over a context of more than 128 tokens in hipGraph mode (device coefficient word).
+"""
+import json
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import pww_cases as cases
+from oracle import pww_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_bench(args, env_extra=None, timeout=1500):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PWW_BENCH_VERBOSE="0")
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(cases.REPO, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=cases.REPO)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads(out.stdout)            # stdout carries the line and nothing else
+
+
+# drift of the unfused half-precision torch path on the same GPU: the calibrated bar of every loop test is 1.5 x that + 2e-3
+UNFUSED_DRIFT = {2: 8.3e-3, 4: 1.11e-2}
+
+
+@pytest.mark.parametrize("config", [2, 4])
+def test_bench_parity_in_the_timed_configuration(gpu_device, config):
+    """bench.py --config {2, 4} exactly as the driver times it -- hipGraph mode, UNet in channels_last, MIOpen find mode ON (the test suite's
+    other loop tests run immediate mode and NCHW) -- one warm-up step (global step 0 = the fixture's seeds) and one timed step: the line's
+    `parity` holds the rel-L2 of the warm-up step's final latents against the reference-loop fixture, inside BASELINE.md's bar AND inside
+    the calibrated bar of the NCHW loop tests (1.5 x the unfused torch path's drift + 2e-3)."""
+    line = _run_bench(["--config", str(config), "--steps", "1", "--warmup", "1", "--no-roofline-pass", "--no-reference-ops", "--cpu-steps", "0"],
+                      env_extra={"PWW_MIOPEN_FIND": "1"})
+    par = line["parity"]
+    print("bench.py --config %d parity: %s" % (config, par))
+    assert "MIOpen find mode" in line["config"]["stock_op_settings"] and "channels_last" in line["config"]["stock_op_settings"]
+    assert line["config"]["mode"] == "graph" and line["config"]["hipgraph_captures"] == 1
+    assert par is not None and par["ok"] and par["bar"] == 5e-2
+    assert par["rel_l2"] <= 1.5 * UNFUSED_DRIFT[config] + 2e-3
+    assert sorted(par["per_image"]) == (["0"] if config == 2 else ["0", "5"])
+
+
+def test_bench_fails_above_the_parity_bar(gpu_device):
+    """The run FAILS -- non-zero exit, no json line -- when the final latents leave the bar (here: a bar no half-precision run can meet)."""
+    env = dict(os.environ, PWW_BENCH_VERBOSE="0", PWW_MIOPEN_FIND="0")
+    out = subprocess.run([sys.executable, os.path.join(cases.REPO, "bench.py"), "--steps", "1", "--warmup", "1", "--no-roofline-pass", "--no-reference-ops",
+                          "--cpu-steps", "0", "--parity-bar", "1e-6"], capture_output=True, text=True, timeout=900, env=env, cwd=cases.REPO)
+    assert out.returncode != 0 and out.stdout.strip() == ""
+    assert "above the 1e-06 bar" in out.stderr
+
+
+def test_two_ranks_stage_their_warmup(gpu_device, tmp_path):
+    """bench.py --gpus 2 (two ranks sharing this GPU over gloo, 1/8-width model, MIOpen find mode on): rank 0 warms up first, rank 1 adopts
+    its MIOpen user db before its own first convolution; the line carries every rank's warm-up seconds and the files adopted."""
+    line = _run_bench(["--gpus", "2", "--config", "3", "--batch", "1", "--denoise-steps", "2", "--steps", "1", "--warmup", "1", "--no-roofline-pass",
+                       "--no-reference-ops", "--cpu-steps", "0", "--tiny"],
+                      env_extra={"PWW_DIST_ONE_DEVICE": "1", "PWW_MIOPEN_FIND": "1", "PWW_MIOPEN_DB_BASE": str(tmp_path / "miopen")})
+    db = line["config"]["miopen_db"]
+    print("staged warm-up:", db, line["config"]["warmup_s_per_rank"])
+    assert db["staged_warmup"] is True and db["files_adopted_from_rank0"][0] == 0 and db["files_adopted_from_rank0"][1] >= 1
+    assert len(line["config"]["warmup_s_per_rank"]) == 2 and len(line["config"]["warmup_s_per_rank"][0]) == 1
+    assert line["parity"] is None                   # (--tiny is not the fixture's workload)
+    r0, r1 = (set(os.listdir(tmp_path / "miopen" / ("pww_rank%d" % r))) for r in (0, 1))
+    assert {f for f in r0 if not f.endswith(".lock")} <= r1
+
+
+# ---- stat = (None, STAT_NONE, c) with M > 128 ------------------------------------------------------------------
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_stat_free_weight_function_long_context(gpu_device, dtype):
+    """A statistic-free weight function (0.4 w log(1 + sigma)) over a 154-token context with the hipGraph mode's device coefficient word:
+    attention.py hands ops.attention stat = (None, STAT_NONE, c) without scratch or partials. Round 5's dispatch sent that to the
+    pass-2-only launch (<= 128 keys) and raised; it belongs on the general launch (no key limit)."""
+    from pww_hip import ops
+    B, N, H, D, M = 2, 256, 8, 40, 154
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(B, N, H * D, generator=g).to(dtype)
+    k = torch.randn(1, M, H * D, generator=g).to(dtype)
+    v = torch.randn(1, M, H * D, generator=g).to(dtype)
+    w = (torch.rand(N, M, generator=g) < 0.2).float() * torch.rand(N, M, generator=g)
+    gate = torch.tensor([1.0, 0.0])
+    c = 0.4 * math.log(1 + 7.84)
+    dev = gpu_device
+    coeff_dev = torch.tensor([c], dtype=torch.float32, device=dev)
+    out = ops.attention(q.to(dev), k.to(dev), v.to(dev), H, D ** -0.5, bias=w.to(dev), bias_coeff=gate.to(dev), stat=(None, ops.STAT_NONE, 123.0),
+                        coeff_dev=coeff_dev).float().cpu()
+    out_scalar = ops.attention(q.to(dev), k.to(dev), v.to(dev), H, D ** -0.5, bias=w.to(dev), bias_coeff=gate.to(dev), stat=(None, ops.STAT_NONE, c)).float().cpu()
+    qh, kh, vh = (O.split_heads(t.double(), H) for t in (q, k.expand(B, -1, -1), v.expand(B, -1, -1)))
+    logits = torch.matmul(qh, kh.transpose(-1, -2)).view(B, H, N, M) + (c * gate.double())[:, None, None, None] * w.double()[None, None]
+    ref = O.merge_heads(torch.matmul((logits * D ** -0.5).softmax(-1).view(B * H, N, M), vh), H)
+    tol = 2e-3 if dtype == torch.float16 else 1.6e-2
+    for name, o in (("device word", out), ("scalar", out_scalar)):
+        err = (o.double() - ref).abs().max().item() / ref.abs().max().item()
+        print(f"stat-free weight function, M = {M}, {dtype}, coefficient from the {name}: max err / max|O| = {err:.3e}")
+        assert err <= tol
+    # with partials the pass-2-only launch still says what it takes
+    with pytest.raises(ops.PwwHipError):
+        ops.attention(q.to(dev), k.to(dev), v.to(dev), H, D ** -0.5, bias=w.to(dev), stat=(None, ops.STAT_MAX, c),
+                      parts=torch.zeros(B, 4, 4, dtype=torch.float64, device=dev))
