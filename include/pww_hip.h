@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define PWW_VERSION 125 /* 0.1.25: pww_cross_attn_fwd_parts_out / pww_cross_attn_out_supported (the C = 320 cross-attention layers with to_out + bias [+ residual] in the attention launch); 0.1.24: pww_qk_parts / pww_qk_parts_count (statistic partials over a finished Q; pww_cross_attn_fwd_parts takes the small one-block-per-workgroup kernel where it fits); 0.1.23: pww_group_norm_fwd / pww_group_norm_workspace_bytes, pww_add_layer_norm, pww_geglu, pww_bias_residual (norms and elementwise glue of the blocks that call the attention path); 0.1.22: pww_qproj_stat / pww_qproj_parts / pww_cross_attn_fwd_parts (score statistic formed in the to_q GEMM's epilogue), pww_mask_build_f32_levels, PWW_STAT_ALL; 0.1.21: pww_cross_opts_t.gated_images (was padding); 0.1.20: + pww_cross_attn_fwd_fused_ex / pww_cross_attn_fwd_stat_ex (pww_cross_opts_t: device-side coefficient word, bias column bound,
+#define PWW_VERSION 126 /* 0.1.26: the forms that were measured and not made a default moved to libpww_hip_experiments.so (section "experiments" below: pww_cross_attn_fwd_fused[_ex], pww_cross_fused_*_bytes, pww_cross_attn_fwd_parts_out, pww_cross_attn_out_supported); pww_has_experiments; 0.1.25: pww_cross_attn_fwd_parts_out / pww_cross_attn_out_supported (the C = 320 cross-attention layers with to_out + bias [+ residual] in the attention launch); 0.1.24: pww_qk_parts / pww_qk_parts_count (statistic partials over a finished Q; pww_cross_attn_fwd_parts takes the small one-block-per-workgroup kernel where it fits); 0.1.23: pww_group_norm_fwd / pww_group_norm_workspace_bytes, pww_add_layer_norm, pww_geglu, pww_bias_residual (norms and elementwise glue of the blocks that call the attention path); 0.1.22: pww_qproj_stat / pww_qproj_parts / pww_cross_attn_fwd_parts (score statistic formed in the to_q GEMM's epilogue), pww_mask_build_f32_levels, PWW_STAT_ALL; 0.1.21: pww_cross_opts_t.gated_images (was padding); 0.1.20: + pww_cross_attn_fwd_fused_ex / pww_cross_attn_fwd_stat_ex (pww_cross_opts_t: device-side coefficient word, bias column bound,
                            compact bias), pww_debug_timeline (0.1.11: pww_profile_*; 0.1.10: fused cross-attention, blur, resize, inpaint prep) */
 
 #define PWW_OK 0
@@ -83,6 +83,8 @@ typedef struct pww_attn_desc {
 
 /* ABI version (PWW_VERSION of the built library). */
 int pww_version(void);
+/* 1 in libpww_hip_experiments.so (section "experiments" at the end of this file), 0 in libpww_hip.so (version >= 126). */
+int pww_has_experiments(void);
 
 /* Description of the last error on this thread ("" if none). */
 const char *pww_last_error(void);
@@ -135,36 +137,6 @@ int pww_cross_attn_fwd_stat(const void *q, const void *k, const void *v, void *o
                             const float *gate, const pww_attn_desc_t *desc, void *stream);
 
 /*
- * pww_qk_reduce + pww_cross_attn_fwd_stat as ONE launch, for cross-attention over at most 128 keys (the 77 prompt
- * tokens): the cond branch of inj_forward (paint_with_words.py:87-116) for weight functions of the form
- * c0 * w * g(sigma) * reduce(qk). Every workgroup reduces its score tiles and publishes one partial per query block
- * in `state`; the workgroups of an image re-read those slots until none is empty, fold them (agent-scope atomics on
- * both sides, no fence, no counter on the critical path) and carry on with bias -> softmax -> PV. Output and
- * statistics are bit-identical to the two-launch path.
- *   bias        fp32 map, required (desc->bias_stride)
- *   stat_kind   PWW_STAT_*; PWW_STAT_NONE gives c[b] = coeff_scalar * gate[b] with no hand-off at all
- *   gate        fp32 [B] device array or NULL; images with gate[b] == 0 (the unconditional rows of a CFG-folded batch)
- *               get no bias and take no part in the reduction
- *   stats_out   optional double [B][4] (device): { max, min, sum, sum of squares } of the gated-in images
- *   state       device buffer of pww_cross_fused_state_bytes(desc) bytes, 8-byte aligned, owned by the caller and
- *               ZERO before the first call. The kernel leaves it zero again (the last workgroup of an image to leave
- *               clears the image's words), so one buffer serves any number of calls -- of any shape it is large enough
- *               for -- issued on ONE stream, hipGraph replays included; calls that may overlap on different streams
- *               need a buffer each. Word B*H + B is an error flag: it becomes 1 if a hand-off ever timed out (1 s;
- *               the affected outputs are NaN) -- re-zero the buffer then.
- *   workspace   caller-owned scratch, pww_cross_fused_workspace_bytes(desc) bytes, 8-byte aligned, uninitialised;
- *               only touched by the two-launch path below
- * The launch is sized to be fully resident (<= 2 workgroups per CU, several query blocks per workgroup for large
- * batches); if B*H alone exceeds that, the call issues the two launches instead.
- */
-int pww_cross_attn_fwd_fused(const void *q, const void *k, const void *v, void *o, const float *bias,
-                             int32_t stat_kind, float coeff_scalar, const float *gate, const pww_attn_desc_t *desc,
-                             double *stats_out, void *state, size_t state_bytes, void *workspace, size_t workspace_bytes,
-                             void *stream);
-size_t pww_cross_fused_state_bytes(const pww_attn_desc_t *desc);
-size_t pww_cross_fused_workspace_bytes(const pww_attn_desc_t *desc);
-
-/*
  * Optional arguments of the *_ex cross-attention entry points. Zero-initialise, then set `size = sizeof(pww_cross_opts_t)`
  * (fields added by later versions are appended; a library accepts every size it knows).
  *   coeff_scalar_dev  device word that REPLACES the by-value `coeff_scalar` argument; it is read when the kernel RUNS, so one
@@ -200,12 +172,8 @@ typedef struct pww_cross_opts {
     int64_t col_idx_stride;      /* image (elements) */
 } pww_cross_opts_t;
 
-/* pww_cross_attn_fwd_fused / pww_cross_attn_fwd_stat with the optional arguments above (opts == NULL: identical to the plain forms).
-   pww_cross_attn_fwd_stat_ex reads coeff_scalar_dev only; the other fields concern the fused kernel's LDS bias tile. */
-int pww_cross_attn_fwd_fused_ex(const void *q, const void *k, const void *v, void *o, const float *bias,
-                                int32_t stat_kind, float coeff_scalar, const float *gate, const pww_attn_desc_t *desc,
-                                double *stats_out, void *state, size_t state_bytes, void *workspace, size_t workspace_bytes,
-                                const pww_cross_opts_t *opts, void *stream);
+/* pww_cross_attn_fwd_stat with the optional arguments above (opts == NULL: identical to the plain form): reads coeff_scalar_dev only; the
+   other fields concern the LDS bias tile of pww_cross_attn_fwd_parts (and of pww_cross_attn_fwd_fused_ex, section "experiments"). */
 int pww_cross_attn_fwd_stat_ex(const void *q, const void *k, const void *v, void *o, const float *bias,
                                const double *stats, int32_t stat_kind, double stat_count, float coeff_scalar,
                                const float *gate, const pww_attn_desc_t *desc, const pww_cross_opts_t *opts, void *stream);
@@ -273,29 +241,6 @@ int pww_cross_attn_fwd_parts(const void *q, const void *k, const void *v, void *
 int pww_qk_parts(const void *q, const void *k, const float *gate, const pww_attn_desc_t *desc, int32_t stat_kind, int32_t gated_images,
                  double *partials, size_t partials_bytes, void *stream);
 int32_t pww_qk_parts_count(const pww_attn_desc_t *desc);
-
-/*
- * pww_cross_attn_fwd_parts WITH the layer's output projection in the launch (version >= 125; SURVEY.md section 8 row f-1):
- *     out[b][n][:] = to_out[0]( merge_heads(O) )[b][n][:] (+ residual[b][n][:])        paint_with_words.py:118-123
- *       = sum over heads h of  W[:, h*D .. h*D+D) . O_h[b][n][:]  + w_bias
- * One workgroup owns 128 query rows of an image and walks ALL heads (O_h is rounded to the storage type where the two-launch path stores
- * it, then multiplied from registers; the sum over heads and the bias add run in fp32, one rounding; the residual add is a second
- * rounding, like the stock `linear(...) + residual`). O is never written. Differences to pww_cross_attn_fwd_parts + a library GEMM: the
- * fp32 summation order of the 320-term dot products (results agree to the last bit or two of the storage type).
- *   out        [B][N][C]   addressed out + b*desc->o_stride[0] + n*desc->o_stride[2] + c   (o_stride[1] is not read), 16-byte aligned rows
- *   w          [C][H*D]    row-major nn.Linear weight (contiguous), storage type of q;  w_bias [C] same type, or NULL
- *   residual   [B][N][C]   same type or NULL;  residual_stride = { b, n } in elements (read only with a residual)
- *   bias       required, dense rows (bias_stride[3] == 1) shared by the heads (bias_stride[1] == 0), at most 64 non-zero columns
- *              (opts->bias_cols or M <= 64)
- * Supported (pww_cross_attn_out_supported returns 1): C = H*D = 320 with D <= 64 (SD1.5: 8 x 40, SD2.1: 5 x 64), 64 <= M <= 128; anything
- * else returns PWW_ENOTSUP and the caller keeps pww_cross_attn_fwd_parts + its own GEMM. A launch has B * ceil(N / 128) workgroups (heads
- * are sequential inside one): worth taking from ~8 images per launch on, measured slower below (profiles/r05_to_out_epilogue.md).
- */
-int pww_cross_attn_fwd_parts_out(const void *q, const void *k, const void *v, void *out, const float *bias, int32_t stat_kind, float coeff_scalar,
-                                 const float *gate, const pww_attn_desc_t *desc, const double *partials, int32_t nparts, double *stats_out,
-                                 const pww_cross_opts_t *opts, const void *w, const void *w_bias, const void *residual,
-                                 const int64_t *residual_stride, void *stream);
-int32_t pww_cross_attn_out_supported(const pww_attn_desc_t *desc, int32_t c_out, int32_t bias_cols);
 
 /*
  * GroupNorm of the UNet blocks that call the attention path, fused with the elementwise neighbours those callers put around it
@@ -482,6 +427,77 @@ void pww_profile_reset(void);
  * [4] outputs stored, [5] exit; self-attention: [2] key loop done, [3] outputs stored. buf == NULL switches it off (the default).
  */
 void pww_debug_timeline(void *device_buffer, size_t bytes);
+
+/* ================================================================ experiments ================================================================
+ * Entry points of libpww_hip_experiments.so ONLY (version >= 126; `pww_has_experiments()` returns 1 there, 0 in libpww_hip.so). That library
+ * is the product library compiled with -DPWW_EXPERIMENTS=1 (python paint-with-words-sd_amd/build.py --experiments): everything above, plus
+ * the forms that were built, measured on MI355X and NOT made a default -- kept for the tests and the A/B tools, never loaded by the product:
+ *   - round 3's in-launch score statistic (pass 1 + device-scope hand-off between workgroups, spin limit, residency requirement):
+ *     pww_cross_attn_fwd_fused[_ex], pww_cross_fused_state_bytes, pww_cross_fused_workspace_bytes -- superseded by partials formed outside the
+ *     launch (pww_qproj_stat / pww_qk_parts + pww_cross_attn_fwd_parts: no launch waits for another workgroup);
+ *   - round 5's attention + to_out launch: pww_cross_attn_fwd_parts_out, pww_cross_attn_out_supported -- bit-identical to the two-launch
+ *     route, slower at batch 1 and a tie at 16 rows (profiles/r05_to_out_epilogue.md);
+ *   - kernels behind PWW_DEBUG knobs that lost their A/B (single-buffered key-split self-attention, running-maximum forms of the range-free
+ *     launches, 4 x 2 key-split workgroups).
+ * In libpww_hip.so these symbols do not exist. */
+
+/*
+ * pww_qk_reduce + pww_cross_attn_fwd_stat as ONE launch, for cross-attention over at most 128 keys (the 77 prompt
+ * tokens): the cond branch of inj_forward (paint_with_words.py:87-116) for weight functions of the form
+ * c0 * w * g(sigma) * reduce(qk). Every workgroup reduces its score tiles and publishes one partial per query block
+ * in `state`; the workgroups of an image re-read those slots until none is empty, fold them (agent-scope atomics on
+ * both sides, no fence, no counter on the critical path) and carry on with bias -> softmax -> PV. Output and
+ * statistics are bit-identical to the two-launch path.
+ *   bias        fp32 map, required (desc->bias_stride)
+ *   stat_kind   PWW_STAT_*; PWW_STAT_NONE gives c[b] = coeff_scalar * gate[b] with no hand-off at all
+ *   gate        fp32 [B] device array or NULL; images with gate[b] == 0 (the unconditional rows of a CFG-folded batch)
+ *               get no bias and take no part in the reduction
+ *   stats_out   optional double [B][4] (device): { max, min, sum, sum of squares } of the gated-in images
+ *   state       device buffer of pww_cross_fused_state_bytes(desc) bytes, 8-byte aligned, owned by the caller and
+ *               ZERO before the first call. The kernel leaves it zero again (the last workgroup of an image to leave
+ *               clears the image's words), so one buffer serves any number of calls -- of any shape it is large enough
+ *               for -- issued on ONE stream, hipGraph replays included; calls that may overlap on different streams
+ *               need a buffer each. Word B*H + B is an error flag: it becomes 1 if a hand-off ever timed out (1 s;
+ *               the affected outputs are NaN) -- re-zero the buffer then.
+ *   workspace   caller-owned scratch, pww_cross_fused_workspace_bytes(desc) bytes, 8-byte aligned, uninitialised;
+ *               only touched by the two-launch path below
+ * The launch is sized to be fully resident (<= 2 workgroups per CU, several query blocks per workgroup for large
+ * batches); if B*H alone exceeds that, the call issues the two launches instead.
+ */
+int pww_cross_attn_fwd_fused(const void *q, const void *k, const void *v, void *o, const float *bias,
+                             int32_t stat_kind, float coeff_scalar, const float *gate, const pww_attn_desc_t *desc,
+                             double *stats_out, void *state, size_t state_bytes, void *workspace, size_t workspace_bytes,
+                             void *stream);
+size_t pww_cross_fused_state_bytes(const pww_attn_desc_t *desc);
+size_t pww_cross_fused_workspace_bytes(const pww_attn_desc_t *desc);
+
+int pww_cross_attn_fwd_fused_ex(const void *q, const void *k, const void *v, void *o, const float *bias,
+                                int32_t stat_kind, float coeff_scalar, const float *gate, const pww_attn_desc_t *desc,
+                                double *stats_out, void *state, size_t state_bytes, void *workspace, size_t workspace_bytes,
+                                const pww_cross_opts_t *opts, void *stream);
+
+/*
+ * pww_cross_attn_fwd_parts WITH the layer's output projection in the launch (version >= 125; SURVEY.md section 8 row f-1):
+ *     out[b][n][:] = to_out[0]( merge_heads(O) )[b][n][:] (+ residual[b][n][:])        paint_with_words.py:118-123
+ *       = sum over heads h of  W[:, h*D .. h*D+D) . O_h[b][n][:]  + w_bias
+ * One workgroup owns 128 query rows of an image and walks ALL heads (O_h is rounded to the storage type where the two-launch path stores
+ * it, then multiplied from registers; the sum over heads and the bias add run in fp32, one rounding; the residual add is a second
+ * rounding, like the stock `linear(...) + residual`). O is never written. Differences to pww_cross_attn_fwd_parts + a library GEMM: the
+ * fp32 summation order of the 320-term dot products (results agree to the last bit or two of the storage type).
+ *   out        [B][N][C]   addressed out + b*desc->o_stride[0] + n*desc->o_stride[2] + c   (o_stride[1] is not read), 16-byte aligned rows
+ *   w          [C][H*D]    row-major nn.Linear weight (contiguous), storage type of q;  w_bias [C] same type, or NULL
+ *   residual   [B][N][C]   same type or NULL;  residual_stride = { b, n } in elements (read only with a residual)
+ *   bias       required, dense rows (bias_stride[3] == 1) shared by the heads (bias_stride[1] == 0), at most 64 non-zero columns
+ *              (opts->bias_cols or M <= 64)
+ * Supported (pww_cross_attn_out_supported returns 1): C = H*D = 320 with D <= 64 (SD1.5: 8 x 40, SD2.1: 5 x 64), 64 <= M <= 128; anything
+ * else returns PWW_ENOTSUP and the caller keeps pww_cross_attn_fwd_parts + its own GEMM. A launch has B * ceil(N / 128) workgroups (heads
+ * are sequential inside one): worth taking from ~8 images per launch on, measured slower below (profiles/r05_to_out_epilogue.md).
+ */
+int pww_cross_attn_fwd_parts_out(const void *q, const void *k, const void *v, void *out, const float *bias, int32_t stat_kind, float coeff_scalar,
+                                 const float *gate, const pww_attn_desc_t *desc, const double *partials, int32_t nparts, double *stats_out,
+                                 const pww_cross_opts_t *opts, const void *w, const void *w_bias, const void *residual,
+                                 const int64_t *residual_stride, void *stream);
+int32_t pww_cross_attn_out_supported(const pww_attn_desc_t *desc, int32_t c_out, int32_t bias_cols);
 
 #ifdef __cplusplus
 }

@@ -2,6 +2,15 @@
 
 No torch headers are involved: the library is plain HIP behind the C ABI of include/pww_hip.h, and
 is loaded from Python with ctypes (pww_hip/_lib.py). hipcc cross-compiles without a GPU.
+
+Two libraries come out of the same sources:
+  libpww_hip.so               the product: what the default routes and the documented switches call. `build_lib()`, and all that
+                              __graft_entry__.build() compiles.
+  libpww_hip_experiments.so   the same sources with -DPWW_EXPERIMENTS=1 (+ pww_cross_out.hip): the product plus the forms that were built,
+                              measured and not made a default (include/pww_hip.h, section "experiments"). Built by the tests / tools that
+                              need it (`build_experiments()`, `python build.py --experiments`), never loaded by the product.
+The large kernel families are instantiated in slices (one translation unit per storage type, the general cross-attention kernel also per
+workgroup width) so that the compile runs side by side on the build box's cores.
 """
 import os
 import subprocess
@@ -11,8 +20,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "pww_hip", "libpww_hip.so")
-SOURCES = ["pww_api.hip", "pww_attn.hip", "pww_cross.hip", "pww_cross_lean.hip", "pww_cross_out.hip", "pww_reduce.hip", "pww_mask.hip", "pww_qproj.hip", "pww_norm.hip", "pww_blocks.hip"]
-HEADERS = ["pww_common.h", "pww_tile.h", "pww_attn_core.h", "pww_cross_tile.h", os.path.join(REPO, "include", "pww_hip.h")]
+LIB_EXPERIMENTS = os.path.join(HERE, "pww_hip", "libpww_hip_experiments.so")
+# (source, extra defines, object suffix): the instantiation units are compiled once per slice
+UNITS = [("pww_api.hip", [], ""), ("pww_attn.hip", [], ""), ("pww_cross.hip", [], ""), ("pww_cross_lean.hip", [], ""), ("pww_reduce.hip", [], ""),
+         ("pww_mask.hip", [], ""), ("pww_qproj.hip", [], ""), ("pww_norm.hip", [], ""), ("pww_blocks.hip", [], ""),
+         ("pww_attn_inst.hip", ["-DPWW_INST_F16"], ".f16"), ("pww_attn_inst.hip", ["-DPWW_INST_BF16"], ".bf16"),
+         ("pww_cross_inst.hip", ["-DPWW_INST_F16", "-DPWW_INST_NW=2"], ".f16.nw2"), ("pww_cross_inst.hip", ["-DPWW_INST_F16", "-DPWW_INST_NW=4"], ".f16.nw4"),
+         ("pww_cross_inst.hip", ["-DPWW_INST_BF16", "-DPWW_INST_NW=2"], ".bf16.nw2"), ("pww_cross_inst.hip", ["-DPWW_INST_BF16", "-DPWW_INST_NW=4"], ".bf16.nw4")]
+EXPERIMENT_UNITS = [("pww_cross_out.hip", [], "")]      # sources only the experiments library has
+SOURCES = sorted({u[0] for u in UNITS + EXPERIMENT_UNITS})
+HEADERS = ["pww_common.h", "pww_tile.h", "pww_attn_core.h", "pww_attn_kernel.h", "pww_cross_tile.h", "pww_cross_kernel.h", os.path.join(REPO, "include", "pww_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
          "-Wno-unused-function"]
@@ -29,47 +46,75 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_lib(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS] + [__file__]
-    if not force and not _newer(LIB, deps):
-        return LIB
-    objs = []
-    procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
-    for s in srcs:  # compile translation units in parallel
-        o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
-        objs.append(o)
-        cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    for cmd, p in procs:
+def _deps():
+    return ([os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS] + [__file__])
+
+
+def _build(lib, units, defines, objdir, verbose, jobs=None):
+    os.makedirs(objdir, exist_ok=True)
+    # longest compiles first (the general cross-attention slices), at most `jobs` at a time
+    order = sorted(units, key=lambda u: {"pww_cross_inst.hip": 0, "pww_attn_inst.hip": 1, "pww_cross_lean.hip": 2}.get(u[0], 3))
+    jobs = jobs or max(2, min(len(order), (os.cpu_count() or 4)))
+    pending, running, objs = list(order), [], []
+    while pending or running:
+        while pending and len(running) < jobs:
+            src, defs, suffix = pending.pop(0)
+            o = os.path.join(objdir, src + suffix + ".o")
+            objs.append(o)
+            cmd = [HIPCC] + FLAGS + defines + defs + PER_FILE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            running.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        cmd, p = running.pop(0)
         out, _ = p.communicate()
         if p.returncode != 0:
+            for _, q in running:
+                q.kill()
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out))
         if verbose and out.strip():
             print(out)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + sorted(objs) + ["-o", lib], check=True)
+    return lib
+
+
+def build_lib(force=False, verbose=False):
+    """The product library (what __graft_entry__.build() compiles)."""
+    if not force and not _newer(LIB, _deps()):
+        return LIB
+    return _build(LIB, UNITS, [], os.path.join(HERE, "build"), verbose)
+
+
+def build_experiments(force=False, verbose=False):
+    """libpww_hip_experiments.so: the product + the measured-and-not-default forms (tests and tools only)."""
+    if not force and not _newer(LIB_EXPERIMENTS, _deps()):
+        return LIB_EXPERIMENTS
+    return _build(LIB_EXPERIMENTS, UNITS + EXPERIMENT_UNITS, ["-DPWW_EXPERIMENTS=1"], os.path.join(HERE, "build", "experiments"), verbose)
+
+
+def _build_check(exe, lib, libname, defines, force):
+    src = os.path.join(REPO, "tests", "native", "attn_check.cpp")
+    if not force and not _newer(exe, [src, lib, os.path.join(REPO, "include", "pww_hip.h")]):
+        return exe
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17"] + defines + [src, "-o", exe, "-L" + os.path.dirname(lib), "-l" + libname,
+                                                                              "-Wl,-rpath,$ORIGIN/../../paint-with-words-sd_amd/pww_hip"]
     subprocess.run(cmd, check=True)
-    return LIB
+    return exe
 
 
 def build_native_check(force=False):
-    """tests/native/attn_check: C++ harness that drives the C ABI directly (test infrastructure)."""
-    src = os.path.join(REPO, "tests", "native", "attn_check.cpp")
-    exe = os.path.join(REPO, "tests", "native", "attn_check")
-    lib = build_lib()
-    if not force and not _newer(exe, [src, lib, os.path.join(REPO, "include", "pww_hip.h")]):
-        return exe
-    libdir = os.path.dirname(lib)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", src, "-o", exe, "-L" + libdir, "-lpww_hip",
-           "-Wl,-rpath,$ORIGIN/../../paint-with-words-sd_amd/pww_hip"]
-    subprocess.run(cmd, check=True)
-    return exe
+    """tests/native/attn_check: C++ harness that drives the C ABI of the PRODUCT library directly (test infrastructure)."""
+    return _build_check(os.path.join(REPO, "tests", "native", "attn_check"), build_lib(), "pww_hip", [], force)
+
+
+def build_native_check_experiments(force=False):
+    """tests/native/attn_check_experiments: the same harness over libpww_hip_experiments.so, with the cases of the moved entry points."""
+    return _build_check(os.path.join(REPO, "tests", "native", "attn_check_experiments"), build_experiments(), "pww_hip_experiments", ["-DPWW_EXPERIMENTS=1"], force)
 
 
 if __name__ == "__main__":
     force = "--force" in sys.argv
     print(build_lib(force=force, verbose=True))
     print(build_native_check(force=force))
+    if "--experiments" in sys.argv:
+        print(build_experiments(force=force, verbose=True))
+        print(build_native_check_experiments(force=force))

@@ -201,6 +201,7 @@ int bias_residual(const void *r, const void *v, const void *bias, void *y, int32
 extern "C" {
 
 int pww_version(void) { return PWW_VERSION; }
+int pww_has_experiments(void) { return PWW_EXPERIMENTS; }
 
 int pww_profile_arm(void) { return pww::profile_arm(); }
 int pww_profile_elapsed_us(int slot, float *us) { return pww::profile_elapsed_us(slot, us); }
@@ -230,6 +231,7 @@ int pww_cross_attn_fwd_stat(const void *q, const void *k, const void *v, void *o
                          coeff_scalar);
 }
 
+#if PWW_EXPERIMENTS      // libpww_hip_experiments.so only (include/pww_hip.h, "experiments")
 int pww_cross_attn_fwd_fused(const void *q, const void *k, const void *v, void *o, const float *bias, int32_t stat_kind,
                              float coeff_scalar, const float *gate, const pww_attn_desc_t *desc, double *stats_out, void *state,
                              size_t state_bytes, void *workspace, size_t workspace_bytes, void *stream) {
@@ -243,6 +245,7 @@ int pww_cross_attn_fwd_fused_ex(const void *q, const void *k, const void *v, voi
     return pww::cross_attn_fused(q, k, v, o, bias, stat_kind, coeff_scalar, gate, desc, stats_out, state, state_bytes, workspace,
                                  workspace_bytes, opts, static_cast<hipStream_t>(stream));
 }
+#endif
 
 int pww_cross_attn_fwd_stat_ex(const void *q, const void *k, const void *v, void *o, const float *bias,
                                const double *stats, int32_t stat_kind, double stat_count, float coeff_scalar,
@@ -270,6 +273,7 @@ int pww_qk_parts(const void *q, const void *k, const float *gate, const pww_attn
 
 int32_t pww_qk_parts_count(const pww_attn_desc_t *desc) { return pww::qk_parts_count(desc); }
 
+#if PWW_EXPERIMENTS
 int pww_cross_attn_fwd_parts_out(const void *q, const void *k, const void *v, void *out, const float *bias, int32_t stat_kind, float coeff_scalar,
                                  const float *gate, const pww_attn_desc_t *desc, const double *partials, int32_t nparts, double *stats_out,
                                  const pww_cross_opts_t *opts, const void *w, const void *w_bias, const void *residual,
@@ -281,6 +285,7 @@ int pww_cross_attn_fwd_parts_out(const void *q, const void *k, const void *v, vo
 int32_t pww_cross_attn_out_supported(const pww_attn_desc_t *desc, int32_t c_out, int32_t bias_cols) {
     return pww::cross_attn_out_supported(desc, c_out, bias_cols);
 }
+#endif
 
 int pww_cross_attn_fwd_parts(const void *q, const void *k, const void *v, void *o, const float *bias, int32_t stat_kind,
                              float coeff_scalar, const float *gate, const pww_attn_desc_t *desc, const double *partials,
@@ -301,9 +306,11 @@ void pww_debug_timeline(void *device_buffer, size_t bytes) {
     pww::g_timeline_bytes = device_buffer ? bytes : 0;
 }
 
+#if PWW_EXPERIMENTS
 size_t pww_cross_fused_workspace_bytes(const pww_attn_desc_t *desc) { return pww::cross_fused_workspace_bytes(desc); }
 
 size_t pww_cross_fused_state_bytes(const pww_attn_desc_t *desc) { return pww::cross_fused_state_bytes(desc); }
+#endif
 
 int pww_qk_reduce(const void *q, const void *k, const pww_attn_desc_t *desc, double *stats, void *workspace,
                   size_t workspace_bytes, void *stream) {

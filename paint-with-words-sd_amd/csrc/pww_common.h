@@ -7,6 +7,13 @@
 #include <stdarg.h>
 #include "../../include/pww_hip.h"
 
+// PWW_EXPERIMENTS = 1 builds libpww_hip_experiments.so: the product library plus the forms that were built, measured and NOT made a default
+// (round 3's in-launch score statistic with its workgroup hand-off: pww_cross_attn_fwd_fused[_ex]; round 5's single-buffered key-split
+// self-attention kernel and the to_out epilogue kernel; the A/B instantiations behind PWW_DEBUG). Tests and tools load it; the product never does.
+#ifndef PWW_EXPERIMENTS
+#define PWW_EXPERIMENTS 0
+#endif
+
 namespace pww {
 
 typedef _Float16 f16;

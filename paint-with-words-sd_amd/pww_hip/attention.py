@@ -33,15 +33,16 @@ GATED_ROWS = "_PWW_GATED_ROWS"     # private context key: int, _PWW_ROW_GATE is 
 # that the attention launch folds at entry (pww_cross_attn_fwd_parts: nothing waits for another workgroup, nothing has to be resident,
 # no time-out path) -- either in the epilogue of the to_q GEMM (pww_qproj_stat, where qproj_route says it wins) or by one small launch
 # over the finished Q of the stock GEMM (pww_qk_parts: the C = 1280 layers). PWW_FUSED_CROSS=1 selects round 3's form instead (statistic
-# + device-scope hand-off inside the attention launch, pww_cross_attn_fwd_fused: needs every workgroup resident at once): TEST / A-B only.
+# + device-scope hand-off inside the attention launch, pww_cross_attn_fwd_fused: needs every workgroup resident at once): TEST / A-B only,
+# and since round 6 only with libpww_hip_experiments.so built (the product library does not hold that launch).
 FUSED_CROSS = os.environ.get("PWW_FUSED_CROSS", "0") == "1"
 # the C = 320 cross-attention layers with to_out (+ bias) applied INSIDE the attention launch
 # (pww_cross_attn_fwd_parts_out: one workgroup per 128 query rows walks all heads, then multiplies its O image with W_o). Built, pinned
 # to the two-launch route bit for bit on the test shapes, and measured: 34 us against 18 us (small kernel + the stock GEMM with its bias
 # epilogue) at the 2 folded rows of a batch-1 request, 38 against 41 at 8 rows, 71 against 73 at 16 (profiles/r05_to_out_epilogue.md) --
-# heads run one after the other inside a workgroup where the two-launch route runs them on eight CUs. Off by default; PWW_FUSE_TO_OUT=1
-# takes it wherever the kernel covers the layer.
-FUSE_TO_OUT = os.environ.get("PWW_FUSE_TO_OUT", "0") == "1"
+# heads run one after the other inside a workgroup where the two-launch route runs them on eight CUs. Round 6: NOT a product route any
+# more (no environment switch); the kernel lives in libpww_hip_experiments.so and the tests / tools set this flag themselves.
+FUSE_TO_OUT = False
 QPROJ_STAT = os.environ.get("PWW_QPROJ_STAT", "1")       # "1" where it wins (default) | "0" never | "all" wherever the kernel supports the shape
 
 

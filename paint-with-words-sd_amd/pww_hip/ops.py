@@ -74,7 +74,7 @@ FUSED_MAX_KEYS = 128   # pww_cross_attn_fwd_fused: one K/V stage
 
 
 class FusedScratch:
-    """Device buffers of pww_cross_attn_fwd_fused for one call site (one attention layer): the persistent state words
+    """EXPERIMENTS LIBRARY (libpww_hip_experiments.so; tests and A/B tools): device buffers of pww_cross_attn_fwd_fused for one call site (one attention layer): the persistent state words
     (zeroed ONCE here -- the kernel leaves them zero after every launch, so captured hipGraphs replay without a memset
     node) and the scratch of the two-launch path. Allocated outside stream capture (the first, eager call of a layer
     creates them) and kept alive by their owner, because captured graphs hold their addresses: a buffer that has to grow
@@ -98,6 +98,7 @@ class FusedScratch:
         return (torch.zeros if zero else torch.empty)((n,), dtype=torch.int64, device=device)
 
     def ensure(self, lib, d, device):
+        lib = _lib.load_experiments()      # (the hand-off form's size queries live where the launch lives)
         self.state = self._alloc(self.state, int(lib.pww_cross_fused_state_bytes(ctypes.byref(d))), device, True)
         self.ws = self._alloc(self.ws, int(lib.pww_cross_fused_workspace_bytes(ctypes.byref(d))), device, False)
         self._err_index = d.B * d.H + d.B
@@ -283,8 +284,8 @@ def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None, scra
                 if stats_out is not None and (stats_out.dtype != torch.float64 or tuple(stats_out.shape) != (B, 4) or not stats_out.is_contiguous()):
                     raise PwwHipError("stats_out must be a contiguous float64 [B, 4] tensor")
                 keep = []
-                if compact is not None and compact[0].shape[-1] > COMPACT_MAX_R:
-                    compact = None
+                if compact is not None and (compact[0].shape[-1] > COMPACT_MAX_R or not _lib.has_experiments()):
+                    compact = None          # (the compact form of the map is an experiments-library form: the dense map serves)
                 op = _cross_opts(B, N, coeff_dev, bias_cols, compact, keep, gated)
                 rc = lib.pww_cross_attn_fwd_parts(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(bias), int(kind), float(scalar), _ptr(bias_coeff),
                                                   ctypes.byref(d), _ptr(parts), int(parts.shape[1]) if parts is not None else 0, _ptr(stats_out),
@@ -294,17 +295,18 @@ def attention(q, k, v, heads, scale, bias=None, bias_coeff=None, stat=None, scra
                 _, kind, scalar = stat
                 if M > FUSED_MAX_KEYS:
                     raise PwwHipError("fused statistic needs a FusedScratch and at most %d keys" % FUSED_MAX_KEYS)
-                state, ws = scratch.ensure(lib, d, q.device)
+                xlib = _lib.load_experiments()      # round 3's in-launch statistic is not part of the product library
+                state, ws = scratch.ensure(xlib, d, q.device)
                 if stats_out is not None and (stats_out.dtype != torch.float64 or tuple(stats_out.shape) != (B, 4) or not stats_out.is_contiguous()):
                     raise PwwHipError("stats_out must be a contiguous float64 [B, 4] tensor")
                 keep = []
                 if compact is not None and compact[0].shape[-1] > COMPACT_MAX_R:
                     compact = None
                 op = _cross_opts(B, N, coeff_dev, bias_cols, compact, keep, gated)
-                rc = lib.pww_cross_attn_fwd_fused_ex(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(bias), int(kind), float(scalar),
-                                                     _ptr(bias_coeff), ctypes.byref(d), _ptr(stats_out), _ptr(state), state.numel() * 8,
-                                                     _ptr(ws), ws.numel() * 8, ctypes.byref(op) if op is not None else None, _stream())
-                _lib.check(rc, "pww_cross_attn_fwd_fused_ex")
+                rc = xlib.pww_cross_attn_fwd_fused_ex(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(bias), int(kind), float(scalar),
+                                                      _ptr(bias_coeff), ctypes.byref(d), _ptr(stats_out), _ptr(state), state.numel() * 8,
+                                                      _ptr(ws), ws.numel() * 8, ctypes.byref(op) if op is not None else None, _stream())
+                _lib.check(rc, "pww_cross_attn_fwd_fused_ex", xlib)
             elif stat is not None:
                 stats, kind, scalar = stat
                 if stats is not None and (stats.dtype != torch.float64 or tuple(stats.shape) != (B, 4) or not stats.is_contiguous()):
@@ -330,7 +332,7 @@ def _bias_view(bias, B, heads, N, M):
 
 
 def attention_out_supported(q, k, heads, bias, weight, bias_cols=0):
-    """True if attention_out (cross-attention + to_out in one launch) takes this problem: C = heads * D = 320 with D <= 64, 64 <= M <= 128,
+    """EXPERIMENTS LIBRARY. True if attention_out (cross-attention + to_out in one launch) takes this problem: C = heads * D = 320 with D <= 64, 64 <= M <= 128,
     a dense fp32 map shared by the heads with at most 64 non-zero columns, weight [C, C] of q's dtype."""
     if q.dtype not in _DT or q.dim() != 3 or k.dim() != 3 or bias is None or not torch.is_tensor(weight):
         return False
@@ -347,12 +349,14 @@ def attention_out_supported(q, k, heads, bias, weight, bias_cols=0):
     d.B, d.H, d.N, d.M, d.D = B, heads, N, M, C // heads
     d.q_stride[:] = [q.stride(0), C // heads, q.stride(1)]
     d.bias_stride[:] = list(bv.stride())
-    return bool(_lib.load().pww_cross_attn_out_supported(ctypes.byref(d), C, int(bias_cols)))
+    return bool(_lib.load_experiments().pww_cross_attn_out_supported(ctypes.byref(d), C, int(bias_cols)))
 
 
 def attention_out(q, k, v, heads, scale, bias, weight, weight_bias=None, residual=None, bias_coeff=None, stat=None, parts=None, stats_out=None,
                   coeff_dev=None, bias_cols=0, gated=0):
-    """linear(attention(q, k, v, ...), weight, weight_bias) [+ residual] in ONE launch (pww_cross_attn_fwd_parts_out: reference
+    """EXPERIMENTS LIBRARY (libpww_hip_experiments.so: measured slower than the two-launch route at batch 1, a tie at 16 rows --
+    profiles/r05_to_out_epilogue.md; not a product route since round 6).
+    linear(attention(q, k, v, ...), weight, weight_bias) [+ residual] in ONE launch (pww_cross_attn_fwd_parts_out: reference
     paint_with_words.py:106-123): the pass-2-only cross-attention of `attention(..., stat=(None, kind, scalar), parts=parts)` with the
     layer's to_out projection applied to the heads' outputs while they are still in registers. stat = (None, kind, scalar) or None
     (= a plain `bias_coeff * bias`). Ask attention_out_supported first; anything else raises."""
@@ -390,12 +394,12 @@ def attention_out(q, k, v, heads, scale, bias, weight, weight_bias=None, residua
     keep = []
     op = _cross_opts(B, N, coeff_dev, bias_cols, None, keep, gated)
     rs = (ctypes.c_int64 * 2)(residual.stride(0), residual.stride(1)) if residual is not None else None
-    lib = _lib.load()
+    lib = _lib.load_experiments()
     with torch.cuda.device(q.device):
         rc = lib.pww_cross_attn_fwd_parts_out(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(bias), int(kind), float(scalar), _ptr(bias_coeff), ctypes.byref(d),
                                               _ptr(parts), int(parts.shape[1]) if parts is not None else 0, _ptr(stats_out),
                                               ctypes.byref(op) if op is not None else None, _ptr(weight), _ptr(weight_bias), _ptr(residual), rs, _stream())
-    _lib.check(rc, "pww_cross_attn_fwd_parts_out")
+    _lib.check(rc, "pww_cross_attn_fwd_parts_out", lib)
     return out
 
 

@@ -39,6 +39,17 @@ def built_lib():
 
 
 @pytest.fixture(scope="session")
+def experiments_lib(built_lib):
+    """libpww_hip_experiments.so (+ tests/native/attn_check_experiments): the product library compiled with -DPWW_EXPERIMENTS=1 -- round 3's
+    in-launch statistic, the attention + to_out launch, the A/B kernels behind PWW_DEBUG. Built in-tree when missing (about a minute of
+    hipcc); only tests ask for it."""
+    import build as pww_build
+    lib = pww_build.build_experiments()
+    pww_build.build_native_check_experiments()
+    return lib
+
+
+@pytest.fixture(scope="session")
 def gpu_device(built_lib):
     import torch
     if not torch.cuda.is_available():

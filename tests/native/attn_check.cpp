@@ -28,6 +28,9 @@ static uint16_t to_t(float f, int dt) { return dt == PWW_DTYPE_F16 ? to_f16(f) :
 static float from_t(uint16_t u, int dt) { return dt == PWW_DTYPE_F16 ? from_f16(u) : from_bf16(u); }
 
 static int g_fail = 0;
+#ifndef PWW_EXPERIMENTS
+#define PWW_EXPERIMENTS 0      // 1: built against libpww_hip_experiments.so (attn_check_experiments): + the cases of the moved entry points
+#endif
 static bool g_product_only = false;  // --product-only: for a cross-attention case, ONLY the launch the product issues (fused_ex with bias_cols and the
                                      // gated-images hint, first half of the gates open), 20 times, no checks: what a PMC pass should see
 static bool g_timeline = false;      // --timeline: print the phase time stamps of the case's launches (pww_debug_timeline)
@@ -129,6 +132,9 @@ static void run_case(const Case &c, bool timing) {
     const size_t ws_bytes = pww_workspace_bytes(&d);
     void *dws = dalloc<char>(ws_bytes + 8);
 
+#if !PWW_EXPERIMENTS
+    if (g_product_only) { printf("SKIP %-28s --product-only on this case class launches round 3's fused_ex: attn_check_experiments\n", c.name); return; }
+#else
     if (g_product_only) {
         if (c.bias_mode != 1 || M > 128) { printf("SKIP %-28s --product-only needs a cross-attention case with the [N, M] map\n", c.name); return; }
         const size_t fws_bytes = pww_cross_fused_workspace_bytes(&d), sync_bytes = pww_cross_fused_state_bytes(&d);
@@ -145,6 +151,7 @@ static void run_case(const Case &c, bool timing) {
         if (r) g_fail++;
         return;
     }
+#endif
     int rc = c.bias_mode ? pww_cross_attn_fwd(dq, dk, dv, dout, dbias, dcoeff, &d, nullptr)
                          : pww_self_attn_fwd(dq, dk, dv, dout, &d, nullptr);
     if (rc) { printf("FAIL %-28s attn rc=%d err=%s\n", c.name, rc, pww_last_error()); g_fail++; return; }
@@ -191,6 +198,7 @@ static void run_case(const Case &c, bool timing) {
         }
     }
 
+#if PWW_EXPERIMENTS
     // pww_cross_attn_fwd_fused: statistic + attention in ONE launch == pww_qk_reduce + pww_cross_attn_fwd_stat, bit for bit
     // (output AND statistics), with every gate open and with the last image gated out (the unconditional rows of a
     // CFG-folded batch); repeated launches re-use the same sync words (the kernel leaves them zero).
@@ -407,6 +415,8 @@ static void run_case(const Case &c, bool timing) {
         }
         for (void *ptr : {(void *)fws, (void *)dsync, (void *)fstats, (void *)o1, (void *)o2, (void *)dgate}) (void)hipFree(ptr);
     }
+
+#endif  // PWW_EXPERIMENTS
 
     // fp64 reference on sampled rows: O = softmax((QK^T + c*bias) * scale) V
     double max_err = 0, max_ref = 0; long nchk = 0; int nan_count = 0;
@@ -764,6 +774,7 @@ static void run_qproj(const QCase &c, bool timing) {
         printf("%s %-30s qk_parts + parts-attention kind=%d: max diff %.3e vs two-step path (nan=%ld, rc %d %s)\n", ok3 ? "PASS" : "FAIL", c.name, kind, dmax3, nan3, r3, r3 ? pww_last_error() : "");
         if (!ok3) g_fail++;
     }
+#if PWW_EXPERIMENTS
     // (4) the same attention WITH the layer's output projection in the launch (pww_cross_attn_fwd_parts_out, the C = 320 layers): against the
     // fp64 projection of the O the two-launch route just stored (sampled rows, every output channel) -- one rounding of the storage type
     if (pww_cross_attn_out_supported(&d, C, op.bias_cols)) {
@@ -800,6 +811,7 @@ static void run_qproj(const QCase &c, bool timing) {
         if (!okp) g_fail++;
         (void)hipFree(dwo); (void)hipFree(dwob);
     }
+#endif  // PWW_EXPERIMENTS
     if (timing && g_timeline) {
         std::vector<float> g2(B, 1.f); if (B > 1) for (int b = B / 2; b < B; ++b) g2[b] = 0.f;
         HIPCHECK(hipMemcpy(dgate, g2.data(), B * 4, hipMemcpyHostToDevice));
@@ -815,16 +827,24 @@ static void run_qproj(const QCase &c, bool timing) {
         std::vector<float> g2(B, 1.f); if (B > 1) for (int b = B / 2; b < B; ++b) g2[b] = 0.f;       // a CFG-folded batch
         HIPCHECK(hipMemcpy(dgate, g2.data(), B * 4, hipMemcpyHostToDevice));
         op.gated_images = B > 1 ? B / 2 : 0;
+#if PWW_EXPERIMENTS
         const size_t fws_bytes = pww_cross_fused_workspace_bytes(&d), sync_bytes = pww_cross_fused_state_bytes(&d);
         void *fws = dalloc<char>(fws_bytes + 8); unsigned *dsync = dalloc<unsigned>(sync_bytes / 4 + 1);
         HIPCHECK(hipMemset(dsync, 0, sync_bytes));
+#else
+        void *fws = nullptr; unsigned *dsync = nullptr;
+#endif
         float ms[6] = {0, 0, 0, 0, 0, 0};
         for (int pass = 0; pass < 6; ++pass) {
             for (int i = 0; i < 5 + iters; ++i) {
                 if (i == 5) HIPCHECK(hipEventRecord(e0, nullptr));
                 if (pass == 0) pww_qproj_stat(dx, dw, dq, dk, dgate, &qd, PWW_STAT_MAX, dparts, (size_t)B * nparts * 32, nullptr);
                 else if (pass == 1) pww_cross_attn_fwd_parts(dq, dk, dv, o2, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, dparts, nparts, nullptr, &op, nullptr);
+#if PWW_EXPERIMENTS
                 else if (pass == 2) pww_cross_attn_fwd_fused_ex(dq, dk, dv, o1, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, nullptr, dsync, sync_bytes, fws, fws_bytes, &op, nullptr);
+#else
+                else if (pass == 2) { }       // (round 3's fused launch: attn_check_experiments)
+#endif
                 else if (pass == 3) { pww_qproj_stat(dx, dw, dq, dk, dgate, &qd, PWW_STAT_MAX, dparts, (size_t)B * nparts * 32, nullptr);
                        pww_cross_attn_fwd_parts(dq, dk, dv, o2, dbias, PWW_STAT_MAX, 0.37f, dgate, &d, dparts, nparts, nullptr, &op, nullptr); }
                 else if (pass == 4) pww_qk_parts(dq, dk, dgate, &d, PWW_STAT_MAX, op.gated_images, dparts2, (size_t)B * nparts2 * 32, nullptr);

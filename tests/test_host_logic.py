@@ -14,17 +14,39 @@ from oracle import pww_oracle as O
 
 
 def test_library_loads_and_exports_every_declared_symbol(built_lib):
+    """libpww_hip.so exports exactly what include/pww_hip.h declares outside its "experiments" section -- and none of the experiments
+    section (the product library holds the default routes and the documented switches, nothing else)."""
     import pww_hip
+    from pww_hip import _lib
     lib = pww_hip.load_library()
     header = open(os.path.join(cases.REPO, "include", "pww_hip.h")).read()
-    declared = set(re.findall(r"\b(pww_[a-z0-9_]+)\s*\(", header))
-    assert declared == set(pww_hip.EXPORTS), declared ^ set(pww_hip.EXPORTS)
+    cut = header.index("= experiments =")
+    code = lambda text: re.sub(r"/\*.*?\*/", " ", text, flags=re.S)       # noqa: E731  (declarations only: comments name functions too)
+    product = set(re.findall(r"\b(pww_[a-z0-9_]+)\s*\(", code(header[:cut] + "*/")))
+    moved = set(re.findall(r"\b(pww_[a-z0-9_]+)\s*\(", code("/*" + header[cut:])))
+    assert product == set(pww_hip.EXPORTS), product ^ set(pww_hip.EXPORTS)
+    assert moved == set(_lib.EXPERIMENT_EXPORTS), moved ^ set(_lib.EXPERIMENT_EXPORTS)
     raw = ctypes.CDLL(built_lib)
-    for name in declared:
+    for name in product:
         assert hasattr(raw, name), name
-    assert lib.pww_version() == 125
+    for name in moved:
+        assert not hasattr(raw, name), "%s belongs to libpww_hip_experiments.so" % name
+    assert lib.pww_version() == 126 and lib.pww_has_experiments() == 0 and not _lib.has_experiments()
     assert lib.pww_last_error() == b"" or isinstance(lib.pww_last_error(), bytes)
     assert lib.pww_workspace_bytes(None) == 0
+    assert os.path.getsize(built_lib) <= 6 * 1024 * 1024, "the product library grew past 6 MB: %d bytes" % os.path.getsize(built_lib)
+
+
+def test_experiments_library_is_a_superset(experiments_lib):
+    """libpww_hip_experiments.so (tests / tools only; built by the `experiments_lib` fixture when missing): every product symbol plus the
+    header's experiments section, same ABI version, and it says what it is."""
+    from pww_hip import _lib
+    raw = ctypes.CDLL(experiments_lib)
+    for name in _lib.EXPORTS + _lib.EXPERIMENT_EXPORTS:
+        assert hasattr(raw, name), name
+    raw.pww_has_experiments.restype = ctypes.c_int
+    assert raw.pww_has_experiments() == 1 and raw.pww_version() == 126
+    assert _lib.load_experiments().pww_has_experiments() == 1
 
 
 def test_struct_layout_matches_header():
@@ -819,14 +841,14 @@ def test_qproj_route_follows_the_measured_table(monkeypatch):
     assert not A.qproj_route(320, 40)
 
 
-def test_fused_projection_entry_point_says_what_it_takes(built_lib):
+def test_fused_projection_entry_point_says_what_it_takes(experiments_lib):
     """pww_cross_attn_out_supported is host logic (no GPU): the shapes pww_cross_attn_fwd_parts_out takes -- H * D = 320 with D <= 64,
     64 <= M <= 128, dense bias rows shared by the heads, at most 64 non-zero map columns -- and nothing else; the Python op refuses CPU
-    tensors like every other op; the route is opt-in."""
+    tensors like every other op. Since round 6 an EXPERIMENTS-library entry point (measured slower / a tie: no product switch selects it)."""
     import ctypes
     import pww_hip
     from pww_hip import _lib, ops, attention
-    lib = _lib.load()
+    lib = _lib.load_experiments()
 
     def desc(H, D, N=4096, M=77, bias_stride=(0, 0, 77, 1), dtype=1):
         d = _lib.AttnDesc()
@@ -846,4 +868,4 @@ def test_fused_projection_entry_point_says_what_it_takes(built_lib):
     x = torch.randn(1, 128, 320).half()
     with pytest.raises(pww_hip.PwwHipError):
         ops.attention_out(x, x[:, :77], x[:, :77], 8, 1.0, torch.rand(128, 77), torch.randn(320, 320).half())
-    assert attention.FUSE_TO_OUT is (os.environ.get("PWW_FUSE_TO_OUT", "0") == "1")
+    assert attention.FUSE_TO_OUT is False and not hasattr(_lib.load(), "pww_cross_attn_fwd_parts_out") or _lib.has_experiments()

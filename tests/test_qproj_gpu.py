@@ -102,7 +102,7 @@ def test_qproj_unsupported_shapes_say_so(gpu_device):
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("shape", ["sd15_n4096", "sd15_n1024", "sd15_n256", "sd15_n64", "sd21_n576"])
-def test_product_path_with_and_without_the_gemm_epilogue_statistic(gpu_device, shape, dtype, monkeypatch):
+def test_product_path_with_and_without_the_gemm_epilogue_statistic(gpu_device, experiments_lib, shape, dtype, monkeypatch):
     """inj_forward through the default path (to_q GEMM with the statistic in its epilogue + pass-2-only attention) against the
     round-3 launch (PWW_QPROJ_STAT=0: stock to_q GEMM + statistic and hand-off inside the attention kernel) on the reference's
     attention cases, every shipped weight function: the two differ by the roundings of two different GEMM kernels (<= a few

@@ -231,7 +231,7 @@ def test_magnitude_guard(gpu_device, dtype, target_max):
 
 # ---- 1d: the fused hand-off's error word reaches the caller ----------------------------------------------------------------
 
-def test_fused_handoff_timeout_raises(gpu_device):
+def test_fused_handoff_timeout_raises(gpu_device, experiments_lib):
     """If the workgroups of a fused cross-attention launch are not all resident (here: forced with the library's test hook
     PWW_DEBUG=cross_assume_resident=n -- in the field: another process or stream holding compute units), the hand-off times out after
     1 s, the outputs are NaN and an error word is set. The product reads that
@@ -259,14 +259,14 @@ except PwwHipError as e:
     print("raised:", str(e)[:60])
 print("state clean:", not m.__dict__["_pww_fused_scratch"].error())
 ''' % (os.path.join(cases.REPO, "paint-with-words-sd_amd"), cases.REPO)
-    env = dict(os.environ, PWW_DEBUG="cross_assume_resident=8")
+    env = dict(os.environ, PWW_DEBUG="cross_assume_resident=8")      # (read by libpww_hip_experiments.so, where the hand-off launch lives since round 6)
     out = subprocess.run(["timeout", "240", sys.executable, "-c", code], capture_output=True, text=True, env=env)
     print(out.stdout[-600:], out.stderr[-600:])
     assert out.returncode == 0, out.stderr[-2000:]
     assert "nan outputs: True" in out.stdout and "raised: a fused cross-attention launch timed out" in out.stdout and "state clean: True" in out.stdout
 
 
-def test_sampler_raises_on_a_set_error_word(gpu_device, monkeypatch):
+def test_sampler_raises_on_a_set_error_word(gpu_device, experiments_lib, monkeypatch):
     """The round-3 launch (statistic + hand-off inside the attention kernel; since round 5 only behind PWW_FUSED_CROSS=1 / attention.FUSED_CROSS,
     a test and A/B switch) can fail at run time. PwWSampler posts the error words of every attention layer after the loop (one
     device -> host copy behind an event) and raises when they are looked at: in the PIL-returning entry points right after the
@@ -343,7 +343,7 @@ def test_one_graph_serves_thirty_steps_and_the_fallback_still_works(gpu_device):
 
 @pytest.mark.parametrize("shape,dtype,B", [("sd15_n4096", torch.bfloat16, 2), ("sd15_n4096", torch.float16, 16), ("sd15_n1024", torch.float16, 16),
                                            ("sd15_n256", torch.bfloat16, 2), ("sd21_n576", torch.bfloat16, 6)])
-def test_bias_hints_do_not_change_a_bit(gpu_device, shape, dtype, B):
+def test_bias_hints_do_not_change_a_bit(gpu_device, experiments_lib, shape, dtype, B):
     """pww_cross_attn_fwd_fused_ex: the bias rows of a query block staged in LDS from the dense map (only the columns below the
     column bound) or from the compact [N, R] + col_idx form give bit-identical outputs; the gated-images hint (right or wrong) only
     moves work between workgroups. Against the call WITHOUT hints (per-lane global bias loads: since round 4 the only form that keeps
@@ -380,10 +380,12 @@ def test_bias_hints_do_not_change_a_bit(gpu_device, shape, dtype, B):
     assert last_bits(base, two)
 
 
-def test_opt_in_compact_maps_through_the_product(gpu_device, monkeypatch):
+def test_opt_in_compact_maps_through_the_product(gpu_device, experiments_lib, monkeypatch):
     """conditioning.COMPACT_BIAS (env PWW_COMPACT_BIAS=1) adds the compact [N, R] + col_idx form of every weight map to the
     conditional context; the folded batch stacks them and pww_attention hands them to the fused kernel. Off by default (slower
-    than the dense LDS tile in every measured shape); on, the latents must equal the default route's."""
+    than the dense LDS tile in every measured shape) and since round 6 an EXPERIMENTS-library form (the product library drops the compact
+    form and uses the dense map): the request runs on libpww_hip_experiments.so here (`_lib.experiments()`); on, the latents must equal the
+    default route's."""
     import paint_with_words as pw
     from pww_hip import conditioning
     from pww_hip.attention import COMPACT_IDX
@@ -391,8 +393,9 @@ def test_opt_in_compact_maps_through_the_product(gpu_device, monkeypatch):
     kw = dict(color_map_image=Image.fromarray(cases.load_example_rgb()), color_context=dict(cases.RUNNER_CONTEXT), input_prompt=cases.RUNNER_PROMPT,
               num_inference_steps=3, guidance_scale=7.5, seed=5, device=str(gpu_device), weight_function=cases.weight_fn_runner,
               preloaded_utils=tools, return_latents=True)
+    from pww_hip import _lib
     try:
-        with _mode("graph"):
+        with _mode("graph"), _lib.experiments():
             assert conditioning.COMPACT_BIAS is (os.environ.get("PWW_COMPACT_BIAS", "0") == "1")
             monkeypatch.setattr(conditioning, "COMPACT_BIAS", False)
             base = pw.paint_with_words(**kw)

@@ -155,7 +155,7 @@ OUT_SHAPES = [
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("name,B,N,H,D,M,shared", OUT_SHAPES)
-def test_cross_attention_with_to_out_in_the_launch(gpu_device, dtype, name, B, N, H, D, M, shared):
+def test_cross_attention_with_to_out_in_the_launch(gpu_device, experiments_lib, dtype, name, B, N, H, D, M, shared):
     """pww_cross_attn_fwd_parts_out (row f-1: attention + to_out + bias [+ residual] in one launch) against the two-launch route it
     replaces -- `linear(pww_cross_attn_fwd_parts(...), W, b) [+ residual]` in fp64 ON THE KERNEL'S OWN rounded O (the projection must see
     exactly the O the two-launch path stores) -- and against the fp64 reference of the whole expression (paint_with_words.py:106-123).
@@ -206,7 +206,7 @@ def test_cross_attention_with_to_out_in_the_launch(gpu_device, dtype, name, B, N
     assert torch.equal(out, ops.attention_out(q, k, v, H, scale, bias, w, wb, **kw))
 
 
-def test_cross_attention_with_to_out_declines_what_it_does_not_take(gpu_device):
+def test_cross_attention_with_to_out_declines_what_it_does_not_take(gpu_device, experiments_lib):
     from pww_hip import ops
     dev, dt = gpu_device, torch.bfloat16
     q, k, v = _qkv("decl", 2, 256, 8, 80, 77, False, dt, dev)          # C = 640
@@ -254,7 +254,7 @@ def test_default_path_has_no_handoff_state_on_any_layer(gpu_device):
 
 
 @pytest.mark.parametrize("shape", ["sd15_n4096", "sd21_n2304"])
-def test_plug_with_to_out_inside_the_launch(gpu_device, monkeypatch, shape):
+def test_plug_with_to_out_inside_the_launch(gpu_device, experiments_lib, monkeypatch, shape):
     """PWW_FUSE_TO_OUT (row f-1, opt-in): inj_forward of a C = 320 cross-attention layer with the projection inside the attention launch
     against the default two-launch route -- the same module, the same PwW dict; eager and with a CFG-folded row gate. A layer the kernel
     does not cover (C = 640) silently keeps the two-launch route."""
@@ -313,12 +313,12 @@ def test_small_self_attention_vs_fp64_and_repeatable(gpu_device, dtype, N, C, H)
     assert torch.equal(out, ops.attention(q, k, v, H, D ** -0.5))
 
 
-def test_single_buffer_key_split_kernel_behind_its_knob(gpu_device):
+def test_single_buffer_key_split_kernel_behind_its_knob(gpu_device, experiments_lib):
     """The single-buffered key-split self-attention kernel of round 5 (attn_ksplit1_kernel: VERDICT round 4 item 1b asked for more waves in
     flight at N <= 1024) measured slower than the double-buffered form it was to replace (profiles/r05_small_attn.md) and is off by default;
     it stays correct behind PWW_DEBUG=attn_ksplit1=1: every head dim x token count of the sweep inside the per-call bar (own process: the
     library reads its knobs once)."""
-    env = dict(os.environ, PWW_DEBUG="attn_ksplit1=1")
+    env = dict(os.environ, PWW_DEBUG="attn_ksplit1=1", PWW_HIP_LIB=experiments_lib)      # (an experiments-library kernel since round 6)
     out = subprocess.run(["timeout", "300", sys.executable, os.path.join(cases.REPO, "tools", "diag_selfattn_dims.py")], capture_output=True, text=True, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if " err " in l]

@@ -24,8 +24,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", CSRC, "-I", os.path.join(REPO, "include")]
 
 
-def resource_usage(src):
-    out = subprocess.run([HIPCC] + FLAGS + ["-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
+def resource_usage(src, extra=()):
+    out = subprocess.run([HIPCC] + FLAGS + list(extra) + ["-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
     rows, cur = {}, None
     for line in out.splitlines():
         m = re.search(r"remark: [^:]*:\d+:\d+:\s+(.*?)\s*\[-Rpass", line) or re.search(r"remark:\s+(.*?)\s*\[-Rpass", line)
@@ -40,10 +40,10 @@ def resource_usage(src):
     return rows
 
 
-def kernel_isa(src, symbol_regex):
+def kernel_isa(src, symbol_regex, extra=()):
     with tempfile.TemporaryDirectory() as tmp:
         asm = os.path.join(tmp, "k.s")
-        subprocess.run([HIPCC] + FLAGS + ["-S", "--cuda-device-only", src, "-o", asm], capture_output=True, text=True, check=True)
+        subprocess.run([HIPCC] + FLAGS + list(extra) + ["-S", "--cuda-device-only", src, "-o", asm], capture_output=True, text=True, check=True)
         text = open(asm).read()
     out = {}
     for m in re.finditer(r"^(%s):.*?s_endpgm" % symbol_regex, text, re.M | re.S):
@@ -60,13 +60,19 @@ def main():
             bad.append(what)
 
     # ---- 1. register budgets -------------------------------------------------------------------------------------------------
-    attn = resource_usage(os.path.join(CSRC, "pww_attn.hip"))
+    # (round 6: the kernel families are instantiated per storage type -- and the general cross kernel per workgroup width -- in
+    # pww_attn_inst.hip / pww_cross_inst.hip; the hand-off form of section 2 is an experiments-library kernel: -DPWW_EXPERIMENTS=1)
+    attn = {}
+    for t in ("-DPWW_INST_F16", "-DPWW_INST_BF16"):
+        attn.update(resource_usage(os.path.join(CSRC, "pww_attn_inst.hip"), [t]))
     for name, r in attn.items():
         if "attn_fwd_fold_kernel" in name and not name.endswith("ELi2EEEvNS_10AttnParamsE"):      # d = 40 folded kernels, 8- and 4-wave workgroups
             # (the dominant launch; the 2-wave variant serves under-filled launches at one wave per SIMD): two waves per SIMD, no scratch
             check(int(r["Occupancy [waves/SIMD]"]) >= 2 and int(r["ScratchSize [bytes/lane]"]) == 0,
                   "%s: %s VGPRs, occupancy %s, %s B scratch (>= 2 waves per SIMD, no scratch)" % (name, r["VGPRs"], r["Occupancy [waves/SIMD]"], r["ScratchSize [bytes/lane]"]))
-    cross = resource_usage(os.path.join(CSRC, "pww_cross.hip"))
+    cross = {}
+    for t in ("-DPWW_INST_F16", "-DPWW_INST_BF16"):
+        cross.update(resource_usage(os.path.join(CSRC, "pww_cross_inst.hip"), [t, "-DPWW_INST_NW=4"]))
     for name, r in cross.items():
         m = re.match(r"_ZN3pww18cross_fused_kernelI(DF16_|DF16b)Li(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])EEE", name)
         if not m:
@@ -78,7 +84,8 @@ def main():
                                                                                       r["ScratchSize [bytes/lane]"], r["Occupancy [waves/SIMD]"]))
 
     # ---- 2. the several-blocks-per-workgroup cross kernel (bf16, d = 40, dense) -----------------------------------------------
-    isa = kernel_isa(os.path.join(CSRC, "pww_cross.hip"), r"_ZN3pww18cross_fused_kernelIDF16bLi3ELi2ELi4ELb0ELb0EEEvNS_11CrossParamsE")
+    isa = kernel_isa(os.path.join(CSRC, "pww_cross_inst.hip"), r"_ZN3pww18cross_fused_kernelIDF16bLi3ELi2ELi4ELb0ELb0EEEvNS_11CrossParamsE",
+                     ["-DPWW_INST_BF16", "-DPWW_INST_NW=4", "-DPWW_EXPERIMENTS=1"])
     lines = next(iter(isa.values()))
     body = "\n".join(lines)
     # (round 4: the entry fold of the projection's fp64 partials is a small loop of two global 16-byte loads next to v_max_f64 / v_add_f64 --
@@ -143,10 +150,10 @@ def main():
     # hipcc selects the accumulator-file form of every MFMA and copies each score / O tile to and from it: 1136 v_accvgpr moves and 40 us per
     # workgroup in the one-phase version), with no scratch and no waterfall loop around a buffer load
     out_src = os.path.join(CSRC, "pww_cross_out.hip")
-    for name, r in resource_usage(out_src).items():
+    for name, r in resource_usage(out_src, ["-DPWW_EXPERIMENTS=1"]).items():
         if "cross_out_kernel" in name:
             check(int(r["ScratchSize [bytes/lane]"]) == 0 and int(r["VGPRs"]) <= 256, "%s: %s VGPRs (<= 256), %s B scratch (none)" % (name[:60], r["VGPRs"], r["ScratchSize [bytes/lane]"]))
-    isa = kernel_isa(out_src, r"_ZN3pww16cross_out_kernelIDF16bLi3ELi10EEEvNS_9OutParamsE")
+    isa = kernel_isa(out_src, r"_ZN3pww16cross_out_kernelIDF16bLi3ELi10EEEvNS_9OutParamsE", ["-DPWW_EXPERIMENTS=1"])
     lines = [l.strip() for l in next(iter(isa.values()))]
     acc = sum(1 for l in lines if l.startswith("v_accvgpr"))
     wf = sum(1 for i, l in enumerate(lines) if l.startswith("buffer_load") and any(x.startswith("s_cbranch_execnz") for x in lines[i + 1:i + 4]))      # (load; s_xor exec; s_cbranch_execnz = a waterfall loop)

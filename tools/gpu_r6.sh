@@ -1,0 +1,47 @@
+#!/bin/bash
+# Round-6 GPU runner: `bash tools/gpu_r6.sh <stage> [...]`; everything lands under gpurun_out/r6_<stage>*.
+export TMPDIR=/tmp
+mkdir -p gpurun_out; O=gpurun_out
+SHORT="--steps 3 --warmup 1 --cpu-steps 0 --no-reference-ops --no-live-counters"
+summ() { python - "$1" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+ap = d.get("attention_path") or {}
+print(sys.argv[1], "img/s", d["value"], "ms", d["ms_per_step"], "parity", (d.get("parity") or {}).get("rel_l2"), "dom", ap.get("dominant_us_per_forward"), "others", ap.get("others_us_per_forward"), "b2b", ap.get("others_us_per_forward_back_to_back"))
+for r in d.get("kernels", []):
+    if "N" in r:
+        print("   %-44s N=%-5s D=%-4s n=%-4s us=%-7s b2b=%s" % (r["kernel"][:44], r.get("N"), r.get("D"), r.get("launches"), r.get("avg_us"), r.get("avg_us_back_to_back")))
+PY
+}
+for stage in "$@"; do
+case $stage in
+kernarg)
+  # cold start of the small launches: where do the kernel arguments live? (HIP_FORCE_DEV_KERNARG: device memory instead of host-coherent memory)
+  for v in 0 1; do HIP_FORCE_DEV_KERNARG=$v timeout 400 python bench.py $SHORT > $O/r6_bench_devkernarg$v.json 2> $O/r6_bench_devkernarg$v.log; summ $O/r6_bench_devkernarg$v.json; done
+  ;;
+qprojroute)
+  PWW_QPROJ_STAT=0 timeout 400 python bench.py $SHORT > $O/r6_bench_qproj0.json 2> $O/r6_bench_qproj0.log; summ $O/r6_bench_qproj0.json
+  ;;
+bench)
+  timeout 400 python bench.py $SHORT > $O/r6_bench.json 2> $O/r6_bench.log; tail -2 $O/r6_bench.log; summ $O/r6_bench.json
+  ;;
+benchfull)
+  timeout 900 python bench.py > $O/r6_bench_default.json 2> $O/r6_bench_default.log; tail -2 $O/r6_bench_default.log; summ $O/r6_bench_default.json
+  ;;
+native)
+  (cd tests/native && timeout 900 ./attn_check --quick > ../../$O/r6_native.log 2>&1; grep -c "^PASS" ../../$O/r6_native.log; grep -v "^PASS\|^TIME\|^TIMELINE" ../../$O/r6_native.log | tail -15)
+  ;;
+pytest)
+  timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | grep -v amdgpu.ids | tail -15 | tee $O/r6_pytest.log
+  ;;
+subset)
+  timeout 1200 python -m pytest tests/test_attention_gpu.py tests/test_qproj_gpu.py tests/test_round3_gpu.py tests/test_round5_gpu.py tests/test_round6_gpu.py -m gpu -q -x 2>&1 | grep -v amdgpu.ids | tail -30 | tee $O/r6_subset.log
+  ;;
+configs)
+  for c in 3 4 5; do
+    timeout 900 python bench.py --config $c --steps 1 --warmup 1 --cpu-steps 0 --no-reference-ops --no-live-counters > $O/r6_bench_c$c.json 2> $O/r6_bench_c$c.log; summ $O/r6_bench_c$c.json
+  done
+  ;;
+*) if [ -f "tools/gpu_r6_$stage.sh" ]; then bash tools/gpu_r6_$stage.sh; else echo "unknown stage $stage"; fi;;
+esac
+done
