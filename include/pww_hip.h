@@ -420,6 +420,12 @@ int pww_profile_arm(void);
 int pww_profile_elapsed_us(int32_t slot, float *microseconds);
 void pww_profile_reset(void);
 
+/* Measurement aid (version >= 126): three uint32 counters in device memory (zeroed by the caller) that every workgroup of the d = 40
+ * folded-reference self-attention kernel bumps at its end -- [0] finished on the range-free fast path, [1] finished on the lazy-reference
+ * path (an fp16 workgroup whose first key stage showed a hot row), [2] recomputed its rows on the exact path (overflow or magnitude guard).
+ * NULL switches it off (the default). Process-wide, like pww_debug_timeline; bench.py reports the counts of its hot-logit rows. */
+void pww_debug_path_counts(void *device_buffer);
+
 /*
  * Phase time stamps of the attention kernels (debug / measurement aid). After pww_debug_timeline(buf, bytes) every attention
  * launch of the PROCESS whose grid fits writes 8 uint64 wall-clock stamps (100 MHz) per workgroup to buf[workgroup][8]:

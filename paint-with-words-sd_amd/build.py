@@ -36,7 +36,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
 
 
 # pww_mask.hip restates fp32 formulas that must match the CPU oracle bit for bit: no FMA contraction.
-PER_FILE_FLAGS = {"pww_mask.hip": ["-ffp-contract=off"]}
+# pww_cross_lean.hip: the leading scalar arguments of its kernels (<= 16 dwords) are preloaded into SGPRs by the dispatcher instead of fetched by
+# the wave's first s_load (gfx950 supports kernarg preload; the compiler keeps a compatibility prologue for firmware that does not).
+PER_FILE_FLAGS = {"pww_mask.hip": ["-ffp-contract=off"], "pww_cross_lean.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=16"]}
 
 
 def _newer(target, deps):

@@ -32,7 +32,8 @@ const DebugKnobs &debug_knobs() {
             {"attn_pair_major", &k.attn_pair_major}, {"attn_wide_store", &k.attn_wide_store}, {"cross_wg_per_cu", &k.cross_wg_per_cu},
             {"cross_assume_resident", &k.cross_assume_resident}, {"cross_gate_weight", &k.cross_gate_weight},
             {"cross_tile_nbuf", &k.cross_tile_nbuf}, {"cross_bias_lds", &k.cross_bias_lds}, {"cross_lean", &k.cross_lean},
-            {"cross_lean_nw", &k.cross_lean_nw}, {"attn_ksplit_nw", &k.attn_ksplit_nw}, {"attn_ksplit1", &k.attn_ksplit1}};
+            {"cross_lean_nw", &k.cross_lean_nw}, {"attn_ksplit_nw", &k.attn_ksplit_nw}, {"attn_ksplit1", &k.attn_ksplit1}, {"attn_ksplit_half", &k.attn_ksplit_half},
+            {"attn_hot_sum", &k.attn_hot_sum}, {"attn_fold_limit_f16", &k.attn_fold_limit_f16}};
         const char *p = e;
         while (*p) {
             const char *eq = strchr(p, '='), *end = strchr(p, ',');
@@ -151,6 +152,9 @@ static unsigned long long *g_timeline = nullptr;
 static size_t g_timeline_bytes = 0;
 unsigned long long *debug_timeline() { std::lock_guard<std::mutex> lock(g_prof_mutex); return g_timeline_bytes ? g_timeline : nullptr; }
 size_t debug_timeline_bytes() { std::lock_guard<std::mutex> lock(g_prof_mutex); return g_timeline ? g_timeline_bytes : 0; }
+// ---- path counters of the folded-reference self-attention kernel (pww_debug_path_counts): { range-free, lazy, exact } workgroups
+static unsigned *g_path_counts = nullptr;
+unsigned *debug_path_counts() { std::lock_guard<std::mutex> lock(g_prof_mutex); return g_path_counts; }
 
 int attn_fwd(const void *q, const void *k, const void *v, void *o, const float *bias, const float *bias_coeff,
              const pww_attn_desc_t *d, hipStream_t stream, const double *stats = nullptr, int stat_kind = PWW_STAT_NONE,
@@ -298,6 +302,11 @@ int pww_cross_attn_fwd_parts(const void *q, const void *k, const void *v, void *
 int pww_mask_build_f32_levels(const float *masks, int32_t H, int32_t W, int32_t R, const int32_t *col_ptr, const int32_t *col_reg,
                               int32_t T, float *out8, float *out16, float *out32, float *out64, void *stream) {
     return pww::mask_build_f32_levels(masks, H, W, R, col_ptr, col_reg, T, out8, out16, out32, out64, static_cast<hipStream_t>(stream));
+}
+
+void pww_debug_path_counts(void *device_buffer) {
+    std::lock_guard<std::mutex> lock(pww::g_prof_mutex);
+    pww::g_path_counts = static_cast<unsigned *>(device_buffer);
 }
 
 void pww_debug_timeline(void *device_buffer, size_t bytes) {

@@ -27,6 +27,7 @@ namespace pww {
 int attn_dispatch_f16(const AttnParams &p, hipStream_t s);
 int attn_dispatch_bf16(const AttnParams &p, hipStream_t s);
 bool attn_wide_groups_rule(int B, int H, int N, int D);
+unsigned *debug_path_counts();
 
 bool attn_wide_groups_dims(int B, int H, int N, int D) { return attn_wide_groups_rule(B, H, N, D); }
 bool attn_wide_groups(const pww_attn_desc_t *d) { return attn_wide_groups_rule(d->B, d->H, d->N, d->D); }
@@ -109,6 +110,12 @@ void attn_fill_params(AttnParams &p, const void *q, const void *k, const void *v
     p.pair_major = ((d->B * d->H) % 8 == 0 && d->B * d->H >= pair_major_min() && !bias) ? 1 : 0;
     p.o_wide = (d->o_stride[0] % 8 == 0 && d->o_stride[1] % 8 == 0 && d->o_stride[2] % 8 == 0 && wide_store_mode()) ? 1 : 0;
     p.timeline_wgs = (unsigned)(debug_timeline_bytes() / (TL_SLOTS * sizeof(unsigned long long)));
+    // folded-reference d = 40 kernel (pww_attn_kernel.h): FoldLimit of the storage type (PWW_DEBUG=attn_fold_limit_f16=n overrides the f16 one, A/B),
+    // the hot-row threshold of the f16 range-free mode (PWW_DEBUG=attn_hot_sum=n; 0 = never switch: round 5's behaviour, -1 = lazy from the start)
+    const DebugKnobs &kn = debug_knobs();
+    p.fold_limit = d->dtype == PWW_DTYPE_F16 ? (kn.attn_fold_limit_f16 > 0 ? (float)kn.attn_fold_limit_f16 : FOLD_LIMIT_F16) : FOLD_LIMIT_BF16;
+    p.hot_sum = (float)kn.attn_hot_sum;
+    p.path_counts = debug_path_counts();
 }
 
 int attn_fwd(const void *q, const void *k, const void *v, void *o, const float *bias,

@@ -30,7 +30,19 @@ struct AttnParams {
     int pair_major;                  // 1: workgroups of one (image, head) pair run on ONE XCD, pairs dealt round-robin to the XCDs
     unsigned long long *timeline;    // debug: per-workgroup phase time stamps (pww_debug_timeline), normally null
     unsigned timeline_wgs;           // workgroups the debug buffer has room for
+    // folded-reference self-attention (d = 40): the magnitude guard's limit on |row maximum| in exp2 units (FoldLimit<T>), the first-stage row
+    // sum below which an f16 workgroup leaves the range-free mode (0: never, < 0: lazy from the start), and three debug counters
+    // { range-free, lazy, exact } workgroups (pww_debug_path_counts), normally null
+    float fold_limit, hot_sum;
+    unsigned *path_counts;
 };
+
+// Magnitude guard of the folded-reference d = 40 kernel (FoldLimit<T>, pww_attn_kernel.h), exp2 units. Round 6, from the sweep of
+// tools/diag_hot_f16.py (profiles/r06_hot_logits.md: error against fp64 on sampled rows, N = 4096, scaled-logit std 1 ... 8): f16 0.8e-3 of max|O| at
+// row maxima of 22 natural units, 1.2e-3 at 33, 1.55e-3 at 36 (bar 2e-3) -> 48 (= 33 natural units; was 36 = 25: every workgroup of a
+// std-5 input took the exact path, after a complete fast pass); bf16 1.05e-2 at 35 natural units, 1.1 - 1.6e-2 at 39 - 41 (bar 1.6e-2) ->
+// 56 (= 39; was 72 = 50, extrapolated from two points in round 2).
+constexpr float FOLD_LIMIT_BF16 = 56.f, FOLD_LIMIT_F16 = 48.f;
 
 // the Python scalar c0 * g(sigma) of the weight function: baked into the launch, or read from a device word
 __device__ __forceinline__ float coeff_scalar_of(const AttnParams &p) {
@@ -302,19 +314,20 @@ __device__ __forceinline__ void bias_ref_tile(BiasRef &b, const char *tile, int 
     b.lds_cols = cols;
 }
 
-template <typename T, int KS, int DT, int HAS_BIAS, bool MASKED, bool ROWSUM_MFMA, int STEP = 0>
+template <typename T, int KS, int DT, int HAS_BIAS, bool MASKED, bool ROWSUM_MFMA, int STEP = 0, int ONLY = -1>
 __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[DT], float &m_run, float &l_run, const char *Vs,
                                                 int key0, int M, int l31, int hi, const BiasRef &bias,
                                                 float coeff, float c1);
 
-template <typename T, int KS, int DT, int HAS_BIAS, bool MASKED, bool ROWSUM_MFMA, int STEP = 0>
+// ONLY = 0 / 1: only that 32-key block of the 64-key tile takes part (half-tile key groups); -1: the whole tile.
+template <typename T, int KS, int DT, int HAS_BIAS, bool MASKED, bool ROWSUM_MFMA, int STEP = 0, int ONLY = -1>
 __device__ __forceinline__ void attn_tile(f32x16 (&oacc)[DT], float &m_run, float &l_run,
                                           const typename Vec<T>::v8 (&qf)[KS], const char *Ks, const char *Vs,
                                           int key0, int M, int l31, int hi, const BiasRef &bias,
                                           float coeff, float c1) {
     f32x16 s[2];
-    score_tile<T, KS>(s, qf, Ks, key0, MASKED ? M : 0x7fffffff, l31, hi);
-    attn_tile_sm_pv<T, KS, DT, HAS_BIAS, MASKED, ROWSUM_MFMA, STEP>(s, oacc, m_run, l_run, Vs, key0, M, l31, hi, bias, coeff, c1);
+    score_tile<T, KS, ONLY>(s, qf, Ks, key0, MASKED ? M : 0x7fffffff, l31, hi);
+    attn_tile_sm_pv<T, KS, DT, HAS_BIAS, MASKED, ROWSUM_MFMA, STEP, ONLY>(s, oacc, m_run, l_run, Vs, key0, M, l31, hi, bias, coeff, c1);
 }
 
 // Headroom of the lazy step (STEP 2), in exp2 units: a later tile keeps the row's running reference while no score of it exceeds the
@@ -327,7 +340,7 @@ constexpr float LAZY_HEADROOM = 8.f;
 //       first MFMA of every channel tile starts from a zero constant -- the caller need not clear O^T); 2 a LATER tile with a lazy
 //       reference: the running maximum is only raised (and O^T rescaled) when some row of the wave would otherwise produce a P above
 //       2^LAZY_HEADROOM -- any reference gives the same softmax, it only has to keep P inside the storage type's range.
-template <typename T, int KS, int DT, int HAS_BIAS, bool MASKED, bool ROWSUM_MFMA, int STEP>
+template <typename T, int KS, int DT, int HAS_BIAS, bool MASKED, bool ROWSUM_MFMA, int STEP, int ONLY>
 __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[DT], float &m_run, float &l_run, const char *Vs,
                                                 int key0, int M, int l31, int hi, const BiasRef &bias,
                                                 float coeff, float c1) {
@@ -338,7 +351,7 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
     // (a 4-way max tree and packed v_pk_fma_f32 for the exp arguments were measured: neutral to -3%)
     // a 32-key block entirely past M (the second block of a ragged tail: keys 96..127 of the 77 prompt tokens) takes no part in
     // anything below -- wave-uniform, and its P^T fragments are never multiplied (the PV loop skips the same blocks)
-    const bool live0 = !MASKED || key0 < M, live1 = !MASKED || key0 + 32 < M;
+    const bool live0 = ONLY != 1 && (!MASKED || key0 < M), live1 = ONLY != 0 && (!MASKED || key0 + 32 < M);
     float tmax = -INFINITY;
     if (HAS_BIAS == 2) {
         // the lane's 8 consecutive keys of each (block, half) are 32 contiguous bytes of its row in the LDS tile; a 16-key
@@ -464,7 +477,7 @@ __device__ __forceinline__ void attn_tile_sm_pv(f32x16 (&s)[2], f32x16 (&oacc)[D
     // O^T[d][row] += V^T[d][key] * P^T[key][row]   (V^T fragments come out of the transpose read)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-        if (!MASKED || key0 + kb * 32 < M) {
+        if ((ONLY < 0 || ONLY == kb) && (!MASKED || key0 + kb * 32 < M)) {
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
 #pragma unroll

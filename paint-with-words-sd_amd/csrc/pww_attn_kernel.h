@@ -72,12 +72,17 @@ __device__ __forceinline__ void exact_rows(f32x16 (&oacc)[DT], float &l_run, con
 // RF = range-free softmax (pww_attn_core.h: attn_tile_rf; bf16 without bias, KG == 1 only): no running maximum in the loop,
 // one range check at the end, exact_rows as the fallback.
 template <typename T, int KS, int DT, int NW, int NSUB, int KG, bool HAS_BIAS, bool ROWSUM_MFMA, bool RF = false>
-__global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, HAS_BIAS>::value)) attn_fwd_kernel(const AttnParams p) {
+__global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? (NW * KG >= 12 ? 3 : 2) : MinWaves<DT, NW, HAS_BIAS>::value)) attn_fwd_kernel(const AttnParams p) {
     static_assert(!RF || (KG == 1 && !HAS_BIAS && RangeFree<T>::value), "range-free mode: no bias, no key split");
     typedef typename Vec<T>::v8 V8;
     typedef KTile<KS> KT;
     typedef VTile<DT> VT;
-    static_assert(KG == 1 || NSUB == KG, "key-split workgroups process one sub-tile per key group");
+    // HALF (round 6): KG = 2 NSUB key groups, each owns one 32-key BLOCK of a stage (half a sub-tile): twice the waves of the plain key
+    // split on the same stage buffers -- two waves per SIMD whose dependent chains (LDS -> MFMA -> max -> exp -> MFMA) the hardware
+    // interleaves -- for launches that otherwise run ONE wave per SIMD (SD1.5 N = 1024 d = 80 at 2 folded rows: 8 tiles per wave at
+    // ~2800 cycles each for ~700 cycles of MFMA)
+    constexpr bool HALF = KG > 1 && KG == 2 * NSUB;
+    static_assert(KG == 1 || NSUB == KG || HALF, "key-split workgroups process one sub-tile (or one 32-key block of it) per key group");
     constexpr int NT = NW * KG * 64;
     constexpr int SUB_BYTES = KT::BYTES + VT::BYTES;     // one 64-key sub-tile: K rows, then V rows
     constexpr int STAGE_BYTES = NSUB * SUB_BYTES;
@@ -170,7 +175,12 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
         // barrier), then re-use the registers for stage st+2, whose loads fly during this stage's compute
         if (st + 1 < nstage) stage_store<DT, KPT, VPT>(kreg, vreg, plan, nxt);
         if (st + 2 < nstage) stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
-        if constexpr (KG > 1) {
+        if constexpr (HALF) {
+            const char *sb = cur + (kg >> 1) * SUB_BYTES;       // (wave-uniform: kg comes from the wave index)
+            const int key0 = st * STAGE_KEYS + (kg >> 1) * KVBLK;
+            if (kg & 1) attn_tile<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA, 0, 1>(oacc, m_run, l_run, qf, sb, sb + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
+            else attn_tile<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA, 0, 0>(oacc, m_run, l_run, qf, sb, sb + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
+        } else if constexpr (KG > 1) {
             attn_tile<T, KS, DT, HAS_BIAS, false, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + kg * SUB_BYTES,
                                                                cur + kg * SUB_BYTES + KT::BYTES, st * STAGE_KEYS + kg * KVBLK,
                                                                p.M, l31, hi, bias, coeff, c1);
@@ -190,7 +200,14 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? KG : MinWaves<DT, NW, 
     }
     if (st < nstage) {           // ragged tail stage (already in LDS: stored by the prologue or the last iteration)
         char *cur = smem + (st & 1) * STAGE_BYTES;
-        if constexpr (KG > 1) {
+        if constexpr (HALF) {
+            const char *sb = cur + (kg >> 1) * SUB_BYTES;
+            const int key0 = st * STAGE_KEYS + (kg >> 1) * KVBLK;
+            if (key0 + (kg & 1) * 32 < p.M) {       // (a block past the last key: this key group saw nothing -- m = -inf, merged as such)
+                if (kg & 1) attn_tile<T, KS, DT, HAS_BIAS, true, ROWSUM_MFMA, 0, 1>(oacc, m_run, l_run, qf, sb, sb + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
+                else attn_tile<T, KS, DT, HAS_BIAS, true, ROWSUM_MFMA, 0, 0>(oacc, m_run, l_run, qf, sb, sb + KT::BYTES, key0, p.M, l31, hi, bias, coeff, c1);
+            }
+        } else if constexpr (KG > 1) {
             const int key0 = st * STAGE_KEYS + kg * KVBLK;
             if (key0 < p.M)
                 attn_tile<T, KS, DT, HAS_BIAS, true, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + kg * SUB_BYTES,
@@ -470,8 +487,8 @@ constexpr float FOLD_TAU = 6.f;
 // natural units: 1.3e-2 of max|O| extrapolated, inside the 1.6e-2 bar), f16 36 (= 25 natural units: <= 1.3e-3 extrapolated, inside the
 // 2e-3 bar; measured 6e-4 at row maxima of 12 - 14). The f16 reference follows the running maximum to within 2^FOLD_TAU, so its
 // final bound is min(m_ref + FOLD_TAU, m_ref + log2(row sum)) -- tight enough that logits of std 3 - 4 stay on the fast path.
-template <typename T> struct FoldLimit { static constexpr float value = 72.f; };
-template <> struct FoldLimit<f16> { static constexpr float value = 36.f; };
+// (round 6: the kernels read the limit from AttnParams::fold_limit; the host fills in FOLD_LIMIT_F16 = 48 / FOLD_LIMIT_BF16 = 56 of pww_attn_core.h --
+// re-measured, see there -- or the A/B knob's value: pww_attn.hip)
 
 template <typename T, int KS>
 __device__ __forceinline__ void fold_set_ref(typename Vec<T>::v8 (&qf)[KS], float mref, int hi, int D) {
@@ -547,7 +564,7 @@ __device__ __forceinline__ float max32(const f32x16 (&s)[2], float m) {
 }
 
 // one (possibly ragged) 64-key sub-tile
-template <typename T, int KS, int DT, bool MASKED>
+template <typename T, int KS, int DT, bool MASKED, bool RFMODE>
 __device__ __forceinline__ void fold_tile(f32x16 (&oacc)[DT], float &mref, bool first, typename Vec<T>::v8 (&qf)[KS],
                                           const char *Ks, const char *Vs, int key0, int M, int l31, int hi, int D, float ref_floor) {
     f32x16 s[1][2];
@@ -558,7 +575,7 @@ __device__ __forceinline__ void fold_tile(f32x16 (&oacc)[DT], float &mref, bool 
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[0][kb][r] = key0 + key_of(kb, r, hi) < M ? s[0][kb][r] : -INFINITY;
     }
-    if constexpr (RangeFree<T>::value) {
+    if constexpr (RFMODE) {
         if (first) fold_rereference<T, KS, DT, 1>(s, oacc, mref, qf, fmaxf(xhalf_max(max32(s[0], -INFINITY)), ref_floor) + RfHeadroom<T>::value, true, hi, D);
     } else {
         const float tmax = xhalf_max(max32(s[0], -INFINITY));   // finite: key0 < M
@@ -627,7 +644,8 @@ __device__ __forceinline__ void exp_tile(typename Vec<T>::v8 (&pf)[2][2], const 
 
 // one full 128-key stage: all K fragments and the first sub-tile's V fragments are requested up front, both
 // sub-tiles are scored, one joint reference check, then exp / PV per sub-tile
-template <typename T, int KS, int DT, int SUB_BYTES>
+// RFMODE: the reference is fixed by the first stage (range-free); else it follows the running maximum lazily (FOLD_TAU)
+template <typename T, int KS, int DT, int SUB_BYTES, bool RFMODE>
 __device__ __forceinline__ void fold_stage2(f32x16 (&oacc)[DT], float &mref, bool first, typename Vec<T>::v8 (&qf)[KS],
                                             const char *cur, int key0, int l31, int hi, int D, float ref_floor) {
     typedef typename Vec<T>::v8 V8;
@@ -642,7 +660,7 @@ __device__ __forceinline__ void fold_stage2(f32x16 (&oacc)[DT], float &mref, boo
     score_frags<T, KS>(s[1], k1, qf);
     load_vfrags<T, DT>(v1, cur + SUB_BYTES + KT::BYTES, l31, hi);   // lands during the max / check below
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (RangeFree<T>::value) {    // reference set once, from the first stage (see the header comment)
+    if constexpr (RFMODE) {    // reference set once, from the first stage (see the header comment)
         if (first) fold_rereference<T, KS, DT, 2>(s, oacc, mref, qf, fmaxf(xhalf_max(max32(s[1], max32(s[0], -INFINITY))), ref_floor) + RfHeadroom<T>::value, true, hi, D);
     } else {
         const float tmax = xhalf_max(max32(s[1], max32(s[0], -INFINITY)));
@@ -703,6 +721,19 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
     float mref = 0.f;      // softmax reference of the lane's row (exp2 domain), identical in both half-waves
     bool first = true;     // no tile processed yet: m_ref not established
     bool early = false;    // magnitude guard tripped after the first stage: skip the fast path
+    // f16 only: range-free until the first stage shows a hot row, lazily following the running maximum from then on (see the loop)
+    constexpr bool CAN_SWITCH = RangeFree<T>::value && RfHeadroom<T>::value == 0.f;
+    bool lazy = false;                               // (p.hot_sum < 0: lazy from the second stage on whatever the rows look like -- A/B)
+    auto tl_sum = [&]() -> float {     // the lane's share of row D of O^T (the running softmax denominator: the ones column of V)
+        const int rl_ = p.D & 31, tl_ = p.D >> 5;
+        float lv = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const float c = rl_ == 8 ? oacc[dt][4] : oacc[dt][12];
+            lv = dt == tl_ ? c : lv;
+        }
+        return lv;
+    };
     tl_stamp(p, 0);
 
     // padding is never staged: zero the stage buffers once, then column D of every V row = one (softmax denominator
@@ -744,13 +775,38 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
         char *nxt = smem + ((st & 1) ^ 1) * STAGE_BYTES;            // so the whole body up to the reference check is one block
         stage_store<DT, KPT, VPT>(kreg, vreg, plan, nxt);
         stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
-        fold_stage2<T, KS, DT, SUB_BYTES>(oacc, mref, first, qf, cur, st * STAGE_KEYS, l31, hi, p.D, ref_floor);
+        fold_stage2<T, KS, DT, SUB_BYTES, RangeFree<T>::value>(oacc, mref, first, qf, cur, st * STAGE_KEYS, l31, hi, p.D, ref_floor);
         first = false;
         if (st == 0) {       // magnitude guard, early form: the first stage's row maximum (m_ref minus the range-free headroom)
             const float m0 = mref - (RangeFree<T>::value ? RfHeadroom<T>::value : 0.f);
-            if (__syncthreads_or(qvalid && !(fabsf(m0) <= FoldLimit<T>::value))) { early = true; break; }
+            if (__syncthreads_or(qvalid && !(fabsf(m0) <= p.fold_limit))) { early = true; break; }
+            if constexpr (CAN_SWITCH) {
+                // HOT ROWS (round 6). The f16 range-free reference has 16 binary orders of room above the first stage's maximum: a row whose
+                // logits spread over more than that (scaled-logit std >= ~3: what trained SD layers produce) overflows P to inf at some later
+                // key, and the whole workgroup used to redo its rows on the exact path (733 us instead of 484 at 16 rows, scaled-logit std 4).
+                // The first stage says which rows those are: its row sum relative to its own maximum is the effective number of keys that
+                // carry the softmax -- ~128 e^(sigma^2 / 2 - 2.6 sigma) of the stage's 128 for logits of std sigma: 40 at 0.5, 16 at 1, 5 at 3 --
+                // and a workgroup with a row below p.hot_sum (8) follows the running maximum lazily from here on: the SECOND loop below (the
+                // FOLD_TAU reference of the non-range-free form: one max per score and stage, +8 % on that workgroup; P can no longer
+                // overflow). Two loops, not one loop with two bodies: that form spilled 350 - 480 bytes per lane.
+                const float l0 = __shfl(tl_sum(), l31);        // (row D of O^T sits in the hi == 0 half)
+                lazy = __syncthreads_or((qvalid && l0 < p.hot_sum) || p.hot_sum < 0.f) != 0;
+                if (lazy) { ++st; break; }
+            }
         } else {
             __syncthreads();
+        }
+    }
+    if constexpr (CAN_SWITCH) {
+        if (lazy && !early) {
+            for (; st < nfull; ++st) {
+                char *cur = smem + (st & 1) * STAGE_BYTES;
+                char *nxt = smem + ((st & 1) ^ 1) * STAGE_BYTES;
+                stage_store<DT, KPT, VPT>(kreg, vreg, plan, nxt);
+                stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
+                fold_stage2<T, KS, DT, SUB_BYTES, false>(oacc, mref, false, qf, cur, st * STAGE_KEYS, l31, hi, p.D, ref_floor);
+                __syncthreads();
+            }
         }
     }
     if (st < nstage && !early) {           // ragged tail stage (already in LDS)
@@ -759,8 +815,10 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
         for (int sub = 0; sub < NSUB; ++sub) {
             const int key0 = st * STAGE_KEYS + sub * KVBLK;
             if (key0 < p.M) {
-                fold_tile<T, KS, DT, true>(oacc, mref, first, qf, cur + sub * SUB_BYTES, cur + sub * SUB_BYTES + KT::BYTES,
-                                           key0, p.M, l31, hi, p.D, ref_floor);
+                if (CAN_SWITCH ? lazy : !RangeFree<T>::value)
+                    fold_tile<T, KS, DT, true, false>(oacc, mref, first, qf, cur + sub * SUB_BYTES, cur + sub * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, p.D, ref_floor);
+                else
+                    fold_tile<T, KS, DT, true, true>(oacc, mref, first, qf, cur + sub * SUB_BYTES, cur + sub * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, p.D, ref_floor);
                 first = false;
             }
         }
@@ -790,9 +848,11 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
 #pragma unroll
             for (int r = 0; r < 16; ++r) asum += fabsf(oacc[dt][r]);     // inf or NaN anywhere makes the comparison below false
         float est_max = mref + __builtin_amdgcn_logf(lsum);              // v_log_f32 = log2
-        if (!RangeFree<T>::value) est_max = fminf(est_max, mref + FOLD_TAU);       // the lazy reference is never more than 2^FOLD_TAU below a score
-        const bool bad = qvalid && !(lsum > 0.f && lsum < 3.0e38f && asum < 3.0e38f && fabsf(est_max) <= FoldLimit<T>::value);
-        if (early || __syncthreads_or(bad)) {
+        if (!RangeFree<T>::value || lazy) est_max = fminf(est_max, mref + FOLD_TAU);       // the lazy reference is never more than 2^FOLD_TAU below a score
+        const bool bad = qvalid && !(lsum > 0.f && lsum < 3.0e38f && asum < 3.0e38f && fabsf(est_max) <= p.fold_limit);
+        const bool redo = early || __syncthreads_or(bad);
+        if (p.path_counts && threadIdx.x == 0) atomicAdd(p.path_counts + (redo ? 2 : lazy ? 1 : 0), 1u);     // debug: which path this workgroup took
+        if (redo) {
             float l_unused;
             exact_rows<T, KS, DT, NSUB, true, KPT, VPT>(oacc, l_unused, p, Qp + (long)qrow * p.q_sn, qvalid, smem, plan, srd_k, srd_v, k_step, v_step, l31, hi);
             float lv = 0.f;
@@ -852,13 +912,15 @@ static int launch_attn_rs(const AttnParams &p, hipStream_t stream) {
 
 // key-split workgroups: NW row groups x KG key groups, KG*64-key stages (self-attention launches too small to give
 // every SIMD a wave otherwise): d <= 64 uses 4 x 3 = 12 waves, d = 80/96 uses 2 x 2 = 4 waves
-template <typename T, int KS, int DT, int NW, int KG, bool ROWSUM_MFMA>
+// NSUB = KG: every key group owns a 64-key sub-tile of a stage; NSUB = KG / 2 (round 6): a 32-key block of one
+template <typename T, int KS, int DT, int NW, int KG, bool ROWSUM_MFMA, int NSUB = KG>
 static int launch_attn_ksplit(const AttnParams &p, hipStream_t stream) {
-    constexpr size_t stage = KG * (KTile<KS>::BYTES + VTile<DT>::BYTES);
+    constexpr size_t stage = NSUB * (KTile<KS>::BYTES + VTile<DT>::BYTES);
     constexpr size_t merge = (size_t)(KG - 1) * NW * (DT * 16 + 2) * 64 * sizeof(float);
     constexpr size_t lds = 2 * stage > merge ? 2 * stage : merge;
+    static_assert(lds <= 160 * 1024, "stage buffers / merge records of the key-split workgroup");
     const int qblocks = (p.N + NW * 32 - 1) / (NW * 32);
-    auto kern = attn_fwd_kernel<T, KS, DT, NW, KG, KG, false, ROWSUM_MFMA>;
+    auto kern = attn_fwd_kernel<T, KS, DT, NW, NSUB, KG, false, ROWSUM_MFMA>;
     static thread_local bool done = false;
     if (!done) {
         if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
@@ -964,6 +1026,11 @@ static int launch_attn(const AttnParams &p, hipStream_t stream) {
                 return launch_attn_ksplit<T, KS, DT, 4, 2, false>(p, stream);
             }
 #endif
+            if (debug_knobs().attn_ksplit_half) {
+                // (round 6) 2 row groups x 4 key groups of HALF a sub-tile each on the same 128-key stages: 8 waves, two per SIMD
+                if ((p.D & 31) != 0) return launch_attn_ksplit<T, KS, DT, 2, 4, true, 2>(p, stream);
+                return launch_attn_ksplit<T, KS, DT, 2, 4, false, 2>(p, stream);
+            }
             if ((p.D & 31) != 0) return launch_attn_ksplit<T, KS, DT, 2, 2, true>(p, stream);
             return launch_attn_ksplit<T, KS, DT, 2, 2, false>(p, stream);
         }

@@ -28,13 +28,15 @@ namespace pww {
 // ------------------------------------------------------------------------------------------------------------------------------------
 // qk_parts: statistic partials over a finished Q
 // ------------------------------------------------------------------------------------------------------------------------------------
+// Kernel arguments in two parts (round 6). HOT: what the wave needs to issue its first loads -- 14 dwords, passed as
+// leading scalar arguments so that the dispatcher preloads them into SGPRs (this unit is compiled with -mllvm
+// -amdgpu-kernarg-preload-count=16; a by-value struct is never preloaded): the wave does not start with a dependent s_load round trip to a
+// cold kernarg segment. COLD (this struct): what is looked at after the MFMAs -- fetched by an s_load that has the loads' latency to land.
 struct QkPartsParams {
-    const void *q, *k;
     const float *gate;        // [B] or null
     double *partials;         // [B][nparts][4]
-    int B, H, N, M, D;
-    long q_sb, q_sh, q_sn, k_sb, k_sh, k_sm;
-    int nrb, nkb, nparts;     // 32-row blocks, 32-key blocks, partials per image = H * nrb * nkb
+    int B, H;
+    int nparts;               // partials per image = H * nrb * nkb (fine) / H * ceil(nrb / 4) (coarse)
     int n_img;                // images the grid covers (the hinted-in ones first)
     int fields;               // bit 0 max, 1 min, 2 sum, 3 sum of squares
 };
@@ -48,39 +50,42 @@ struct QkPartsParams {
 constexpr int QKP_MAX_FINE = 256;
 
 template <typename T, int KS, bool COARSE>
-__global__ void __launch_bounds__(256) qk_parts_kernel(const QkPartsParams p) {
+__global__ void __launch_bounds__(256) qk_parts_kernel(const void *q_, const void *k_, int q_sb, int q_sh, int q_sn, int k_sb, int k_sh, int k_sm,
+                                                       int N, int M, int D, int blocks, const QkPartsParams p) {
+    // (14 dwords is what the dispatcher preloads: 16 user SGPRs less the kernarg pointer) blocks = 32-row blocks << 3 | 32-key blocks (<= 4)
+    const int nrb = blocks >> 3, nkb = blocks & 7;
     typedef typename Vec<T>::v8 V8;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.z, h = blockIdx.y;
-    const float gate = p.gate ? p.gate[b] : 1.f;                  // requested with everything else, looked at before the store
-    const T *Qp = reinterpret_cast<const T *>(p.q) + b * p.q_sb + h * p.q_sh;
-    const T *Kp = reinterpret_cast<const T *>(p.k) + b * p.k_sb + h * p.k_sh;
-    const auto srd_q = head_srd(Qp, p.N, p.q_sn, p.D);
-    const auto srd_k = head_srd(Kp, p.M, p.k_sm, p.D);
+    const T *Qp = reinterpret_cast<const T *>(q_) + (long)b * q_sb + (long)h * q_sh;
+    const T *Kp = reinterpret_cast<const T *>(k_) + (long)b * k_sb + (long)h * k_sh;
+    const auto srd_q = head_srd(Qp, N, q_sn, D);
+    const auto srd_k = head_srd(Kp, M, k_sm, D);
     int rb, kb0;
     if constexpr (COARSE) { rb = blockIdx.x * 4 + wave; kb0 = 0; }
     else {
         const int f = blockIdx.x * 4 + wave;          // (row block, key block), key blocks fastest; nkb <= 4: divisions by constants
-        rb = p.nkb == 3 ? f / 3 : p.nkb == 2 ? f >> 1 : p.nkb == 4 ? f >> 2 : f;
-        kb0 = f - rb * p.nkb;
-        if (rb >= p.nrb) return;                      // (wave-uniform; the fine form has no barrier)
+        rb = nkb == 3 ? f / 3 : nkb == 2 ? f >> 1 : nkb == 4 ? f >> 2 : f;
+        kb0 = f - rb * nkb;
+        if (rb >= nrb) return;                        // (wave-uniform; the fine form has no barrier)
     }
     const int qrow = rb * 32 + l31;
-    const bool rvalid = qrow < p.N;                   // (COARSE: a row block past the last one only contributes neutral elements)
-    const unsigned k_lane = (unsigned)((long)swap23(l31) * p.k_sm * 2), k_blk = (unsigned)(32 * p.k_sm * 2);
+    const bool rvalid = qrow < N;                     // (COARSE: a row block past the last one only contributes neutral elements)
+    const unsigned k_lane = (unsigned)((long)swap23(l31) * k_sm * 2), k_blk = (unsigned)(32 * k_sm * 2);
     // rows past N / keys past M lie beyond the descriptors: zeros, no memory traffic, no compare on the way to the load
     V8 qf[KS], kf[2][KS];
-    load_q_frags_buf<T, KS>(qf, srd_q, (unsigned)((long)qrow * p.q_sn * 2), hi, p.D);
-    load_q_frags_buf<T, KS>(kf[0], srd_k, k_lane + (unsigned)kb0 * k_blk, hi, p.D);
+    load_q_frags_buf<T, KS>(qf, srd_q, (unsigned)((long)qrow * q_sn * 2), hi, D);
+    load_q_frags_buf<T, KS>(kf[0], srd_k, k_lane + (unsigned)kb0 * k_blk, hi, D);
+    const float gate = p.gate ? p.gate[b] : 1.f;      // (the cold arguments: requested behind the loads above, looked at before the store)
     float vmax = -INFINITY, vmin = INFINITY;
     double dsum = 0.0, dsq = 0.0;
     constexpr int NKB = COARSE ? 4 : 1;
 #pragma unroll
     for (int i = 0; i < NKB; ++i) {
         const int kb = kb0 + i;
-        if (COARSE && i + 1 < NKB) load_q_frags_buf<T, KS>(kf[(i + 1) & 1], srd_k, k_lane + (unsigned)(kb + 1) * k_blk, hi, p.D);
-        if (!COARSE || kb < p.nkb) {                  // (wave-uniform)
+        if (COARSE && i + 1 < NKB) load_q_frags_buf<T, KS>(kf[(i + 1) & 1], srd_k, k_lane + (unsigned)(kb + 1) * k_blk, hi, D);
+        if (!COARSE || kb < nkb) {                  // (wave-uniform)
             f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -91,7 +96,7 @@ __global__ void __launch_bounds__(256) qk_parts_kernel(const QkPartsParams p) {
             float usum = 0.f, usq = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const bool live = rvalid && kb * 32 + 16 * (r >> 3) + 8 * hi + (r & 7) < p.M;
+                const bool live = rvalid && kb * 32 + 16 * (r >> 3) + 8 * hi + (r & 7) < M;
                 const float x = s[r];
                 vmax = fmaxf(vmax, live ? x : -INFINITY);
                 vmin = fminf(vmin, live ? x : INFINITY);
@@ -132,7 +137,7 @@ __global__ void __launch_bounds__(256) qk_parts_kernel(const QkPartsParams p) {
             out[3] = (p.fields & 8) ? sq : 0.0;
         }
     } else if (lane == 0 && gate != 0.f) {       // (a gated-out image's rows are left untouched, like pww_qproj_stat)
-        double *out = p.partials + ((long)b * p.nparts + ((long)h * p.nrb + rb) * p.nkb + kb0) * 4;
+        double *out = p.partials + ((long)b * p.nparts + ((long)h * nrb + rb) * nkb + kb0) * 4;
         out[0] = (p.fields & 1) ? (double)vmax : -INFINITY;
         out[1] = (p.fields & 2) ? (double)vmin : INFINITY;
         out[2] = (p.fields & 4) ? dsum : 0.0;
@@ -184,21 +189,24 @@ int qk_parts(const void *q, const void *k, const float *gate, const pww_attn_des
         return PWW_EINVAL;
     }
     if (partials_bytes < (size_t)d->B * nparts * 4 * sizeof(double)) { set_error("qk_parts: partials buffer too small (need %zu bytes)", (size_t)d->B * nparts * 4 * sizeof(double)); return PWW_EINVAL; }
+    for (int i = 0; i < 3; ++i)
+        if (d->q_stride[i] >= (1L << 31) || d->k_stride[i] >= (1L << 31) || d->q_stride[i] < 0 || d->k_stride[i] < 0) { set_error("qk_parts: strides must be below 2^31 elements"); return PWW_ENOTSUP; }
     QkPartsParams p;
-    p.q = q; p.k = k; p.gate = gate; p.partials = partials;
-    p.B = d->B; p.H = d->H; p.N = d->N; p.M = d->M; p.D = d->D;
-    p.q_sb = d->q_stride[0]; p.q_sh = d->q_stride[1]; p.q_sn = d->q_stride[2];
-    p.k_sb = d->k_stride[0]; p.k_sh = d->k_stride[1]; p.k_sm = d->k_stride[2];
-    p.nrb = (d->N + 31) / 32; p.nkb = (d->M + 31) / 32; p.nparts = nparts;
+    p.gate = gate; p.partials = partials;
+    p.B = d->B; p.H = d->H; p.nparts = nparts;
+    const int nrb = (d->N + 31) / 32, nkb = (d->M + 31) / 32;
     p.n_img = (gate && gated_images > 0 && gated_images < d->B) ? gated_images : d->B;
     p.fields = fields;
     if (d->H > 65535 || p.n_img > 65535) { set_error("qk_parts: more than 65535 heads or images"); return PWW_ENOTSUP; }
     const bool coarse = qk_parts_coarse(d);
-    const dim3 grid(coarse ? (unsigned)((p.nrb + 3) / 4) : (unsigned)(((long)p.nrb * p.nkb + 3) / 4), (unsigned)d->H, (unsigned)p.n_img);
+    const dim3 grid(coarse ? (unsigned)((nrb + 3) / 4) : (unsigned)(((long)nrb * nkb + 3) / 4), (unsigned)d->H, (unsigned)p.n_img);
+    // the 14 hot dwords first (preloaded into SGPRs by the dispatcher), the cold struct behind them
+#define PWW_QKP_ARGS q, k, (int)d->q_stride[0], (int)d->q_stride[1], (int)d->q_stride[2], (int)d->k_stride[0], (int)d->k_stride[1], (int)d->k_stride[2], \
+                     (int)d->N, (int)d->M, (int)d->D, (nrb << 3) | nkb, p
 #define PWW_QKP1(T, KSV)                                                                                          \
     do {                                                                                                           \
-        if (coarse) launch_attn_kernel(qk_parts_kernel<T, KSV, true>, grid, dim3(256), 0, stream, p);             \
-        else launch_attn_kernel(qk_parts_kernel<T, KSV, false>, grid, dim3(256), 0, stream, p);                   \
+        if (coarse) launch_timed(qk_parts_kernel<T, KSV, true>, grid, dim3(256), 0, stream, PWW_QKP_ARGS);        \
+        else launch_timed(qk_parts_kernel<T, KSV, false>, grid, dim3(256), 0, stream, PWW_QKP_ARGS);              \
     } while (0)
 #define PWW_QKP(T)                                      \
     do {                                                \
@@ -213,6 +221,7 @@ int qk_parts(const void *q, const void *k, const float *gate, const pww_attn_des
     if (d->dtype == PWW_DTYPE_F16) PWW_QKP(f16); else PWW_QKP(bf16);
 #undef PWW_QKP
 #undef PWW_QKP1
+#undef PWW_QKP_ARGS
     return check_hip(hipGetLastError(), "qk_parts_kernel launch");
 }
 

@@ -77,13 +77,14 @@ __device__ __forceinline__ void ktile_store(const u32x4 (&kreg)[KPT], char *Ks, 
 // front of each MFMA -- compiles to read -> s_waitcnt lgkmcnt(0) -> MFMA per k-step (hipcc re-uses one register quad for all the
 // fragments): 2 KS exposed LDS latencies per tile, which is what a tile cost at one wave per SIMD (the N <= 1024 self-attention and
 // every cross-attention launch at 2 folded rows: ~3000 cycles per tile for ~700 cycles of MFMA). Same MFMAs in the same order: bit-identical scores.
-template <typename T, int KS>
+// ONLY = 0 / 1: just that 32-key block of the tile (key-split workgroups whose key groups own HALF a tile each); -1: both.
+template <typename T, int KS, int ONLY = -1>
 __device__ __forceinline__ void score_tile(f32x16 (&s)[2], const typename Vec<T>::v8 (&qf)[KS],
                                            const char *Ks, int key0, int M, int l31, int hi) {
     typedef typename Vec<T>::v8 V8;
     typedef KTile<KS> KT;
     const char *base = Ks + swap23(l31) * KT::STRIDE + hi * 16;
-    const bool live0 = key0 < M, live1 = key0 + 32 < M;      // wave-uniform
+    const bool live0 = ONLY != 1 && key0 < M, live1 = ONLY != 0 && key0 + 32 < M;      // wave-uniform
     V8 kf[2][KS];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {

@@ -23,7 +23,7 @@ MAX_HEAD_DIM = 160
 EXPORTS = ("pww_version", "pww_has_experiments", "pww_last_error", "pww_device_arch", "pww_self_attn_fwd", "pww_cross_attn_fwd",
            "pww_cross_attn_fwd_stat", "pww_cross_attn_fwd_stat_ex",
            "pww_qk_reduce", "pww_mask_build", "pww_mask_build_rgb", "pww_mask_build_f32", "pww_resize_tokens", "pww_gauss_blur", "pww_inpaint_prep", "pww_cfg_combine", "pww_store_f32",
-           "pww_workspace_bytes", "pww_profile_arm", "pww_profile_elapsed_us", "pww_profile_reset", "pww_debug_timeline",
+           "pww_workspace_bytes", "pww_profile_arm", "pww_profile_elapsed_us", "pww_profile_reset", "pww_debug_timeline", "pww_debug_path_counts",
            "pww_qproj_stat", "pww_qproj_parts", "pww_cross_attn_fwd_parts", "pww_mask_build_f32_levels", "pww_qk_parts", "pww_qk_parts_count",
            "pww_group_norm_fwd", "pww_group_norm_workspace_bytes", "pww_add_layer_norm", "pww_add_layer_norm_bias", "pww_geglu", "pww_bias_residual")
 # ... and what only libpww_hip_experiments.so has on top of them (the header's "experiments" section)
@@ -116,6 +116,8 @@ def _bind(lib, experiments):
     lib.pww_bias_residual.restype = ctypes.c_int
     lib.pww_debug_timeline.argtypes = [vp, ctypes.c_size_t]
     lib.pww_debug_timeline.restype = None
+    lib.pww_debug_path_counts.argtypes = [vp]
+    lib.pww_debug_path_counts.restype = None
     lib.pww_qk_reduce.argtypes = [vp, vp, ctypes.POINTER(AttnDesc), vp, vp, ctypes.c_size_t, vp]
     lib.pww_mask_build.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.pww_mask_build_rgb.argtypes = [vp, i32, i32, vp, i32, vp, vp, i32, i32, vp, vp]

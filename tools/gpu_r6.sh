@@ -42,6 +42,28 @@ configs)
     timeout 900 python bench.py --config $c --steps 1 --warmup 1 --cpu-steps 0 --no-reference-ops --no-live-counters > $O/r6_bench_c$c.json 2> $O/r6_bench_c$c.log; summ $O/r6_bench_c$c.json
   done
   ;;
+k1route)
+  # pww_qproj_stat (K1) at 2 rows against the stock to_q GEMM + pww_qk_parts, end to end, alternating runs on ONE box
+  rm -f $O/r6_k1route.txt
+  for i in 1 2 3; do for v in 1 0; do
+    PWW_QPROJ_STAT=$v timeout 300 python bench.py --steps 6 --warmup 1 --no-roofline-pass --no-reference-ops --cpu-steps 0 2> /dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('PWW_QPROJ_STAT=$v', d['value'], d['ms_per_step'])" | tee -a $O/r6_k1route.txt
+  done; done
+  ;;
+cold)
+  # what a small launch costs over operands that are not L2-resident (rotating buffer sets)
+  timeout 600 python tools/time_cold_start.py 2>&1 | grep "^|" | tee $O/r6_cold_start.md
+  ;;
+hot)
+  # the fp16 dominant launch on hot logits -- shipped / round 5's behaviour / always lazy / a raised magnitude-guard limit
+  rm -f $O/r6_hot.md
+  for v in "" "attn_hot_sum=0" "attn_hot_sum=-1" "attn_fold_limit_f16=44" "attn_fold_limit_f16=52"; do PWW_DEBUG="$v" timeout 600 python tools/diag_hot_f16.py 2>&1 | grep "^|" | tee -a $O/r6_hot.md; echo >> $O/r6_hot.md; done
+  ;;
+smallself)
+  # self-attention N = 1024 d = 80 at 2 rows: 2 x 4 half-tile key groups (default) against round 5's 2 x 2
+  rm -f $O/r6_smallself.md
+  for v in "" "attn_ksplit_half=0"; do PWW_DEBUG="$v" timeout 300 python tools/time_small_attn.py self --out $O/r6_smallself.md 2>&1 | grep -v amdgpu.ids | tail -6; done
+  timeout 600 python -m pytest tests/test_round5_gpu.py tests/test_attention_gpu.py -m gpu -q -x -k "small_self or self or attention" 2>&1 | grep -v amdgpu.ids | tail -5
+  ;;
 *) if [ -f "tools/gpu_r6_$stage.sh" ]; then bash tools/gpu_r6_$stage.sh; else echo "unknown stage $stage"; fi;;
 esac
 done
