@@ -17,7 +17,9 @@ template <> struct RangeFree<f16> { static constexpr bool value = true; };     /
 template <typename T, int KS, int DT, int NSUB, bool ROWSUM_MFMA, int KPT, int VPT, typename SRD>
 __device__ __forceinline__ void exact_rows(f32x16 (&oacc)[DT], float &l_run, const AttnParams &p, const T *qrow_ptr, bool qvalid, char *smem,
                                         const StagePlan<KPT, VPT> &plan, SRD srd_k, SRD srd_v, unsigned k_step, unsigned v_step,
-                                        int l31, int hi) {
+                                        int l31, int hi, bool active = true) {
+    // `active` (wave-uniform): this wave has a row to redo. A wave without one keeps its finished O^T and only helps staging K / V (round 6:
+    // at the 2 folded rows of the headline ONE workgroup on this path is the launch's tail -- 8 waves recomputing 256 rows for one bad row).
     typedef typename Vec<T>::v8 V8;
     typedef KTile<KS> KT;
     typedef VTile<DT> VT;
@@ -25,13 +27,15 @@ __device__ __forceinline__ void exact_rows(f32x16 (&oacc)[DT], float &l_run, con
     constexpr int STAGE_BYTES = NSUB * SUB_BYTES;
     constexpr int STAGE_KEYS = NSUB * KVBLK;
     V8 qf[KS];
-    load_q_frags<T, KS>(qf, qrow_ptr, qvalid, hi, p.D);
+    load_q_frags<T, KS>(qf, qrow_ptr, qvalid && active, hi, p.D);
+    if (active) {
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+        for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+            for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+        l_run = 0.f;
+    }
     float m_run = -INFINITY;
-    l_run = 0.f;
     BiasRef bias;
     const float c1 = p.scale_log2e;
     const int nstage = (p.M + STAGE_KEYS - 1) / STAGE_KEYS, nfull = p.M / STAGE_KEYS;
@@ -47,10 +51,12 @@ __device__ __forceinline__ void exact_rows(f32x16 (&oacc)[DT], float &l_run, con
         char *cur = smem + (st & 1) * STAGE_BYTES;
         stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem + ((st & 1) ^ 1) * STAGE_BYTES);
         stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
+        if (active) {
 #pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub)
-            attn_tile<T, KS, DT, false, false, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES, cur + sub * SUB_BYTES + KT::BYTES,
-                                                     st * STAGE_KEYS + sub * KVBLK, p.M, l31, hi, bias, 1.f, c1);
+            for (int sub = 0; sub < NSUB; ++sub)
+                attn_tile<T, KS, DT, false, false, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES, cur + sub * SUB_BYTES + KT::BYTES,
+                                                         st * STAGE_KEYS + sub * KVBLK, p.M, l31, hi, bias, 1.f, c1);
+        }
         __syncthreads();
     }
     if (st < nstage) {
@@ -58,7 +64,7 @@ __device__ __forceinline__ void exact_rows(f32x16 (&oacc)[DT], float &l_run, con
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
             const int key0 = st * STAGE_KEYS + sub * KVBLK;
-            if (key0 < p.M)
+            if (key0 < p.M && active)
                 attn_tile<T, KS, DT, false, true, ROWSUM_MFMA>(oacc, m_run, l_run, qf, cur + sub * SUB_BYTES, cur + sub * SUB_BYTES + KT::BYTES,
                                                         key0, p.M, l31, hi, bias, 1.f, c1);
         }
@@ -135,16 +141,6 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? (NW * KG >= 12 ? 3 : 2
     float l_run = 0.f;        // running row sum (VALU path only), PARTIAL per half-wave
     float mc = 0.f;           // RF: -(reference * c1) - headroom, set by the row's first tile
 
-    // head-dim padding columns are never staged: zero both buffers once; with ROWSUM_MFMA column D of every
-    // V row is one (the PV MFMA then accumulates the softmax denominator in O^T row D)
-    for (int i = tid * 16; i < 2 * STAGE_BYTES; i += NT * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0u, 0u, 0u, 0u};
-    __syncthreads();
-    if (ROWSUM_MFMA) {
-        const T one = (T)1.0f;
-        for (int i = tid; i < 2 * NSUB * KVBLK; i += NT)
-            *reinterpret_cast<T *>(smem + (i >> 6) * SUB_BYTES + KT::BYTES + (i & 63) * VT::STRIDE + p.D * 2) = one;
-    }
-
     StagePlan<KPT, VPT> plan;
     make_plan<T, KS, DT, NT, NSUB, KPT, VPT>(plan, tid, p.D, p.k_sm, p.v_sm);
     const auto srd_k = head_srd(Kp, p.M, p.k_sm, p.D);
@@ -154,14 +150,32 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? (NW * KG >= 12 ? 3 : 2
     u32x4 vreg[VPT];
     const int nstage = (p.M + STAGE_KEYS - 1) / STAGE_KEYS;
     const int nfull = p.M / STAGE_KEYS;                 // stages without any key >= M
+    // prologue: the first stage's global loads are issued BEFORE anything touches LDS (round 6: they used to wait behind a zero fill of
+    // both buffers and its barrier -- 94 KB of LDS stores at d = 80 for 8 KB of padding)
+    stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);
+    // Head-dim padding is never staged: the 16-byte chunks past D of every K / V row of both buffers are zeroed once, here, and with
+    // ROWSUM_MFMA column D of every V row is one (the PV MFMA then accumulates the softmax denominator in O^T row D). Only the padding
+    // chunks are written -- the staged chunks (c * 8 < D) are disjoint from them, so no barrier separates this from the first stage_store;
+    // head dims without padding (64, 96, 128, 160) write nothing.
+    {
+        const int c0 = p.D >> 3;
+        constexpr int NROW = 2 * NSUB * KVBLK;
+        const T one = (T)1.0f;
+        unsigned short one_bits;
+        __builtin_memcpy(&one_bits, &one, 2);
+        for (int c = c0; c < KT::CHK; ++c)
+            for (int r = tid; r < NROW; r += NT) *reinterpret_cast<u32x4 *>(smem + (r >> 6) * SUB_BYTES + (r & 63) * KT::STRIDE + c * 16) = u32x4{0u, 0u, 0u, 0u};
+        for (int c = c0; c < VT::CHK; ++c)
+            for (int r = tid; r < NROW; r += NT)
+                *reinterpret_cast<u32x4 *>(smem + (r >> 6) * SUB_BYTES + KT::BYTES + (r & 63) * VT::STRIDE + c * 16) = (ROWSUM_MFMA && c == c0) ? u32x4{(unsigned)one_bits, 0u, 0u, 0u} : u32x4{0u, 0u, 0u, 0u};
+    }
     // f16 range-free mode: the reference is floored by the row's self-logit (self_logit, pww_attn_core.h); raw-score domain here
     float ref_floor = -INFINITY;
     if constexpr (RF && RfHeadroom<T>::value == 0.f) {
         if (p.M == p.N) { const float sl = self_logit<T, KS>(qf, Kp + (long)qrow * p.k_sm, qvalid, hi, p.D); ref_floor = qvalid ? sl : -INFINITY; }
     }
 
-    // prologue: first stage -> buffer 0, second stage -> registers
-    stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);
+    // first stage -> buffer 0, second stage -> registers
     stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
     if (nstage > 1) stage_load(kreg, vreg, plan, srd_k, srd_v, k_step, v_step);
     __syncthreads();
@@ -290,7 +304,7 @@ __global__ void __launch_bounds__(NW * KG * 64, (KG > 1 ? (NW * KG >= 12 ? 3 : 2
         const bool bad = qvalid && !(l_tot > 0.f && l_tot < 3.0e38f && asum < 3.0e38f);
         if (__syncthreads_or(bad)) {
             exact_rows<T, KS, DT, NSUB, ROWSUM_MFMA, KPT, VPT>(oacc, l_run, p, Qp + (long)qrow * p.q_sn, qvalid, smem, plan, srd_k, srd_v,
-                                                                k_step, v_step, l31, hi);
+                                                                k_step, v_step, l31, hi, __any(bad));      // (only the waves that hold such a row recompute)
             l_tot = row_sum();
         }
     }
@@ -854,7 +868,10 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
         if (p.path_counts && threadIdx.x == 0) atomicAdd(p.path_counts + (redo ? 2 : lazy ? 1 : 0), 1u);     // debug: which path this workgroup took
         if (redo) {
             float l_unused;
-            exact_rows<T, KS, DT, NSUB, true, KPT, VPT>(oacc, l_unused, p, Qp + (long)qrow * p.q_sn, qvalid, smem, plan, srd_k, srd_v, k_step, v_step, l31, hi);
+            // after a COMPLETE fast pass only the waves that hold a bad row recompute (the others keep their results and help staging);
+            // the early exit left every wave without a result
+            const bool wave_redo = early || __any(bad);
+            exact_rows<T, KS, DT, NSUB, true, KPT, VPT>(oacc, l_unused, p, Qp + (long)qrow * p.q_sn, qvalid, smem, plan, srd_k, srd_v, k_step, v_step, l31, hi, wave_redo);
             float lv = 0.f;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
@@ -1026,11 +1043,14 @@ static int launch_attn(const AttnParams &p, hipStream_t stream) {
                 return launch_attn_ksplit<T, KS, DT, 4, 2, false>(p, stream);
             }
 #endif
+#if PWW_EXPERIMENTS
             if (debug_knobs().attn_ksplit_half) {
-                // (round 6) 2 row groups x 4 key groups of HALF a sub-tile each on the same 128-key stages: 8 waves, two per SIMD
+                // (round 6, measured a TIE: profiles/r06_small_attn.md) 2 row groups x 4 key groups of HALF a sub-tile each on the same 128-key
+                // stages: 8 waves, two per SIMD -- the key loop gets 7 % shorter (9.6 against 10.3 us), the merge of four partial states 0.8 us longer
                 if ((p.D & 31) != 0) return launch_attn_ksplit<T, KS, DT, 2, 4, true, 2>(p, stream);
                 return launch_attn_ksplit<T, KS, DT, 2, 4, false, 2>(p, stream);
             }
+#endif
             if ((p.D & 31) != 0) return launch_attn_ksplit<T, KS, DT, 2, 2, true>(p, stream);
             return launch_attn_ksplit<T, KS, DT, 2, 2, false>(p, stream);
         }

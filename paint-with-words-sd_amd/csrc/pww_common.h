@@ -71,7 +71,7 @@ struct DebugKnobs {
     int attn_ksplit1 = 0;          // 1: the small self-attention launches (N >= 512 at d = 80 / 96, N >= 128 at d = 128 / 160) on the single-buffered key-split kernel of round 5 (measured slower: default off)
     int attn_hot_sum = 8;          // f16 d = 40 self-attention: a workgroup whose first key stage leaves a row sum below this follows the running maximum lazily (0: never -- round 5; -1: always)
     int attn_fold_limit_f16 = 0;   // > 0: overrides the f16 magnitude-guard limit of the folded-reference kernel (exp2 units; built-in 36)
-    int attn_ksplit_half = 1;      // d = 80 / 96 key-split self-attention: 1 = 2 row groups x 4 key groups of a 32-key block each (8 waves, round 6) / 0 = 2 x 2 of a 64-key sub-tile each
+    int attn_ksplit_half = 0;      // (experiments library) d = 80 / 96 key-split self-attention: 1 = 2 row groups x 4 key groups of a 32-key block each (8 waves, round 6: a tie) / 0 = 2 x 2 of a 64-key sub-tile each
     int attn_ksplit_nw = 2;        // row groups of the key-split d = 80 / 96 self-attention workgroup: 2 (x 2 key groups) or 4 (x 2)
 };
 const DebugKnobs &debug_knobs();

@@ -49,6 +49,10 @@ k1route)
     PWW_QPROJ_STAT=$v timeout 300 python bench.py --steps 6 --warmup 1 --no-roofline-pass --no-reference-ops --cpu-steps 0 2> /dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('PWW_QPROJ_STAT=$v', d['value'], d['ms_per_step'])" | tee -a $O/r6_k1route.txt
   done; done
   ;;
+halftl)
+  # time line of the N = 1024 d = 80 self-attention, 2 x 4 half-tile key groups against 2 x 2
+  (cd tests/native && for v in "" "attn_ksplit_half=0"; do echo "PWW_DEBUG=$v"; PWW_DEBUG="$v" timeout 120 ./attn_check --timeline --only sd15_self_n1024_d80 2>&1 | grep "^TIMELINE\|^PASS\|^FAIL"; done) | tee $O/r6_half_timeline.log | cut -c1-220
+  ;;
 cold)
   # what a small launch costs over operands that are not L2-resident (rotating buffer sets)
   timeout 600 python tools/time_cold_start.py 2>&1 | grep "^|" | tee $O/r6_cold_start.md
