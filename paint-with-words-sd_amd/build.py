@@ -31,14 +31,15 @@ EXPERIMENT_UNITS = [("pww_cross_out.hip", [], "")]      # sources only the exper
 SOURCES = sorted({u[0] for u in UNITS + EXPERIMENT_UNITS})
 HEADERS = ["pww_common.h", "pww_tile.h", "pww_attn_core.h", "pww_attn_kernel.h", "pww_cross_tile.h", "pww_cross_kernel.h", os.path.join(REPO, "include", "pww_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -amdgpu-kernarg-preload-count=16: the leading SCALAR arguments of a kernel (<= 14 dwords: 16 user SGPRs less the kernarg pointer) are preloaded
+# into SGPRs by the dispatcher instead of fetched by the wave's first s_load (gfx950 supports kernarg preload; the compiler keeps a compatibility
+# prologue for firmware that does not). Kernels that take one by-value struct are unaffected; the small kernels pass their hot arguments first.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
-         "-Wno-unused-function"]
+         "-Wno-unused-function", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 # pww_mask.hip restates fp32 formulas that must match the CPU oracle bit for bit: no FMA contraction.
-# pww_cross_lean.hip: the leading scalar arguments of its kernels (<= 16 dwords) are preloaded into SGPRs by the dispatcher instead of fetched by
-# the wave's first s_load (gfx950 supports kernarg preload; the compiler keeps a compatibility prologue for firmware that does not).
-PER_FILE_FLAGS = {"pww_mask.hip": ["-ffp-contract=off"], "pww_cross_lean.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=16"]}
+PER_FILE_FLAGS = {"pww_mask.hip": ["-ffp-contract=off"]}
 
 
 def _newer(target, deps):

@@ -750,19 +750,6 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
     };
     tl_stamp(p, 0);
 
-    // padding is never staged: zero the stage buffers once, then column D of every V row = one (softmax denominator
-    // from the PV MFMA) and column D of every K row = one (the folded -m_ref term of the score MFMA)
-    constexpr int NBUF = 2;
-    for (int i = tid * 16; i < NBUF * STAGE_BYTES; i += NT * 16) *reinterpret_cast<u32x4 *>(smem + i) = u32x4{0u, 0u, 0u, 0u};
-    __syncthreads();
-    {
-        const T one = (T)1.0f;
-        for (int i = tid; i < NBUF * NSUB * KVBLK; i += NT) {
-            *reinterpret_cast<T *>(smem + (i >> 6) * SUB_BYTES + KT::BYTES + (i & 63) * VT::STRIDE + p.D * 2) = one;
-            *reinterpret_cast<T *>(smem + (i >> 6) * SUB_BYTES + (i & 63) * KT::STRIDE + p.D * 2) = one;
-        }
-    }
-
     StagePlan<KPT, VPT> plan;
     make_plan<T, KS, DT, NT, NSUB, KPT, VPT>(plan, tid, p.D, p.k_sm, p.v_sm);
     const auto srd_k = head_srd(Kp, p.M, p.k_sm, p.D);
@@ -772,13 +759,29 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
     u32x4 vreg[VPT];
     const int nstage = (p.M + STAGE_KEYS - 1) / STAGE_KEYS;
     const int nfull = p.M / STAGE_KEYS;
+    stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);      // (round 6) the first stage's loads fly while the padding is written
+
+    // padding is never staged: the 16-byte chunks past D of every K / V row of both buffers are written once, here -- zeros, with column D
+    // of every V row = one (softmax denominator from the PV MFMA) and column D of every K row = one (the folded -m_ref term of the score
+    // MFMA). Only those chunks (disjoint from what stage_store writes: no barrier in between; round 5 zeroed all 78 KB behind a barrier).
+    {
+        constexpr int NROW = 2 * NSUB * KVBLK;
+        const int c0 = p.D >> 3;
+        const T one = (T)1.0f;
+        unsigned short one_bits;
+        __builtin_memcpy(&one_bits, &one, 2);
+        const u32x4 z = {0u, 0u, 0u, 0u}, o = {(unsigned)one_bits, 0u, 0u, 0u};
+        for (int c = c0; c < KT::CHK; ++c)
+            for (int r = tid; r < NROW; r += NT) *reinterpret_cast<u32x4 *>(smem + (r >> 6) * SUB_BYTES + (r & 63) * KT::STRIDE + c * 16) = c == c0 ? o : z;
+        for (int c = c0; c < VT::CHK; ++c)
+            for (int r = tid; r < NROW; r += NT) *reinterpret_cast<u32x4 *>(smem + (r >> 6) * SUB_BYTES + KT::BYTES + (r & 63) * VT::STRIDE + c * 16) = c == c0 ? o : z;
+    }
     // f16 range-free mode: the reference is floored by the row's self-logit (self_logit, pww_attn_core.h; qf is pre-scaled: exp2 domain)
     float ref_floor = -INFINITY;
     if constexpr (RangeFree<T>::value && RfHeadroom<T>::value == 0.f) {
         if (p.M == p.N) { const float sl = self_logit<T, KS>(qf, Kp + (long)qrow * p.k_sm, qvalid, hi, p.D); ref_floor = qvalid ? sl : -INFINITY; }
     }
 
-    stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);
     stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
     stage_load(kreg, vreg, plan, srd_k, srd_v, k_step, v_step);     // past the last key: zeros (out of range)
     __syncthreads();
@@ -1056,6 +1059,15 @@ static int launch_attn(const AttnParams &p, hipStream_t stream) {
         }
     }
 #if PWW_EXPERIMENTS
+    if constexpr (!HAS_BIAS && DT >= 4 && NW == 4) {
+        // (round 6, A/B) the widest heads at the coarse levels (SD1.5 N = 256 d = 160: 32 workgroups of 4 waves, 4 stages of one 64-key tile): 4 row
+        // groups x 2 key groups of a 32-key block each on the same double-buffered stages -- 8 waves, half the dependent chain per stage
+        const long wgs128 = (long)((p.N + 127) / 128) * p.B * p.H;
+        if (ksplit_mode() == 1 && debug_knobs().attn_ksplit_half && wgs128 <= 256 && p.M >= 128) {
+            if ((p.D & 31) != 0) return launch_attn_ksplit<T, KS, DT, 4, 2, true, 1>(p, stream);
+            return launch_attn_ksplit<T, KS, DT, 4, 2, false, 1>(p, stream);
+        }
+    }
     if constexpr (!HAS_BIAS && DT >= 4 && NW == 4) {
         // (round 5) the widest heads at the coarsest levels (SD1.5 N = 256 d = 160: 32 workgroups of 4 waves walking 4 tiles each): 64-row
         // workgroups of 2 row groups x 2 key groups -- twice the workgroups, half the tiles per wave

@@ -34,8 +34,15 @@ struct LnParams {
     float eps;
 };
 
+// (hot / cold kernel arguments as in pww_norm.hip: the leading 13 dwords are preloaded into SGPRs by the dispatcher)
+struct LnCold { const void *beta, *post_bias; void *s, *y; long s_stride, y_stride; float eps; };
+#define LN_KARGS const void *a_, const void *x_, const void *gamma_, long rows_, long a_stride_, long x_stride_, int C_, const LnCold cold_
+#define LN_UNPACK const LnParams p = {a_, x_, gamma_, cold_.beta, cold_.post_bias, cold_.s, cold_.y, rows_, C_, a_stride_, x_stride_, cold_.s_stride, cold_.y_stride, cold_.eps};
+#define LN_LARGS(p) p.a, p.x, p.gamma, p.rows, p.a_stride, p.x_stride, p.C, LnCold{p.beta, p.post_bias, p.s, p.y, p.s_stride, p.y_stride, p.eps}
+
 template <typename T, int K, bool ADD>
-__global__ void __launch_bounds__(256) add_layer_norm_kernel(const LnParams p) {
+__global__ void __launch_bounds__(256) add_layer_norm_kernel(LN_KARGS) {
+    LN_UNPACK
     typedef typename Vec<T>::v8 V8;
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -109,7 +116,8 @@ __global__ void __launch_bounds__(256) add_layer_norm_kernel(const LnParams p) {
 struct GegluParams { const void *h; void *y; long rows; int D; long h_stride, y_stride; };
 
 template <typename T>
-__global__ void __launch_bounds__(256) geglu_kernel(const GegluParams p) {
+__global__ void __launch_bounds__(256) geglu_kernel(const void *h_, void *y_, long rows_, long h_stride_, long y_stride_, int D_) {
+    const GegluParams p = {h_, y_, rows_, D_, h_stride_, y_stride_};
     typedef typename Vec<T>::v8 V8;
     const int nch = p.D >> 3;
     const long total = p.rows * nch;
@@ -149,7 +157,8 @@ __global__ void __launch_bounds__(256) geglu_kernel(const GegluParams p) {
 struct BrParams { const void *r, *v, *bias; void *y; long nchunk; int C, HW, nhwc; };
 
 template <typename T>
-__global__ void __launch_bounds__(256) bias_residual_kernel(const BrParams p) {
+__global__ void __launch_bounds__(256) bias_residual_kernel(const void *r_, const void *v_, const void *bias_, void *y_, long nchunk_, int C_, int HW_, int nhwc_) {
+    const BrParams p = {r_, v_, bias_, y_, nchunk_, C_, HW_, nhwc_};
     typedef typename Vec<T>::v8 V8;
     constexpr int UN = 4;
     const long stride = (long)gridDim.x * 256;
@@ -191,10 +200,10 @@ int ln_launch(const LnParams &p, hipStream_t stream) {
     const int k = (p.C / 8 + 63) / 64;
     const dim3 grid((unsigned)((p.rows + 3) / 4));
     switch (k) {
-    case 1: hipLaunchKernelGGL((add_layer_norm_kernel<T, 1, ADD>), grid, dim3(256), 0, stream, p); break;
-    case 2: hipLaunchKernelGGL((add_layer_norm_kernel<T, 2, ADD>), grid, dim3(256), 0, stream, p); break;
-    case 3: hipLaunchKernelGGL((add_layer_norm_kernel<T, 3, ADD>), grid, dim3(256), 0, stream, p); break;
-    default: hipLaunchKernelGGL((add_layer_norm_kernel<T, 4, ADD>), grid, dim3(256), 0, stream, p); break;
+    case 1: hipLaunchKernelGGL((add_layer_norm_kernel<T, 1, ADD>), grid, dim3(256), 0, stream, LN_LARGS(p)); break;
+    case 2: hipLaunchKernelGGL((add_layer_norm_kernel<T, 2, ADD>), grid, dim3(256), 0, stream, LN_LARGS(p)); break;
+    case 3: hipLaunchKernelGGL((add_layer_norm_kernel<T, 3, ADD>), grid, dim3(256), 0, stream, LN_LARGS(p)); break;
+    default: hipLaunchKernelGGL((add_layer_norm_kernel<T, 4, ADD>), grid, dim3(256), 0, stream, LN_LARGS(p)); break;
     }
     return check_hip(hipGetLastError(), "add_layer_norm launch");
 }
@@ -230,8 +239,8 @@ int geglu(const void *h, void *y, int64_t rows, int32_t D, int64_t h_stride, int
     if (!arch_ok()) return PWW_ENOTSUP;
     GegluParams p; p.h = h; p.y = y; p.rows = rows; p.D = D; p.h_stride = hs; p.y_stride = ys;
     const int grid = grid_for(rows * (D / 8), 4);
-    if (dtype == PWW_DTYPE_F16) hipLaunchKernelGGL(geglu_kernel<f16>, dim3(grid), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(geglu_kernel<bf16>, dim3(grid), dim3(256), 0, stream, p);
+    if (dtype == PWW_DTYPE_F16) hipLaunchKernelGGL(geglu_kernel<f16>, dim3(grid), dim3(256), 0, stream, p.h, p.y, p.rows, p.h_stride, p.y_stride, p.D);
+    else hipLaunchKernelGGL(geglu_kernel<bf16>, dim3(grid), dim3(256), 0, stream, p.h, p.y, p.rows, p.h_stride, p.y_stride, p.D);
     return check_hip(hipGetLastError(), "geglu launch");
 }
 
@@ -245,8 +254,8 @@ int bias_residual(const void *r, const void *v, const void *bias, void *y, int32
     if (!arch_ok()) return PWW_ENOTSUP;
     BrParams p; p.r = r; p.v = v; p.bias = bias; p.y = y; p.nchunk = (long)B * C * HW / 8; p.C = C; p.HW = HW; p.nhwc = layout == PWW_LAYOUT_NHWC;
     const int grid = grid_for(p.nchunk, 4);
-    if (dtype == PWW_DTYPE_F16) hipLaunchKernelGGL(bias_residual_kernel<f16>, dim3(grid), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(bias_residual_kernel<bf16>, dim3(grid), dim3(256), 0, stream, p);
+    if (dtype == PWW_DTYPE_F16) hipLaunchKernelGGL(bias_residual_kernel<f16>, dim3(grid), dim3(256), 0, stream, p.r, p.v, p.bias, p.y, p.nchunk, p.C, p.HW, p.nhwc);
+    else hipLaunchKernelGGL(bias_residual_kernel<bf16>, dim3(grid), dim3(256), 0, stream, p.r, p.v, p.bias, p.y, p.nchunk, p.C, p.HW, p.nhwc);
     return check_hip(hipGetLastError(), "bias_residual launch");
 }
 

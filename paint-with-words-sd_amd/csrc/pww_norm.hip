@@ -44,6 +44,21 @@ struct GnParams {
     float eps;
 };
 
+// Kernel arguments in two parts (round 6): the 14 dwords a wave needs to issue its first loads travel as leading SCALAR arguments, which the
+// dispatcher preloads into SGPRs (kernarg preload: 16 user SGPRs less the kernarg pointer; a by-value struct is never preloaded), the rest
+// in a struct behind them, fetched by an s_load that has the loads' latency to land. Every launch of these kernels starts cold (546 other
+// kernels run between two launches of the same code): the first dependent round trip -- to the kernarg segment -- is the one a kernel can drop.
+struct GnCold {
+    const void *gamma, *beta;
+    void *y;
+    double *partial;
+    int apply_px, rows_per_wg;
+    float eps;
+};
+#define GN_KARGS const void *x_, const void *pre_, const void *add_, int B_, int C_, int HW_, int G_, int cg_, int add_stride_, int nslab_, int slab_px_, const GnCold cold_
+#define GN_UNPACK const GnParams p = {x_, pre_, add_, cold_.gamma, cold_.beta, cold_.y, cold_.partial, B_, C_, HW_, G_, cg_, add_stride_, nslab_, slab_px_, cold_.apply_px, cold_.rows_per_wg, cold_.eps};
+#define GN_LARGS(p) p.x, p.pre, p.add, p.B, p.C, p.HW, p.G, p.cg, p.add_stride, p.nslab, p.slab_px, GnCold{p.gamma, p.beta, p.y, p.partial, p.apply_px, p.rows_per_wg, p.eps}
+
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 template <typename T> __device__ __forceinline__ float round_to(float v) { return (float)(T)v; }
@@ -77,7 +92,8 @@ __device__ __forceinline__ void wg_sum(double &S, double &Q, double (*red)[2], i
 // Thread t owns the 8-channel chunk t % CH of every PL-th pixel (CH = C / 8 chunks per pixel, PL = NT / CH pixels in flight; threads past
 // PL * CH idle: C = 320 -> 240 of 256 busy). NT = 256 threads, 512 for C > 2048 (the 2560-channel inputs of the first up-block).
 template <typename T, int NT>
-__global__ void __launch_bounds__(NT) gn_moments_nhwc(const GnParams p) {
+__global__ void __launch_bounds__(NT) gn_moments_nhwc(GN_KARGS) {
+    GN_UNPACK
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Vec<T>::v8 V8;
     const int tid = threadIdx.x, b = blockIdx.y, slab = blockIdx.x;
@@ -152,7 +168,8 @@ __global__ void __launch_bounds__(NT) gn_moments_nhwc(const GnParams p) {
 }
 
 template <typename T, int ACT, int NT>
-__global__ void __launch_bounds__(NT) gn_apply_nhwc(const GnParams p) {
+__global__ void __launch_bounds__(NT) gn_apply_nhwc(GN_KARGS) {
+    GN_UNPACK
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Vec<T>::v8 V8;
     constexpr int NPART = 8;                                         // partials a fold lane takes: K = NT / G >= 8 lanes, <= 64 slabs
@@ -240,7 +257,8 @@ __global__ void __launch_bounds__(NT) gn_apply_nhwc(const GnParams p) {
 // One launch, workgroup = (group, image), NHWC: thread t owns the 4-channel piece t % ppp of every PLs-th pixel (ppp = cg / 4 pieces per
 // pixel of the group, PLs = 256 / ppp pixels in flight): its parameters are loaded once, its <= 24 pieces stay in registers.
 template <typename T, int ACT>
-__global__ void __launch_bounds__(GN_NT) gn_group_nhwc(const GnParams p) {
+__global__ void __launch_bounds__(GN_NT) gn_group_nhwc(GN_KARGS) {
+    GN_UNPACK
     typedef T TV __attribute__((ext_vector_type(4)));
     __shared__ double red[GN_NT / 64][2];
     const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
@@ -308,7 +326,8 @@ __global__ void __launch_bounds__(GN_NT) gn_group_nhwc(const GnParams p) {
 // ==== NCHW ==========================================================================================================================
 // A group is one contiguous run of cg * HW elements (HW a multiple of 8: a 16-byte chunk never straddles two channels).
 template <typename T>
-__global__ void __launch_bounds__(GN_NT) gn_moments_nchw(const GnParams p) {
+__global__ void __launch_bounds__(GN_NT) gn_moments_nchw(GN_KARGS) {
+    GN_UNPACK
     typedef typename Vec<T>::v8 V8;
     __shared__ double red[GN_NT / 64][2];
     const int tid = threadIdx.x, seg = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
@@ -356,7 +375,8 @@ __global__ void __launch_bounds__(GN_NT) gn_moments_nchw(const GnParams p) {
 // folds the (<= 16) partials of ITS row's group itself: the loads of all of them fly together with the row's first activations.
 constexpr int GN_NCHW_SLABS = 16;
 template <typename T, int ACT>
-__global__ void __launch_bounds__(GN_NT) gn_apply_nchw(const GnParams p) {
+__global__ void __launch_bounds__(GN_NT) gn_apply_nchw(GN_KARGS) {
+    GN_UNPACK
     typedef typename Vec<T>::v8 V8;
     const int tid = threadIdx.x;
     const int cpr = p.HW >> 3;                               // 16-byte chunks per row
@@ -412,7 +432,8 @@ __global__ void __launch_bounds__(GN_NT) gn_apply_nchw(const GnParams p) {
 // One launch, workgroup = (group, image), NCHW: TPR threads per channel row, RP rows in flight; a thread's <= 12 chunks (rows rl, rl + RP,
 // ... x chunks k0, k0 + TPR, ...) stay in registers.
 template <typename T, int ACT>
-__global__ void __launch_bounds__(GN_NT) gn_group_nchw(const GnParams p) {
+__global__ void __launch_bounds__(GN_NT) gn_group_nchw(GN_KARGS) {
+    GN_UNPACK
     typedef typename Vec<T>::v8 V8;
     constexpr int MAXP = GN_GROUP_PIECES / 2;             // 8-value pieces: half as many as the NHWC form for the same registers
     __shared__ double red[GN_NT / 64][2];
@@ -535,31 +556,31 @@ int gn_launch(const GnParams &p, const pww_gn_desc_t *d, const GnPlan &pl, hipSt
     if (pl.group) {
         const dim3 grid(d->G, d->B);
         if (d->layout == PWW_LAYOUT_NHWC) {
-            if (silu) hipLaunchKernelGGL((gn_group_nhwc<T, 1>), grid, dim3(GN_NT), 0, stream, p);
-            else hipLaunchKernelGGL((gn_group_nhwc<T, 0>), grid, dim3(GN_NT), 0, stream, p);
+            if (silu) hipLaunchKernelGGL((gn_group_nhwc<T, 1>), grid, dim3(GN_NT), 0, stream, GN_LARGS(p));
+            else hipLaunchKernelGGL((gn_group_nhwc<T, 0>), grid, dim3(GN_NT), 0, stream, GN_LARGS(p));
         } else {
-            if (silu) hipLaunchKernelGGL((gn_group_nchw<T, 1>), grid, dim3(GN_NT), 0, stream, p);
-            else hipLaunchKernelGGL((gn_group_nchw<T, 0>), grid, dim3(GN_NT), 0, stream, p);
+            if (silu) hipLaunchKernelGGL((gn_group_nchw<T, 1>), grid, dim3(GN_NT), 0, stream, GN_LARGS(p));
+            else hipLaunchKernelGGL((gn_group_nchw<T, 0>), grid, dim3(GN_NT), 0, stream, GN_LARGS(p));
         }
         return check_hip(hipGetLastError(), "group_norm launch");
     }
     if (d->layout == PWW_LAYOUT_NHWC) {
         const dim3 gm(pl.nslab, d->B), ga((d->HW + pl.apply_px - 1) / pl.apply_px, d->B);
         if (pl.nt == 256) {
-            hipLaunchKernelGGL((gn_moments_nhwc<T, 256>), gm, dim3(256), pl.lds_m, stream, p);
-            if (silu) hipLaunchKernelGGL((gn_apply_nhwc<T, 1, 256>), ga, dim3(256), pl.lds_a, stream, p);
-            else hipLaunchKernelGGL((gn_apply_nhwc<T, 0, 256>), ga, dim3(256), pl.lds_a, stream, p);
+            hipLaunchKernelGGL((gn_moments_nhwc<T, 256>), gm, dim3(256), pl.lds_m, stream, GN_LARGS(p));
+            if (silu) hipLaunchKernelGGL((gn_apply_nhwc<T, 1, 256>), ga, dim3(256), pl.lds_a, stream, GN_LARGS(p));
+            else hipLaunchKernelGGL((gn_apply_nhwc<T, 0, 256>), ga, dim3(256), pl.lds_a, stream, GN_LARGS(p));
         } else {
-            hipLaunchKernelGGL((gn_moments_nhwc<T, 512>), gm, dim3(512), pl.lds_m, stream, p);
-            if (silu) hipLaunchKernelGGL((gn_apply_nhwc<T, 1, 512>), ga, dim3(512), pl.lds_a, stream, p);
-            else hipLaunchKernelGGL((gn_apply_nhwc<T, 0, 512>), ga, dim3(512), pl.lds_a, stream, p);
+            hipLaunchKernelGGL((gn_moments_nhwc<T, 512>), gm, dim3(512), pl.lds_m, stream, GN_LARGS(p));
+            if (silu) hipLaunchKernelGGL((gn_apply_nhwc<T, 1, 512>), ga, dim3(512), pl.lds_a, stream, GN_LARGS(p));
+            else hipLaunchKernelGGL((gn_apply_nhwc<T, 0, 512>), ga, dim3(512), pl.lds_a, stream, GN_LARGS(p));
         }
     } else {
-        hipLaunchKernelGGL(gn_moments_nchw<T>, dim3(pl.nslab, d->G, d->B), dim3(GN_NT), 0, stream, p);
+        hipLaunchKernelGGL(gn_moments_nchw<T>, dim3(pl.nslab, d->G, d->B), dim3(GN_NT), 0, stream, GN_LARGS(p));
         const long nrows = (long)d->B * d->C;
         const dim3 grid((unsigned)((nrows + pl.rows_per_wg - 1) / pl.rows_per_wg));
-        if (silu) hipLaunchKernelGGL((gn_apply_nchw<T, 1>), grid, dim3(GN_NT), 0, stream, p);
-        else hipLaunchKernelGGL((gn_apply_nchw<T, 0>), grid, dim3(GN_NT), 0, stream, p);
+        if (silu) hipLaunchKernelGGL((gn_apply_nchw<T, 1>), grid, dim3(GN_NT), 0, stream, GN_LARGS(p));
+        else hipLaunchKernelGGL((gn_apply_nchw<T, 0>), grid, dim3(GN_NT), 0, stream, GN_LARGS(p));
     }
     return check_hip(hipGetLastError(), "group_norm launch");
 }

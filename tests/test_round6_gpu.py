@@ -141,3 +141,70 @@ def test_half_rounded_statistic_delta(gpu_device, shape, dtype):
           f"largest logit change {d_bias:.3e}; output change {d_out:.2e} of max|O| (per-call bar {2e-3 if dtype == torch.float16 else 1.6e-2:.1e})")
     assert rel <= 1.01 * ulp_half
     assert d_out <= (2e-3 if dtype == torch.float16 else 1.6e-2)
+
+
+# ---- the fp16 d = 40 launch on hot logits ------------------------------------------------------------------------
+
+def _path_counts(fn, device):
+    import ctypes
+    from pww_hip import _lib
+    lib = _lib.load()
+    counts = torch.zeros(4, dtype=torch.int32, device=device)
+    lib.pww_debug_path_counts(ctypes.c_void_p(counts.data_ptr()))
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+    finally:
+        lib.pww_debug_path_counts(None)
+    c = counts.tolist()
+    return out, {"fast": c[0], "lazy": c[1], "exact": c[2]}
+
+
+@pytest.mark.parametrize("std,expect", [(0.5, "fast"), (4.0, "lazy"), (5.0, "lazy")])
+def test_fp16_hot_rows_leave_the_range_free_mode_not_the_fast_path(gpu_device, std, expect):
+    """fp16, N = 4096, d = 40 (the dominant launch of config 3): on cold logits (scaled-logit std 0.5: the random-init UNet's regime) every
+    workgroup stays range-free; at std 4 / 5 (what trained layers produce) the workgroups follow the running maximum lazily and NONE
+    recomputes its rows on the exact path (round 5: a third / nearly all of them did, after a complete fast pass) -- inside the per-call
+    bar against fp64 on the same rounded inputs. pww_debug_path_counts reports the workgroups per path."""
+    from pww_hip import ops
+    B, N, H, D = 2, 4096, 8, 40
+    g = torch.Generator().manual_seed(7)
+    gain = math.sqrt(std)
+    q = (torch.randn(B, N, H * D, generator=g) * gain).to(torch.float16)
+    k = (torch.randn(B, N, H * D, generator=g) * gain).to(torch.float16)
+    v = torch.randn(B, N, H * D, generator=g).to(torch.float16)
+    qd, kd, vd = q.to(gpu_device), k.to(gpu_device), v.to(gpu_device)
+    out, paths = _path_counts(lambda: ops.attention(qd, kd, vd, H, D ** -0.5), gpu_device)
+    total = sum(paths.values())
+    rows = torch.arange(0, N, 97)
+    qh = q[0, rows].double().view(len(rows), H, D).transpose(0, 1)
+    kh, vh = (t[0].double().view(N, H, D).transpose(0, 1) for t in (k, v))
+    logits = torch.matmul(qh, kh.transpose(-1, -2)) * D ** -0.5
+    ref = torch.matmul(logits.softmax(-1), vh).transpose(0, 1).reshape(len(rows), H * D)
+    err = (out[0, rows].double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"fp16 d=40 scaled-logit std {std}: row maxima {logits.max(-1).values.mean():.1f} (max {logits.max():.1f}) natural units; workgroups {paths}; max err / max|O| = {err:.2e}")
+    assert total == B * H * (N // 256) and paths["exact"] == 0 and paths[expect] == total
+    assert err <= 2e-3
+    # the same inputs in bf16 never leave the range-free fast path (8 exponent bits)
+    _, pb = _path_counts(lambda: ops.attention(qd.bfloat16(), kd.bfloat16(), vd.bfloat16(), H, D ** -0.5), gpu_device)
+    assert pb["fast"] == sum(pb.values()) > 0
+
+
+def test_fp16_rows_past_the_magnitude_guard_take_the_exact_path(gpu_device):
+    """Scaled-logit std 8 (row maxima of 29 natural units and more: past the 33-unit guard for many rows): those workgroups recompute on the
+    exact-scale path -- counted as such -- and the result stays inside the per-call bar."""
+    from pww_hip import ops
+    B, N, H, D = 1, 2048, 8, 40
+    g = torch.Generator().manual_seed(3)
+    gain = math.sqrt(8.0)
+    q = (torch.randn(B, N, H * D, generator=g) * gain).to(torch.float16)
+    k = (torch.randn(B, N, H * D, generator=g) * gain).to(torch.float16)
+    v = torch.randn(B, N, H * D, generator=g).to(torch.float16)
+    out, paths = _path_counts(lambda: ops.attention(q.to(gpu_device), k.to(gpu_device), v.to(gpu_device), H, D ** -0.5), gpu_device)
+    rows = torch.arange(0, N, 53)
+    qh = q[0, rows].double().view(len(rows), H, D).transpose(0, 1)
+    kh, vh = (t[0].double().view(N, H, D).transpose(0, 1) for t in (k, v))
+    ref = torch.matmul((torch.matmul(qh, kh.transpose(-1, -2)) * D ** -0.5).softmax(-1), vh).transpose(0, 1).reshape(len(rows), H * D)
+    err = (out[0, rows].double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    print(f"fp16 d=40 scaled-logit std 8: workgroups {paths}; max err / max|O| = {err:.2e}")
+    assert paths["exact"] > 0 and torch.isfinite(out).all() and err <= 2e-3

@@ -57,6 +57,14 @@ cold)
   # what a small launch costs over operands that are not L2-resident (rotating buffer sets)
   timeout 600 python tools/time_cold_start.py 2>&1 | grep "^|" | tee $O/r6_cold_start.md
   ;;
+preload)
+  # kernarg preload for every small pww kernel (K5 block kernels, mask / CFG kernels, pww_qk_parts): the same sources built without the flag, alternating runs
+  rm -f $O/r6_preload_ab.txt
+  for i in 1 2 3; do for v in preload nopreload; do
+    L=""; [ $v = nopreload ] && L="$PWD/paint-with-words-sd_amd/build/ab/libpww_hip_nopreload.so"
+    PWW_HIP_LIB=${L:-$PWD/paint-with-words-sd_amd/pww_hip/libpww_hip.so} timeout 300 python bench.py --steps 6 --warmup 1 --no-roofline-pass --no-reference-ops --cpu-steps 0 2> /dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['ms_per_step'], d['parity']['rel_l2'])" | tee -a $O/r6_preload_ab.txt
+  done; done
+  ;;
 hot)
   # the fp16 dominant launch on hot logits -- shipped / round 5's behaviour / always lazy / a raised magnitude-guard limit
   rm -f $O/r6_hot.md
