@@ -183,7 +183,8 @@ def test_fp16_hot_rows_leave_the_range_free_mode_not_the_fast_path(gpu_device, s
     ref = torch.matmul(logits.softmax(-1), vh).transpose(0, 1).reshape(len(rows), H * D)
     err = (out[0, rows].double().cpu() - ref).abs().max().item() / ref.abs().max().item()
     print(f"fp16 d=40 scaled-logit std {std}: row maxima {logits.max(-1).values.mean():.1f} (max {logits.max():.1f}) natural units; workgroups {paths}; max err / max|O| = {err:.2e}")
-    assert total == B * H * (N // 256) and paths["exact"] == 0 and paths[expect] == total
+    # (cold: a stray row -- 1 of 65536 had a first-stage sum below 8 when this was written -- may take its workgroup to the lazy path: +2 % on that one)
+    assert total == B * H * (N // 256) and paths["exact"] == 0 and paths[expect] >= (0.98 if expect == "fast" else 1.0) * total
     assert err <= 2e-3
     # the same inputs in bf16 never leave the range-free fast path (8 exponent bits)
     _, pb = _path_counts(lambda: ops.attention(qd.bfloat16(), kd.bfloat16(), vd.bfloat16(), H, D ** -0.5), gpu_device)

@@ -65,6 +65,23 @@ preload)
     PWW_HIP_LIB=${L:-$PWD/paint-with-words-sd_amd/pww_hip/libpww_hip.so} timeout 300 python bench.py --steps 6 --warmup 1 --no-roofline-pass --no-reference-ops --cpu-steps 0 2> /dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['ms_per_step'], d['parity']['rel_l2'])" | tee -a $O/r6_preload_ab.txt
   done; done
   ;;
+prof)
+  OUT=/tmp/pww_prof_r06; rm -rf $OUT; R=$PWD
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT -o run -- python $R/bench.py --steps 2 --warmup 1 --cpu-steps 0 --no-reference-ops --no-live-counters > $R/$O/r6_bench_c2_prof.json 2> $R/$O/r6_bench_c2_prof.log) || true
+  DB=$(find $OUT -name "*.db" | head -1)
+  W=$(grep "timed region CLOCK_MONOTONIC" $O/r6_bench_c2_prof.log | sed 's/.*ns //')
+  { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --cpu-steps 0 --no-reference-ops --no-live-counters (round 6)"; echo; echo "## pww kernels, whole process (workload + roofline pass)";
+    python tools/rocpd_stats.py "$DB" --top 60 --grid --match pww --split-b2b attn_fwd_fold_kernel; echo; echo "## pww kernels of the TIMED steps (hipGraph replay: what the product pays per launch)"; python tools/rocpd_stats.py "$DB" --top 60 --grid --match pww --window $W; echo; echo "## every kernel of the TIMED steps"; python tools/rocpd_stats.py "$DB" --top 45 --grid --window $W; } > $O/r6_bench_c2_kernel_stats.md 2>&1
+  tail -1 $O/r6_bench_c2_prof.json | cut -c1-200; grep -c "" $O/r6_bench_c2_kernel_stats.md
+  ;;
+igemm)
+  # stock-op setting A/B: MIOpen's bf16 NHWC asm implicit-GEMM forward solver brings two tensor-op launches per convolution (fp32 workspace
+  # zero + cast: 1736 + 1736 launches per 2 images in the trace); with the solver disabled find mode picks among the others
+  rm -f $O/r6_igemm_ab.txt
+  for i in 1 2; do for v in 1 0; do
+    MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_FWD_GTC_XDLOPS_NHWC=$v timeout 400 python bench.py --steps 6 --warmup 1 --no-roofline-pass --no-reference-ops --cpu-steps 0 2> /dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ASM_FWD_GTC_XDLOPS_NHWC=$v', d['value'], d['ms_per_step'], d['parity']['rel_l2'], d['config']['warmup_s'])" | tee -a $O/r6_igemm_ab.txt
+  done; done
+  ;;
 hot)
   # the fp16 dominant launch on hot logits -- shipped / round 5's behaviour / always lazy / a raised magnitude-guard limit
   rm -f $O/r6_hot.md
