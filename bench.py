@@ -333,7 +333,7 @@ def hot_logit_row(device, dtype, B, N, D, heads, std=4.0):
     produce, unlike the random-init UNet whose scaled logits stay below 1): this row prices what the folded-reference kernel does about them
     -- bf16: nothing (8 exponent bits); fp16: a workgroup whose first key stage shows a hot row leaves the range-free mode and follows the
     running maximum lazily, rows past the magnitude guard take the exact path. `paths` = workgroups of ONE launch per path (the kernel's
-    debug counters, pww_debug_path_counts): range-free fast path / lazy reference / exact recomputation."""
+    debug counters, pww_debug_path_counts): range-free fast path / lazy reference / lazy reference with the exact scale / exact recomputation."""
     import ctypes
     from pww_hip import ops, _lib
     g = torch.Generator(device="cpu").manual_seed(7)
@@ -352,7 +352,7 @@ def hot_logit_row(device, dtype, B, N, D, heads, std=4.0):
     finally:
         lib.pww_debug_path_counts(None)
     c = counts.tolist()
-    row["paths"] = {"fast": c[0], "lazy": c[1], "exact": c[2]}
+    row["paths"] = {"fast": c[0], "lazy": c[1], "lazy_exact_scale": c[3], "exact": c[2]}
     return row
 
 

@@ -420,9 +420,10 @@ int pww_profile_arm(void);
 int pww_profile_elapsed_us(int32_t slot, float *microseconds);
 void pww_profile_reset(void);
 
-/* Measurement aid (version >= 126): three uint32 counters in device memory (zeroed by the caller) that every workgroup of the d = 40
+/* Measurement aid (version >= 126): FOUR uint32 counters in device memory (zeroed by the caller) that every workgroup of the d = 40
  * folded-reference self-attention kernel bumps at its end -- [0] finished on the range-free fast path, [1] finished on the lazy-reference
- * path (an fp16 workgroup whose first key stage showed a hot row), [2] recomputed its rows on the exact path (overflow or magnitude guard).
+ * path (an fp16 workgroup whose first key stage showed a hot row), [2] recomputed its rows on the exact path (overflow or magnitude guard),
+ * [3] finished on the lazy-reference path with the EXACT scale (fp16: a row's logits passed the magnitude guard on the way; no second pass).
  * NULL switches it off (the default). Process-wide, like pww_debug_timeline; bench.py reports the counts of its hot-logit rows. */
 void pww_debug_path_counts(void *device_buffer);
 

@@ -514,15 +514,17 @@ __device__ __forceinline__ void fold_set_ref(typename Vec<T>::v8 (&qf)[KS], floa
 
 // Raise the reference of the rows that need it (all rows on the very first tile, where m_ref is still 0 and may be
 // far ABOVE the scores as well), shift the pending scores and rescale O^T accordingly. Wave-uniform, rare.
+// `cs` / `tau`: 1 and FOLD_TAU when the scores are in the exp2 domain (Q pre-multiplied by scale log2 e); c1 and FOLD_TAU / c1 when they are RAW
+// (the exact-scale mode of the f16 kernel: P = exp2(x c1), the reference lives in the raw domain too).
 template <typename T, int KS, int DT, int NS>
 __device__ __forceinline__ void fold_rereference(f32x16 (&s)[NS][2], f32x16 (&oacc)[DT], float &mref,
-                                                 typename Vec<T>::v8 (&qf)[KS], float tmax, bool first, int hi, int D) {
+                                                 typename Vec<T>::v8 (&qf)[KS], float tmax, bool first, int hi, int D, float cs = 1.f, float tau = FOLD_TAU) {
     // This path must stay a BRANCH: without a side effect in it hipcc if-converts the whole body into the hot loop
     // (64 v_sub_f32 per stage with delta = 0 -- the per-score VALU op the folded reference exists to remove).
     asm volatile("; fold_rereference: rare path" ::: "memory");
-    const float mnew = (first || tmax > FOLD_TAU) ? (float)(T)(mref + tmax) : mref;
+    const float mnew = (first || tmax > tau) ? (float)(T)(mref + tmax) : mref;
     const float delta = mnew - mref;                                   // exact in fp32
-    const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);  // O^T is still zero on the first tile
+    const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta * cs);  // O^T is still zero on the first tile
 #pragma unroll
     for (int n = 0; n < NS; ++n)
 #pragma unroll
@@ -538,16 +540,16 @@ __device__ __forceinline__ void fold_rereference(f32x16 (&s)[NS][2], f32x16 (&oa
 }
 
 // P = exp2(x) -> T, then O^T += V^T P^T for one 64-key sub-tile
-template <typename T, int DT, bool MASKED>
+template <typename T, int DT, bool MASKED, bool RAW = false>
 __device__ __forceinline__ void fold_exp_pv(const f32x16 (&s)[2], f32x16 (&oacc)[DT], const char *Vs, int key0, int M,
-                                            int l31, int hi) {
+                                            int l31, int hi, float c1 = 1.f) {
     typedef typename Vec<T>::v8 V8;
     const char *vl = Vs + vfrag_lane_off<DT>(hi * 32 + l31);
     V8 pf[2][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pf[kb][r >> 3][r & 7] = (T)__builtin_amdgcn_exp2f(s[kb][r]);
+        for (int r = 0; r < 16; ++r) pf[kb][r >> 3][r & 7] = (T)__builtin_amdgcn_exp2f(RAW ? s[kb][r] * c1 : s[kb][r]);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
         if (!MASKED || key0 + kb * 32 < M) {
@@ -578,9 +580,11 @@ __device__ __forceinline__ float max32(const f32x16 (&s)[2], float m) {
 }
 
 // one (possibly ragged) 64-key sub-tile
-template <typename T, int KS, int DT, bool MASKED, bool RFMODE>
+template <typename T, int KS, int DT, bool MASKED, bool RFMODE, bool RAW = false>
 __device__ __forceinline__ void fold_tile(f32x16 (&oacc)[DT], float &mref, bool first, typename Vec<T>::v8 (&qf)[KS],
-                                          const char *Ks, const char *Vs, int key0, int M, int l31, int hi, int D, float ref_floor) {
+                                          const char *Ks, const char *Vs, int key0, int M, int l31, int hi, int D, float ref_floor, float c1 = 1.f) {
+    static_assert(!(RAW && RFMODE), "the exact-scale mode follows the running maximum");
+    const float cs = RAW ? c1 : 1.f, tau = RAW ? FOLD_TAU / c1 : FOLD_TAU;
     f32x16 s[1][2];
     score_tile<T, KS>(s[0], qf, Ks, key0, MASKED ? M : 0x7fffffff, l31, hi);
     if (MASKED) {
@@ -593,9 +597,9 @@ __device__ __forceinline__ void fold_tile(f32x16 (&oacc)[DT], float &mref, bool 
         if (first) fold_rereference<T, KS, DT, 1>(s, oacc, mref, qf, fmaxf(xhalf_max(max32(s[0], -INFINITY)), ref_floor) + RfHeadroom<T>::value, true, hi, D);
     } else {
         const float tmax = xhalf_max(max32(s[0], -INFINITY));   // finite: key0 < M
-        if (first || !__all(tmax <= FOLD_TAU)) fold_rereference<T, KS, DT, 1>(s, oacc, mref, qf, tmax, first, hi, D);
+        if (first || !__all(tmax <= tau)) fold_rereference<T, KS, DT, 1>(s, oacc, mref, qf, tmax, first, hi, D, cs, tau);
     }
-    fold_exp_pv<T, DT, MASKED>(s[0], oacc, Vs, key0, M, l31, hi);
+    fold_exp_pv<T, DT, MASKED, RAW>(s[0], oacc, Vs, key0, M, l31, hi, c1);
 }
 
 // MFMA operand fragments of one 64-key sub-tile, requested from LDS ahead of their use: a ds_read_b128 issued
@@ -648,20 +652,25 @@ __device__ __forceinline__ void pv_frags(const typename Vec<T>::v8 (&pf)[2][2], 
             for (int dt = 0; dt < DT; ++dt) oacc[dt] = mfma32(vf[kb][k2][dt], pf[kb][k2], oacc[dt]);
 }
 
-template <typename T>
-__device__ __forceinline__ void exp_tile(typename Vec<T>::v8 (&pf)[2][2], const f32x16 (&s)[2]) {
+template <typename T, bool RAW = false>
+__device__ __forceinline__ void exp_tile(typename Vec<T>::v8 (&pf)[2][2], const f32x16 (&s)[2], float c1 = 1.f) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pf[kb][r >> 3][r & 7] = (T)__builtin_amdgcn_exp2f(s[kb][r]);
+        for (int r = 0; r < 16; ++r) pf[kb][r >> 3][r & 7] = (T)__builtin_amdgcn_exp2f(RAW ? s[kb][r] * c1 : s[kb][r]);
 }
 
 // one full 128-key stage: all K fragments and the first sub-tile's V fragments are requested up front, both
 // sub-tiles are scored, one joint reference check, then exp / PV per sub-tile
 // RFMODE: the reference is fixed by the first stage (range-free); else it follows the running maximum lazily (FOLD_TAU)
-template <typename T, int KS, int DT, int SUB_BYTES, bool RFMODE>
+// RAW (f16, round 6): Q is NOT pre-scaled -- the MFMA delivers raw score minus the raw-domain reference, P = exp2(x c1): one multiply per
+// score more than the folded scale, and no rounding of Q scale log2 e any more: the form a workgroup continues in when a row's logits
+// pass the magnitude guard (it used to recompute all its rows on the general online-softmax path after the complete fast pass).
+template <typename T, int KS, int DT, int SUB_BYTES, bool RFMODE, bool RAW = false>
 __device__ __forceinline__ void fold_stage2(f32x16 (&oacc)[DT], float &mref, bool first, typename Vec<T>::v8 (&qf)[KS],
-                                            const char *cur, int key0, int l31, int hi, int D, float ref_floor) {
+                                            const char *cur, int key0, int l31, int hi, int D, float ref_floor, float c1 = 1.f) {
+    static_assert(!(RAW && RFMODE), "the exact-scale mode follows the running maximum");
+    const float cs = RAW ? c1 : 1.f, tau = RAW ? FOLD_TAU / c1 : FOLD_TAU;
     typedef typename Vec<T>::v8 V8;
     typedef KTile<KS> KT;
     V8 k0[2][KS], k1[2][KS], v0[2][2][DT], v1[2][2][DT];
@@ -678,12 +687,12 @@ __device__ __forceinline__ void fold_stage2(f32x16 (&oacc)[DT], float &mref, boo
         if (first) fold_rereference<T, KS, DT, 2>(s, oacc, mref, qf, fmaxf(xhalf_max(max32(s[1], max32(s[0], -INFINITY))), ref_floor) + RfHeadroom<T>::value, true, hi, D);
     } else {
         const float tmax = xhalf_max(max32(s[1], max32(s[0], -INFINITY)));
-        if (first || !__all(tmax <= FOLD_TAU)) fold_rereference<T, KS, DT, 2>(s, oacc, mref, qf, tmax, first, hi, D);
+        if (first || !__all(tmax <= tau)) fold_rereference<T, KS, DT, 2>(s, oacc, mref, qf, tmax, first, hi, D, cs, tau);
     }
     V8 pf[2][2];
-    exp_tile<T>(pf, s[0]);
+    exp_tile<T, RAW>(pf, s[0], c1);
     pv_frags<T, DT>(pf, oacc, v0);
-    exp_tile<T>(pf, s[1]);
+    exp_tile<T, RAW>(pf, s[1], c1);
     pv_frags<T, DT>(pf, oacc, v1);
 }
 
@@ -738,6 +747,10 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
     // f16 only: range-free until the first stage shows a hot row, lazily following the running maximum from then on (see the loop)
     constexpr bool CAN_SWITCH = RangeFree<T>::value && RfHeadroom<T>::value == 0.f;
     bool lazy = false;                               // (p.hot_sum < 0: lazy from the second stage on whatever the rows look like -- A/B)
+    // third mode: lazy reference with the EXACT scale (rows past the magnitude guard), see the loops. In the 8-wave workgroups of the large
+    // launches only: the 4-wave form has no registers left for a third loop (12 bytes of scratch), its rows past the guard keep exact_rows.
+    constexpr bool CAN_RAW = CAN_SWITCH && NW >= 8;
+    bool raw = false;
     auto tl_sum = [&]() -> float {     // the lane's share of row D of O^T (the running softmax denominator: the ones column of V)
         const int rl_ = p.D & 31, tl_ = p.D >> 5;
         float lv = 0.f;
@@ -759,11 +772,11 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
     u32x4 vreg[VPT];
     const int nstage = (p.M + STAGE_KEYS - 1) / STAGE_KEYS;
     const int nfull = p.M / STAGE_KEYS;
-    stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);      // (round 6) the first stage's loads fly while the padding is written
 
     // padding is never staged: the 16-byte chunks past D of every K / V row of both buffers are written once, here -- zeros, with column D
     // of every V row = one (softmax denominator from the PV MFMA) and column D of every K row = one (the folded -m_ref term of the score
     // MFMA). Only those chunks (disjoint from what stage_store writes: no barrier in between; round 5 zeroed all 78 KB behind a barrier).
+    // (The first stage's loads are issued AFTER this, unlike in attn_fwd_kernel: with them in flight the 4-wave f16 form spilled 12 bytes.)
     {
         constexpr int NROW = 2 * NSUB * KVBLK;
         const int c0 = p.D >> 3;
@@ -782,6 +795,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
         if (p.M == p.N) { const float sl = self_logit<T, KS>(qf, Kp + (long)qrow * p.k_sm, qvalid, hi, p.D); ref_floor = qvalid ? sl : -INFINITY; }
     }
 
+    stage_load(kreg, vreg, plan, srd_k, srd_v, 0u, 0u);
     stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem);
     stage_load(kreg, vreg, plan, srd_k, srd_v, k_step, v_step);     // past the last key: zeros (out of range)
     __syncthreads();
@@ -816,12 +830,44 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
     }
     if constexpr (CAN_SWITCH) {
         if (lazy && !early) {
+            // second loop: lazy reference, folded scale. The stage's barrier also carries a vote: a row whose reference comes within
+            // FOLD_TAU + 1 of the magnitude guard's limit (the folded scale's rounding error grows with the logits: FOLD_LIMIT_F16) takes
+            // the workgroup to the third loop -- BEFORE the error is made, not after the pass.
+            const float lim_sw = p.fold_limit - FOLD_TAU - 1.f;
             for (; st < nfull; ++st) {
                 char *cur = smem + (st & 1) * STAGE_BYTES;
                 char *nxt = smem + ((st & 1) ^ 1) * STAGE_BYTES;
                 stage_store<DT, KPT, VPT>(kreg, vreg, plan, nxt);
                 stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
                 fold_stage2<T, KS, DT, SUB_BYTES, false>(oacc, mref, false, qf, cur, st * STAGE_KEYS, l31, hi, p.D, ref_floor);
+                if constexpr (CAN_RAW) {
+                    if (__syncthreads_or(qvalid && !(fabsf(mref) <= lim_sw))) { raw = true; ++st; break; }
+                } else {
+                    __syncthreads();
+                }
+            }
+        }
+        if (CAN_RAW && raw) {
+            // third loop: lazy reference, EXACT scale -- Q unscaled again (re-read: a few KB), the reference moved to the raw domain (a T value
+            // r with r c1 as close to the old reference as T allows; O^T rescaled by the difference), P = exp2(x c1). What was accumulated so far
+            // came from logits below the limit (inside the accuracy the guard stands for); everything larger is computed without the rounding of
+            // Q scale log2 e. No magnitude limit from here on, and no second pass (round 5: exact_rows after the complete fast pass, 2 x the time).
+            load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qvalid, hi, p.D);
+            const float c1 = p.scale_log2e;
+            const float r = (float)(T)(mref / c1);
+            const float alpha = __builtin_amdgcn_exp2f(mref - r * c1);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
+            mref = r;                       // RAW domain from here on
+            fold_set_ref<T, KS>(qf, mref, hi, p.D);
+            for (; st < nfull; ++st) {
+                char *cur = smem + (st & 1) * STAGE_BYTES;
+                char *nxt = smem + ((st & 1) ^ 1) * STAGE_BYTES;
+                stage_store<DT, KPT, VPT>(kreg, vreg, plan, nxt);
+                stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
+                fold_stage2<T, KS, DT, SUB_BYTES, false, true>(oacc, mref, false, qf, cur, st * STAGE_KEYS, l31, hi, p.D, ref_floor, c1);
                 __syncthreads();
             }
         }
@@ -832,7 +878,9 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
         for (int sub = 0; sub < NSUB; ++sub) {
             const int key0 = st * STAGE_KEYS + sub * KVBLK;
             if (key0 < p.M) {
-                if (CAN_SWITCH ? lazy : !RangeFree<T>::value)
+                if (CAN_RAW && raw)
+                    fold_tile<T, KS, DT, true, false, true>(oacc, mref, first, qf, cur + sub * SUB_BYTES, cur + sub * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, p.D, ref_floor, p.scale_log2e);
+                else if (CAN_SWITCH ? lazy : !RangeFree<T>::value)
                     fold_tile<T, KS, DT, true, false>(oacc, mref, first, qf, cur + sub * SUB_BYTES, cur + sub * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, p.D, ref_floor);
                 else
                     fold_tile<T, KS, DT, true, true>(oacc, mref, first, qf, cur + sub * SUB_BYTES, cur + sub * SUB_BYTES + KT::BYTES, key0, p.M, l31, hi, p.D, ref_floor);
@@ -866,9 +914,10 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
             for (int r = 0; r < 16; ++r) asum += fabsf(oacc[dt][r]);     // inf or NaN anywhere makes the comparison below false
         float est_max = mref + __builtin_amdgcn_logf(lsum);              // v_log_f32 = log2
         if (!RangeFree<T>::value || lazy) est_max = fminf(est_max, mref + FOLD_TAU);       // the lazy reference is never more than 2^FOLD_TAU below a score
+        if (raw) est_max = 0.f;                                          // exact scale: no magnitude limit (mref is a raw-domain value there)
         const bool bad = qvalid && !(lsum > 0.f && lsum < 3.0e38f && asum < 3.0e38f && fabsf(est_max) <= p.fold_limit);
         const bool redo = early || __syncthreads_or(bad);
-        if (p.path_counts && threadIdx.x == 0) atomicAdd(p.path_counts + (redo ? 2 : lazy ? 1 : 0), 1u);     // debug: which path this workgroup took
+        if (p.path_counts && threadIdx.x == 0) atomicAdd(p.path_counts + (redo ? 2 : raw ? 3 : lazy ? 1 : 0), 1u);     // debug: which path this workgroup took
         if (redo) {
             float l_unused;
             // after a COMPLETE fast pass only the waves that hold a bad row recompute (the others keep their results and help staging);

@@ -46,7 +46,7 @@ def main():
     dev = torch.device("cuda:0")
     N, D, H = 4096, 40, 8
     stds = [float(a) for a in sys.argv[1:]] or [1.0, 4.0, 5.0, 6.0, 7.0, 8.0]
-    print("| PWW_DEBUG=%s | rows | std | row max (nat) mean / max | us | fast / lazy / exact workgroups | max err / max|O| |" % os.environ.get("PWW_DEBUG", ""))
+    print("| PWW_DEBUG=%s | rows | std | row max (nat) mean / max | us | fast / lazy / lazy-exact-scale / exact workgroups | max err / max|O| |" % os.environ.get("PWW_DEBUG", ""))
     print("|---|---|---|---|---|---|---|")
     for dtype in (torch.float16, torch.bfloat16):
         for B in (2, 16):
@@ -75,7 +75,7 @@ def main():
                     ref = torch.matmul(logits.softmax(-1), vh).transpose(0, 1).reshape(len(rows), H * D)
                     err = max(err, (out[b, rows].double() - ref).abs().max().item() / ref.abs().max().item())
                     mx_mean, mx_max = logits.max(-1).values.mean().item(), max(mx_max, logits.max().item())
-                print("| %s | %d | %g | %.1f / %.1f | %.1f | %d / %d / %d | %.2e |" % (str(dtype).replace("torch.", ""), B, std, mx_mean, mx_max, us, c[0], c[1], c[2], err), flush=True)
+                print("| %s | %d | %g | %.1f / %.1f | %.1f | %d / %d / %d / %d | %.2e |" % (str(dtype).replace("torch.", ""), B, std, mx_mean, mx_max, us, c[0], c[1], c[3], c[2], err), flush=True)
 
 
 if __name__ == "__main__":
