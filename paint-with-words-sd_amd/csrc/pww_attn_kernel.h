@@ -744,7 +744,9 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
     float mref = 0.f;      // softmax reference of the lane's row (exp2 domain), identical in both half-waves
     bool first = true;     // no tile processed yet: m_ref not established
     bool early = false;    // magnitude guard tripped after the first stage: skip the fast path
-    // f16 only: range-free until the first stage shows a hot row, lazily following the running maximum from then on (see the loop)
+    // f16 only: range-free until the first stage shows a hot row, lazily following the running maximum from then on (see the loops). (bf16 was
+    // given the same switch and lost it again the same day: its range-free loop is 20 % faster than its lazy one -- 423 against 514 us at 16
+    // rows, where f16 pays 2 - 3 % -- and the benchmark's own rows fell under the threshold: 60.8 -> 73.9 us on the dominant launch.)
     constexpr bool CAN_SWITCH = RangeFree<T>::value && RfHeadroom<T>::value == 0.f;
     bool lazy = false;                               // (p.hot_sum < 0: lazy from the second stage on whatever the rows look like -- A/B)
     // third mode: lazy reference with the EXACT scale (rows past the magnitude guard), see the loops. In the 8-wave workgroups of the large
@@ -820,7 +822,8 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
                 // and a workgroup with a row below p.hot_sum (8) follows the running maximum lazily from here on: the SECOND loop below (the
                 // FOLD_TAU reference of the non-range-free form: one max per score and stage, +8 % on that workgroup; P can no longer
                 // overflow). Two loops, not one loop with two bodies: that form spilled 350 - 480 bytes per lane.
-                const float l0 = __shfl(tl_sum(), l31);        // (row D of O^T sits in the hi == 0 half)
+                // (row D of O^T sits in the hi == 0 half; the bf16 reference sits 2^RfHeadroom above the stage's maximum: the sum is taken relative to the maximum)
+                const float l0 = __shfl(tl_sum(), l31) * __builtin_amdgcn_exp2f(RfHeadroom<T>::value);
                 lazy = __syncthreads_or((qvalid && l0 < p.hot_sum) || p.hot_sum < 0.f) != 0;
                 if (lazy) { ++st; break; }
             }
