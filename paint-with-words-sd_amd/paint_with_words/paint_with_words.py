@@ -60,16 +60,18 @@ def pww_load_tools(device: str = "cuda:0", scheduler_type=LMSDiscreteScheduler, 
         raise ImportError("pww_load_tools needs `diffusers` (the reference pins diffusers==0.10.0); it is not "
                           "installed here. Pass preloaded_utils=(vae, unet, text_encoder, tokenizer, scheduler).")
     from transformers import CLIPTextModel, CLIPTokenizer
-    dtype = torch.float16
+    # the reference's two loading branches (:145-188): half weights from the checkpoint's `fp16` revision everywhere but on Apple's `mps`
+    # device, where it loads fp32 from the default revision (kept for signature / behaviour parity: this package's kernels need a HIP device)
+    half = device != "mps"
     model_path = local_model_path if local_model_path is not None else hf_model_path
-    local_only = local_model_path is not None
+    common = dict(use_auth_token=model_token, torch_dtype=torch.float16 if half else torch.float32, local_files_only=local_model_path is not None)
+    if half:
+        common["revision"] = "fp16"
     print(model_path)
-    vae = AutoencoderKL.from_pretrained(model_path, subfolder="vae", use_auth_token=model_token, torch_dtype=dtype,
-                                        local_files_only=local_only)
+    vae = AutoencoderKL.from_pretrained(model_path, subfolder="vae", **common)
     tokenizer = CLIPTokenizer.from_pretrained(model_path, subfolder="tokenizer")
     text_encoder = CLIPTextModel.from_pretrained(model_path, subfolder="text_encoder")
-    unet = UNet2DConditionModel.from_pretrained(model_path, subfolder="unet", use_auth_token=model_token,
-                                                torch_dtype=dtype, local_files_only=local_only)
+    unet = UNet2DConditionModel.from_pretrained(model_path, subfolder="unet", **common)
     vae.to(device), unet.to(device), text_encoder.to(device)
     if pww_hip.install(unet) == 0 and hasattr(unet, "set_attn_processor"):   # diffusers >= 0.12
         unet.set_attn_processor(pww_hip.PwWAttnProcessor())
