@@ -497,12 +497,14 @@ constexpr float FOLD_TAU = 6.f;
 // logit maxima of 40 - 45 natural units (tests/test_round2_gpu.py::test_hot_logits), negligible at |logit| < 10. The kernel
 // therefore bounds the row maximum it has seen -- exactly, in the exp2 domain: after the first stage (early exit: the whole
 // workgroup goes straight to the exact path) and at the end (m_ref + log2(row sum) >= the true row maximum) -- and a workgroup
-// with a row beyond FoldLimit<T> recomputes its rows with the exact-scale online softmax (exact_rows). Limits: bf16 72 (= 50
-// natural units: 1.3e-2 of max|O| extrapolated, inside the 1.6e-2 bar), f16 36 (= 25 natural units: <= 1.3e-3 extrapolated, inside the
-// 2e-3 bar; measured 6e-4 at row maxima of 12 - 14). The f16 reference follows the running maximum to within 2^FOLD_TAU, so its
-// final bound is min(m_ref + FOLD_TAU, m_ref + log2(row sum)) -- tight enough that logits of std 3 - 4 stay on the fast path.
-// (round 6: the kernels read the limit from AttnParams::fold_limit; the host fills in FOLD_LIMIT_F16 = 48 / FOLD_LIMIT_BF16 = 56 of pww_attn_core.h --
-// re-measured, see there -- or the A/B knob's value: pww_attn.hip)
+// with a row beyond the limit (AttnParams::fold_limit) does not keep the folded scale for it. Limits (round 6, re-measured on a sweep of
+// scaled-logit std 1 ... 8, profiles/r06_hot_logits.md; pww_attn_core.h FOLD_LIMIT_*): f16 48 exp2 units (= 33 natural units: 1.2e-3 of
+// max|O| there, bar 2e-3; rounds 2 - 5: 36), bf16 56 (= 39: 1.1 - 1.6e-2, bar 1.6e-2; rounds 2 - 5: 72, extrapolated from two points).
+// What "does not keep the folded scale" means:
+//   f16, 8-wave workgroups: in the lazy-reference loop a row whose reference comes within FOLD_TAU + 1 of the limit takes the workgroup to
+//        the EXACT-SCALE loop (Q unscaled, raw-domain reference, P = exp2(x c1)) -- before the error is made, no second pass;
+//   everything else (bf16, whose range-free loop keeps no running maximum; the 4- and 2-wave forms; a FIRST key stage already past the
+//        limit): the waves that hold such a row recompute it with the exact-scale online softmax (exact_rows) after the pass.
 
 template <typename T, int KS>
 __device__ __forceinline__ void fold_set_ref(typename Vec<T>::v8 (&qf)[KS], float mref, int hi, int D) {
