@@ -754,7 +754,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
     // third mode: lazy reference with the EXACT scale (rows past the magnitude guard), see the loops. In the 8-wave workgroups of the large
     // launches only: the 4-wave form has no registers left for a third loop (12 bytes of scratch), its rows past the guard keep exact_rows.
     constexpr bool CAN_RAW = CAN_SWITCH && NW >= 8;
-    bool raw = false;
+    bool raw = false, redo0 = false;
     auto tl_sum = [&]() -> float {     // the lane's share of row D of O^T (the running softmax denominator: the ones column of V)
         const int rl_ = p.D & 31, tl_ = p.D >> 5;
         float lv = 0.f;
@@ -814,7 +814,12 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
         first = false;
         if (st == 0) {       // magnitude guard, early form: the first stage's row maximum (m_ref minus the range-free headroom)
             const float m0 = mref - (RangeFree<T>::value ? RfHeadroom<T>::value : 0.f);
-            if (__syncthreads_or(qvalid && !(fabsf(m0) <= p.fold_limit))) { early = true; break; }
+            if (__syncthreads_or(qvalid && !(fabsf(m0) <= p.fold_limit))) {
+                // a FIRST stage already past the limit: the 8-wave f16 form starts over on the exact scale (stage 0 is still in its buffer, stage 1
+                // parked, stage 2 in registers: one stage computed twice); everything else recomputes on exact_rows after the loop
+                if constexpr (CAN_RAW) { raw = true; redo0 = true; } else { early = true; }
+                break;
+            }
             if constexpr (CAN_SWITCH) {
                 // HOT ROWS (round 6). The f16 range-free reference has 16 binary orders of room above the first stage's maximum: a row whose
                 // logits spread over more than that (scaled-logit std >= ~3: what trained SD layers produce) overflows P to inf at some later
@@ -834,7 +839,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
         }
     }
     if constexpr (CAN_SWITCH) {
-        if (lazy && !early) {
+        if (lazy && !early && !raw) {
             // second loop: lazy reference, folded scale. The stage's barrier also carries a vote: a row whose reference comes within
             // FOLD_TAU + 1 of the magnitude guard's limit (the folded scale's rounding error grows with the logits: FOLD_LIMIT_F16) takes
             // the workgroup to the third loop -- BEFORE the error is made, not after the pass.
@@ -859,14 +864,26 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
             // Q scale log2 e. No magnitude limit from here on, and no second pass (round 5: exact_rows after the complete fast pass, 2 x the time).
             load_q_frags<T, KS>(qf, Qp + (long)qrow * p.q_sn, qvalid, hi, p.D);
             const float c1 = p.scale_log2e;
-            const float r = (float)(T)(mref / c1);
-            const float alpha = __builtin_amdgcn_exp2f(mref - r * c1);
+            if (redo0) {                    // (from the first-stage guard: nothing of the folded pass is kept)
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+                for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
-            mref = r;                       // RAW domain from here on
-            fold_set_ref<T, KS>(qf, mref, hi, p.D);
+                    for (int i = 0; i < 16; ++i) oacc[dt][i] = 0.f;
+                mref = 0.f;
+                fold_set_ref<T, KS>(qf, mref, hi, p.D);
+                fold_stage2<T, KS, DT, SUB_BYTES, false, true>(oacc, mref, true, qf, smem, 0, l31, hi, p.D, ref_floor, c1);
+                __syncthreads();            // every wave is done with buffer 0 before iteration 1 parks stage 2 there
+                st = 1;
+            } else {
+                const float r = (float)(T)(mref / c1);
+                const float alpha = __builtin_amdgcn_exp2f(mref - r * c1);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) oacc[dt][i] *= alpha;
+                mref = r;                   // RAW domain from here on
+                fold_set_ref<T, KS>(qf, mref, hi, p.D);
+            }
             for (; st < nfull; ++st) {
                 char *cur = smem + (st & 1) * STAGE_BYTES;
                 char *nxt = smem + ((st & 1) ^ 1) * STAGE_BYTES;
