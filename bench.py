@@ -356,15 +356,24 @@ def hot_logit_row(device, dtype, B, N, D, heads, std=4.0):
     return row
 
 
+# gfx950: FETCH_SIZE = TCC_EA0_RDREQ x 64 bytes, but a read request moves a whole 128-byte line (MI355X_MICROARCH.md, HBM section: "double
+# it before comparing with a byte count" for 16-byte-per-lane loads -- every load of these kernels; re-measured on this access pattern in
+# round 6: tools/ubench_linefill.cpp, profiles/r06_linefill.txt -- a 32-, 64- or 80-byte touch of a line is ONE request and costs the time
+# of 128 bytes). WRITE_SIZE is exact (32- and 64-byte requests, counted as such). Rounds 2 - 5 used 1.0 (calibrated on a kernel whose rows
+# were sliced the same way: the calibration could not see it) and under-reported the read side by half.
+FETCH_LINE_FACTOR = 2.0
+TRAFFIC_CORRECTION = ("hbm bytes = 2 x FETCH_SIZE + WRITE_SIZE: on gfx950 FETCH_SIZE tallies a read request at 64 bytes and a request moves a whole "
+                      "128-byte line (MI355X_MICROARCH.md HBM section; profiles/r06_linefill.txt); rounds 2 - 5 reported FETCH_SIZE + WRITE_SIZE")
+
+
 def measured_traffic(n_tok, d, b_rows, dtype, live=False):
-    """HBM bytes per launch of the dominant kernel (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes as
-    MI355X_MICROARCH.md prescribes; correction: see the `correction` field of the profile file -- the head-sliced rows of this
-    kernel are fetched as 64-byte requests, calibrated x1.0 on the reduce kernel's known byte count). Default: the committed PMC
-    pass of the SHIPPED kernel and dtype for this shape (profiles/r03_traffic.json, else the round-2 file); `live` = run the two
-    passes now over the same launch through the native harness. None if the shape is not covered."""
+    """HBM bytes per launch of the dominant kernel (2 x FETCH_SIZE + WRITE_SIZE: FETCH_LINE_FACTOR above; separate rocprofv3 --pmc passes as
+    MI355X_MICROARCH.md prescribes). Default: the committed PMC pass of the SHIPPED kernel and dtype for this shape
+    (profiles/r06_traffic.json: this round's passes, corrected); `live` = run the two passes now over the same launch through the native
+    harness. None if the shape is not covered."""
     if live:
         return live_traffic(n_tok, d, b_rows, dtype)
-    for name in ("r04_pmc.json", "r03_traffic.json", "r02_attn_traffic.json"):
+    for name in ("r06_traffic.json",):
         path = os.path.join(REPO, "profiles", name)
         if not os.path.isfile(path):
             continue
@@ -401,13 +410,14 @@ HARNESS_CASES = {(4096, 40, 2, "bf16"): "sd15_self_n4096_d40_bf16_b2", (4096, 40
                  (9216, 64, 4, "bf16"): "sd21_self_n9216_d64_b4", (9216, 64, 8, "bf16"): "sd21_self_n9216_d64_b8"}
 
 
+CROSS16_COUNTER_CASE = ("qproj_sd15_n4096_b16", "cross N=4096 d=40, 16 rows (8 gated in): pww_qproj_stat + pww_cross_attn_fwd_parts (the batched C = 320 layers' route)")
 CROSS_COUNTER_CASE = ("qproj_sd15_n256_b2", "cross N=256 d=160, 2 rows: pww_qk_parts + pww_cross_attn_fwd_parts (the C = 1280 layers' route)")
 
 
 def live_counters(case, kernel_keys, flags=()):
     """rocprofv3 --pmc passes over tests/native/attn_check --only <case> (separate passes with --kernel-trace only, as MI355X_MICROARCH.md
     prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass; SQ_VALU_MFMA_BUSY_CYCLES with GRBM_GUI_ACTIVE for the kernel's cycles): per
-    kernel whose name contains one of `kernel_keys`: {"hbm_bytes": (FETCH_SIZE + WRITE_SIZE) KiB -> bytes per dispatch, "mfma_busy":
+    kernel whose name contains one of `kernel_keys`: {"hbm_bytes": (2 x FETCH_SIZE + WRITE_SIZE) KiB -> bytes per dispatch (FETCH_LINE_FACTOR), "mfma_busy":
     SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), "kernel_cycles", "dispatches"}. None when rocprofv3 or the harness
     is missing, {} when a pass produced nothing."""
     import csv
@@ -438,7 +448,8 @@ def live_counters(case, kernel_keys, flags=()):
         m = {k: sum(v) / len(v) for k, v in c.items()}
         r = {"dispatches": max(len(v) for v in c.values())}
         if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
-            r["hbm_bytes"] = int((m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0)
+            r["hbm_bytes"] = int((FETCH_LINE_FACTOR * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024.0)
+            r["fetch_size_kib_raw"], r["write_size_kib"] = round(m["FETCH_SIZE"], 1), round(m["WRITE_SIZE"], 1)
         if m.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
             r["kernel_cycles"] = int(m["GRBM_GUI_ACTIVE"] / 8.0)
             r["mfma_busy"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
@@ -448,7 +459,7 @@ def live_counters(case, kernel_keys, flags=()):
 
 def live_traffic(n_tok, d, b_rows, dtype):
     """rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one pass each; they do not fit one pass) over tests/native/attn_check --only <case>:
-    mean per dispatch of the attention kernel, KiB -> bytes. None if rocprofv3 or a harness case for the shape is missing."""
+    mean per dispatch of the attention kernel, KiB -> bytes, the read side x FETCH_LINE_FACTOR. None if rocprofv3 or a harness case for the shape is missing."""
     import csv
     import glob
     import shutil
@@ -471,7 +482,7 @@ def live_traffic(n_tok, d, b_rows, dtype):
         shutil.rmtree(out, ignore_errors=True)
         if not vals:
             return None
-        total += sum(vals) / len(vals) * 1024.0
+        total += sum(vals) / len(vals) * 1024.0 * (FETCH_LINE_FACTOR if counter == "FETCH_SIZE" else 1.0)
     return int(total)
 
 
@@ -893,7 +904,8 @@ def main():
                                   "SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), back-to-back launches of this shape",
                                   "traffic": measured_traffic(n_dom, d, b_rows, cfg["dtype"], live=args.live_traffic),
                                   "traffic_source": "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes" if args.live_traffic else "CONSTANT from the committed PMC pass of the shipped kernel "
-                                  "(profiles/r04_pmc.json), not measured in this run",
+                                  "(profiles/r06_traffic.json), not measured in this run",
+                                  "traffic_correction": TRAFFIC_CORRECTION,
                                   "algorithmic_bytes": 2 * (2 * b_rows * n_dom * heads * d) * 2,
                                   "avg_us": round(us, 2), "avg_us_method": "kernel-only HIP event timestamps (hipExtLaunchKernelGGL start/stop events) of every launch of this "
                                   "class in an eager pass of the same workload, on the launch stream",
@@ -911,6 +923,9 @@ def main():
             if lv and "mfma_busy" in lv:
                 result["roofline"]["mfma_busy"] = lv["mfma_busy"]
                 result["roofline"]["mfma_busy_source"] = "LIVE: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), same passes"
+            if lv and "fetch_size_kib_raw" in lv:
+                result["roofline"]["traffic_counters_raw"] = {"FETCH_SIZE_KiB": lv["fetch_size_kib_raw"], "WRITE_SIZE_KiB": lv["write_size_kib"]}
+            cross16 = None
             cross = live_counters(CROSS_COUNTER_CASE[0], ["cross_lean_kernel", "qk_parts_kernel", "cross_fused_kernel"], flags=("--product-only",))
             if cross:
                 # algorithmic bytes of the two launches at 2 rows, N = 256, C = 1280, M = 77: attention 2 (2 B N C + 2 B M C) + the cond row's
@@ -920,9 +935,20 @@ def main():
                     if k in alg and "hbm_bytes" in r:
                         r["algorithmic_bytes"] = alg[k]
                         r["traffic_over_algorithmic"] = round(r["hbm_bytes"] / alg[k], 2)
-                result["counters_cross_route"] = {"case": CROSS_COUNTER_CASE[1], "kernels": cross,
+                result["counters_cross_route"] = {"case": CROSS_COUNTER_CASE[1], "kernels": cross, "traffic_correction": TRAFFIC_CORRECTION,
                                                   "source": "LIVE: rocprofv3 --pmc passes of this run over tests/native/attn_check --product-only --only %s" % CROSS_COUNTER_CASE[0]}
-            log("live counters done in %.1f s" % (time.perf_counter() - t_pmc), lv, cross)
+            # the batched route (configs 3 / 4: 16 folded rows, N = 4096, C = 320): the general kernel with several query blocks per workgroup
+            # (VERDICT round 5 item 5). Algorithmic bytes: Q + O (2 x 2 B N C) + K / V (2 x 2 B M C) + the shared map's 32-column span (N x 32 x 4)
+            cross16 = live_counters(CROSS16_COUNTER_CASE[0], ["cross_fused_kernel"], flags=("--product-only",))
+            if cross16:
+                alg16 = 2 * 2 * 16 * 4096 * 320 + 2 * 2 * 16 * 77 * 320 + 4096 * 32 * 4
+                for k, r in cross16.items():
+                    if "hbm_bytes" in r:
+                        r["algorithmic_bytes"] = alg16
+                        r["traffic_over_algorithmic"] = round(r["hbm_bytes"] / alg16, 2)
+                result["counters_cross_route_16rows"] = {"case": CROSS16_COUNTER_CASE[1], "kernels": cross16, "traffic_correction": TRAFFIC_CORRECTION,
+                                                         "source": "LIVE: rocprofv3 --pmc passes of this run over tests/native/attn_check --product-only --only %s" % CROSS16_COUNTER_CASE[0]}
+            log("live counters done in %.1f s" % (time.perf_counter() - t_pmc), lv, cross, cross16)
         from pww_hip import _lib as _pww_lib
         _pww_lib.load().pww_profile_reset()
     if rank == 0 and world == 1 and not args.no_reference_ops and cfg["kind"] == "txt2img":

@@ -108,6 +108,16 @@ void attn_fill_params(AttnParams &p, const void *q, const void *k, const void *v
     p.stats = nullptr; p.stat_kind = PWW_STAT_NONE; p.stat_count = 1.0; p.coeff_scalar = 1.f;
     p.coeff_scalar_dev = nullptr; p.bias_cols = 0; p.timeline = debug_timeline();
     p.pair_major = ((d->B * d->H) % 8 == 0 && d->B * d->H >= pair_major_min() && !bias) ? 1 : 0;
+    // d = 40: a head's 80-byte slice shares its 128-byte lines with its neighbours: keep groups of adjacent heads on one XCD (wg_to_pair_block;
+    // contiguous heads only: h stride = D elements in q, k, v and o). PWW_DEBUG=attn_head_pairs=0: round 5's order, 4: groups of four (A/B)
+    {
+        const int G = debug_knobs().attn_head_pairs, BH = d->B * d->H;
+        const bool contiguous = d->q_stride[1] == d->D && d->k_stride[1] == d->D && d->v_stride[1] == d->D && d->o_stride[1] == d->D;
+        if (p.pair_major && (d->D * 2) % 128 != 0 && contiguous && G >= 2) {
+            if (G >= 4 && d->H % 4 == 0 && BH % 32 == 0) p.pair_major = 4;
+            else if (d->H % 2 == 0 && BH % 16 == 0) p.pair_major = 2;
+        }
+    }
     p.o_wide = (d->o_stride[0] % 8 == 0 && d->o_stride[1] % 8 == 0 && d->o_stride[2] % 8 == 0 && wide_store_mode()) ? 1 : 0;
     p.timeline_wgs = (unsigned)(debug_timeline_bytes() / (TL_SLOTS * sizeof(unsigned long long)));
     // folded-reference d = 40 kernel (pww_attn_kernel.h): FoldLimit of the storage type (PWW_DEBUG=attn_fold_limit_f16=n overrides the f16 one, A/B),

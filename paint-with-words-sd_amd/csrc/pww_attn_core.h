@@ -27,7 +27,7 @@ struct AttnParams {
                                      // hipGraph serves every denoise step, the host rewrites the word before each replay)
     int bias_cols;                   // columns >= bias_cols of the bias map are zero (multiple of 16, <= M rounded up); 0 = unknown
     int o_wide;                      // 1: rows of O are 16-byte aligned (o strides % 8 == 0): 16-byte epilogue stores
-    int pair_major;                  // 1: workgroups of one (image, head) pair run on ONE XCD, pairs dealt round-robin to the XCDs
+    int pair_major;                  // 1: workgroups of one (image, head) pair run on ONE XCD, pairs dealt round-robin to the XCDs; 2 / 4: groups of 2 / 4 adjacent heads per XCD
     unsigned long long *timeline;    // debug: per-workgroup phase time stamps (pww_debug_timeline), normally null
     unsigned timeline_wgs;           // workgroups the debug buffer has room for
     // folded-reference self-attention (d = 40): the magnitude guard's limit on |row maximum| in exp2 units (FoldLimit<T>), the first-stage row
@@ -57,7 +57,18 @@ __device__ __forceinline__ float coeff_scalar_of(const AttnParams &p) {
 // one after the other, all query blocks of a pair together -- a pair's K/V is fetched into one L2 once.
 __device__ __forceinline__ void wg_to_pair_block(const AttnParams &p, int nqb, int &bh, int &qb) {
     const int BH = p.B * p.H;
-    if (p.pair_major) {
+    if (p.pair_major >= 2) {
+        // Head dims whose slices are not whole 128-byte lines (d = 40: 80 bytes of a 640-byte row): an L2 read request moves the WHOLE line
+        // (tools/ubench_linefill.cpp: a 32-, 64- or 80-byte touch costs what 128 bytes cost), and with every head on its own XCD the eight
+        // L2s fetch a row's 5 lines 12 times -- 2.4x on the read side, which rounds 2 - 5 read as 1.2x because FETCH_SIZE tallies a
+        // request at 64 bytes (profiles/r06_sector_sharing.md). Here XCD x takes GROUPS of G = 2 (4) adjacent heads -- 8 (6) line fills
+        // per row -- the heads of a group alternating query block by query block; a group's K / V (1.3 / 2.6 MB at N = 4096) fit its L2.
+        const int lg = p.pair_major == 4 ? 2 : 1, G = 1 << lg;
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int t = j % (G * nqb);
+        qb = t >> lg;
+        bh = (((j / (G * nqb)) * 8 + xcd) << lg) + (t & (G - 1));
+    } else if (p.pair_major) {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         qb = j % nqb;
         bh = (j / nqb) * 8 + xcd;

@@ -60,6 +60,8 @@ struct DebugKnobs {
     int attn_fold = 1;             // folded-reference d = 40 kernel: 0 never / 1 bf16 and fp16 / 2 bf16 only
     int attn_nw8 = 1;              // 0: no 8-wave workgroups
     int attn_pair_major = 16;      // pair-major workgroup order from this many (image, head) pairs on (0: never)
+    int attn_head_pairs = 2;       // head slices that are not whole 128-byte lines: groups of 2 (4) adjacent heads on one XCD; 0: round 5's order
+    int cross_head_major = 1;      // multi-block cross kernel: the heads of one (image, query chunk) adjacent on one XCD; 0: round 5's order
     int attn_wide_store = 1;       // 0: 8-byte instead of 16-byte epilogue stores
     int cross_wg_per_cu = 4;       // upper bound on the resident workgroups per CU the hand-off launch counts on
     int cross_assume_resident = 0; // TEST HOOK: count on n workgroups per CU whatever the occupancy query says (drives the time-out path)

@@ -33,6 +33,7 @@ struct CrossParams {
     // hand-off, no residency requirement, Q read once -- the kernel boundary was the synchronisation.
     const double *ext_part;
     int ext_nparts;
+    int head_major;      // workgroup order: the heads of one (image, query chunk) unit adjacent on one XCD (needs a multiple of 8 units)
     int pass2_only;      // host side: the launch has no hand-off (external partials, or no statistic asked for through pww_cross_attn_fwd_parts): any grid is correct
 };
 
@@ -210,7 +211,19 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_fused_kernel
     // order (heads fastest) every XCD's L2 ends up fetching the whole map (measured: 11.9 MB fetched per launch for 6.7 MB of
     // distinct bytes); dealing query chunk c to XCD c % 8 for every head fetches each bias tile once.
     int bh, chunk, nchunk = cp.nchunk;
-    if (cp.n_gated > 0) {
+    if (cp.head_major) {
+        // (round 6) ... and the H heads of one (image, query chunk) unit ADJACENT on one XCD, for every grid the host may choose: besides
+        // the unit's bias rows they share 32-byte sectors of Q and O where a head's slice is not a whole number of sectors (d = 40: 80
+        // bytes -- 96 moved per 80 with the heads on eight XCDs, which is what 16 images x 4 chunks got: 107.5 MB for 86.7,
+        // profiles/r04_pmc_cross_route.json). XCD x takes the units x, x + 8, ...; the hinted-in images' units come first.
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int h_ = j % p.H, unit = (j / p.H) * 8 + xcd;
+        const int first = cp.n_gated * cp.nchunk;
+        int b_;
+        if (unit < first) { b_ = unit % cp.n_gated; chunk = unit / cp.n_gated; }
+        else { const int i = unit - first, ub = p.B - cp.n_gated; b_ = cp.n_gated + i % ub; chunk = i / ub; nchunk = cp.nchunk_u; }
+        bh = b_ * p.H + h_;
+    } else if (cp.n_gated > 0) {
         // two classes of images (see CrossParams::n_gated): the workgroups of the hinted-in images come first
         const int gh = cp.n_gated * p.H, first = gh * cp.nchunk;
         if ((int)blockIdx.x < first) { bh = blockIdx.x % gh; chunk = blockIdx.x / gh; }
@@ -833,6 +846,7 @@ static int launch_cross(CrossParams cp, hipStream_t stream, bool *launched) {
         if (best_c != best_u) { cp.n_gated = hint; cp.nchunk = (int)best_c; cp.nchunk_u = (int)best_u; }
     }
     const long n_wgs = cp.n_gated ? (long)p.H * (cp.n_gated * (long)cp.nchunk + (p.B - cp.n_gated) * (long)cp.nchunk_u) : BH * nchunk;
+    cp.head_major = ((n_wgs / p.H) % 8 == 0 && debug_knobs().cross_head_major) ? 1 : 0;
     const bool single = cp.nchunk == cp.nqb && cp.nchunk_u == cp.nqb;
     cp.tile_nbuf = 1;
     if (!COMPACT && !single && cp.tile_stride > 0 && bias_tile_mode() == 1) {

@@ -193,8 +193,9 @@ def test_fp16_hot_rows_leave_the_range_free_mode_not_the_fast_path(gpu_device, s
 
 
 def test_fp16_rows_past_the_magnitude_guard_take_the_exact_path(gpu_device):
-    """Scaled-logit std 8 (row maxima of 29 natural units and more: past the 33-unit guard for many rows): those workgroups recompute on the
-    exact-scale path -- counted as such -- and the result stays inside the per-call bar."""
+    """Scaled-logit std 8 (row maxima of 29 natural units and more: past the 33-unit guard for many rows) in the 4-WAVE form (one image of
+    2048 rows; it has no registers for the exact-scale loop): those workgroups recompute on exact_rows -- counted as such -- and the result
+    stays inside the per-call bar."""
     from pww_hip import ops
     B, N, H, D = 1, 2048, 8, 40
     g = torch.Generator().manual_seed(3)
@@ -212,12 +213,12 @@ def test_fp16_rows_past_the_magnitude_guard_take_the_exact_path(gpu_device):
     assert paths["exact"] > 0 and torch.isfinite(out).all() and err <= 2e-3
 
 
-@pytest.mark.parametrize("std,B,N", [(6.0, 2, 4096), (7.0, 2, 4096), (6.0, 3, 4000)])
+@pytest.mark.parametrize("std,B,N", [(6.0, 2, 4096), (7.0, 2, 4096), (8.0, 2, 4096), (6.0, 3, 4000), (8.0, 3, 4000)])
 def test_fp16_rows_past_the_guard_continue_on_the_exact_scale(gpu_device, std, B, N):
     """fp16, 8-wave workgroups (B = 2, N = 4096), scaled-logit std 6 / 7: rows whose logits pass the magnitude guard (33 natural units) no longer
     send their workgroup through a second pass -- the workgroup continues with the unscaled Q and P = exp2(x c1) from the stage where the
-    reference comes close to the limit (`raw` workgroups), inside the per-call bar; only a first key stage that is already past the limit
-    still takes exact_rows."""
+    reference comes close to the limit (`raw` workgroups), inside the per-call bar; a FIRST key stage that is already past the limit (std 7 / 8:
+    most workgroups) starts over in that mode: no workgroup of the 8-wave form takes exact_rows any more."""
     from pww_hip import ops
     H, D = 8, 40           # (N = 4000: a ragged last key stage -- 32 keys -- and a ragged last query block, in the exact-scale mode)
     g = torch.Generator().manual_seed(7)
@@ -235,5 +236,26 @@ def test_fp16_rows_past_the_guard_continue_on_the_exact_scale(gpu_device, std, B
         err = max(err, (out[b, rows].double().cpu() - ref).abs().max().item() / ref.abs().max().item())
     print(f"fp16 d=40 scaled-logit std {std}: workgroups {paths}; max err / max|O| = {err:.2e}")
     assert sum(paths.values()) == B * H * ((N + 255) // 256) and paths["raw"] > 0 and paths["fast"] == 0
-    assert paths["exact"] <= (0.07 if std == 6.0 else 1.0) * sum(paths.values())          # (only workgroups whose FIRST stage is already past the limit)
+    assert paths["exact"] == 0
     assert torch.isfinite(out).all() and err <= 2e-3
+
+
+# ---- workgroup orders that keep adjacent heads on one XCD (d = 40: 80-byte slices of 128-byte lines) --------------------------------------
+
+def test_head_group_workgroup_orders_are_bit_identical_to_round5s(gpu_device):
+    """Round 6 deals the workgroups of the d = 40 self-attention launches in groups of two adjacent heads per XCD and the multi-block
+    cross-attention launch with all heads of an (image, query chunk) unit on one XCD (a read request moves a whole 128-byte line: 12 line
+    fills per 640-byte row became 8 and 5, profiles/r06_sector_sharing.md). Both are permutations of the grid: every output must be
+    BIT-identical to round 5's order (PWW_DEBUG=attn_head_pairs=0,cross_head_major=0; own processes: the library reads its knobs once) and
+    inside the per-call bars -- self-attention at 2 / 3 / 4 / 16 rows (even and odd pair counts, ragged N, hot logits), d = 80 / 160, and the
+    batched cross route with partials, the 32-column bound and the gated-images hint at 16 / 8 / 6 rows (unit counts that are and are not a
+    multiple of 8)."""
+    script = os.path.join(cases.REPO, "tools", "diag_wg_order.py")
+    runs = {}
+    for name, knobs in (("round 6", ""), ("round 5", "attn_head_pairs=0,cross_head_major=0"), ("groups of four", "attn_head_pairs=4")):
+        out = subprocess.run(["timeout", "600", sys.executable, script], capture_output=True, text=True, env=dict(os.environ, PWW_DEBUG=knobs))
+        assert out.returncode == 0, (name, out.stdout[-2000:], out.stderr[-2000:])
+        runs[name] = [l for l in out.stdout.splitlines() if l.startswith("CASE")]
+        assert len(runs[name]) == 20 and not [l for l in runs[name] if "FAIL" in l]
+    print("\n".join(runs["round 6"]))
+    assert runs["round 6"] == runs["round 5"] == runs["groups of four"]

@@ -87,6 +87,54 @@ hot)
   rm -f $O/r6_hot.md
   for v in "" "attn_hot_sum=0" "attn_hot_sum=-1" "attn_fold_limit_f16=44" "attn_fold_limit_f16=52"; do PWW_DEBUG="$v" timeout 600 python tools/diag_hot_f16.py 2>&1 | grep "^|" | tee -a $O/r6_hot.md; echo >> $O/r6_hot.md; done
   ;;
+sectors)
+  # d = 40: heads 2m / 2m + 1 share a 32-byte sector of every Q / K / V / O row. A/B of the workgroup orders that keep them on one XCD:
+  # HBM-side traffic (FETCH_SIZE / WRITE_SIZE passes) and time of the dominant self-attention launch (2 and 16 rows) and the 16-row cross launch
+  rm -f $O/r6_sectors.log
+  for v in "" "attn_head_pairs=0,cross_head_major=0"; do
+    echo "=== PWW_DEBUG=$v" | tee -a $O/r6_sectors.log
+    (cd tests/native && for c in sd15_self_n4096_d40_bf16_b2 sd15_self_n4096_d40_f16_b16 qproj_sd15_n4096_b16; do PWW_DEBUG="$v" timeout 200 ./attn_check --only $c 2>&1 | grep "^TIME\|^FAIL"; done) | cut -c1-330 | tee -a $O/r6_sectors.log
+    t=default; [ -n "$v" ] && t=round5
+    for c in sd15_self_n4096_d40_bf16_b2 sd15_self_n4096_d40_f16_b16 qproj_sd15_n4096_b16; do
+      f=""; [ $c == qproj_sd15_n4096_b16 ] && f="--product-only"
+      PWW_DEBUG="$v" bash tools/pmc_traffic.sh $c gpurun_out/pmc_sectors_${t}_$c $f 2>&1 | sed "s/^/$c: /" | tee -a $O/r6_sectors.log
+    done
+  done
+  ;;
+sectors4)
+  # groups of FOUR heads per XCD at 16 rows (6 line fills per row instead of 8; 2.6 MB of K / V per group and L2) against groups of two; and the
+  # small self-attention launches (d = 80 / 160: 160- / 320-byte slices share lines too) under the new order against round 5's
+  rm -f $O/r6_sectors4.log
+  for v in "attn_head_pairs=4" "" "attn_head_pairs=0"; do
+    echo "=== PWW_DEBUG=$v" | tee -a $O/r6_sectors4.log
+    (cd tests/native && for c in sd15_self_n4096_d40_f16_b16 sd15_self_n4096_d40_bf16_b16 sd15_self_n4096_d40_bf16_b2 sd15_self_n1024_d80 sd15_self_n256_d160; do PWW_DEBUG="$v" timeout 200 ./attn_check --only $c 2>&1 | grep "^TIME\|^FAIL"; done) | cut -c1-200 | tee -a $O/r6_sectors4.log
+  done
+  for v in "attn_head_pairs=4"; do
+    PWW_DEBUG="$v" bash tools/pmc_traffic.sh sd15_self_n4096_d40_f16_b16 gpurun_out/pmc_sectors_quads_f16_b16 2>&1 | grep -A12 fold_kernel | tee -a $O/r6_sectors4.log
+  done
+  for v in "" "attn_head_pairs=0"; do PWW_DEBUG="$v" timeout 300 python tools/time_small_attn.py self --out $O/r6_sectors4_small.md 2>&1 | grep -v amdgpu.ids | tail -6 | tee -a $O/r6_sectors4.log; done
+  ;;
+linefill)
+  # what one TCC_EA0_RDREQ moves (tools/ubench_linefill.cpp): time per touched line for full / half / sector / head-slice reads of a 2 GiB buffer,
+  # and the request counters of the same kernels
+  timeout 300 tools/ubench_linefill 2048 | tee $O/r6_linefill.txt
+  export TMPDIR=/tmp; R=$PWD; cd /tmp
+  for c in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "FETCH_SIZE" "TCC_MISS_sum TCC_HIT_sum"; do
+    n=$(echo $c | tr ' ' '_')
+    timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmc_linefill/$n -o pmc -- $R/tools/ubench_linefill 2048 > $R/gpurun_out/pmc_linefill_$n.log 2>&1
+  done
+  cd $R
+  python3 - <<'PY' | tee -a $O/r6_linefill.txt
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob('gpurun_out/pmc_linefill/*/**/*counter_collection.csv', recursive=True):
+    for row in csv.DictReader(open(f)):
+        if 'reader' in row['Kernel_Name']: agg[row['Kernel_Name']][row['Counter_Name']].append(float(row['Counter_Value']))
+for k, d in sorted(agg.items()):
+    # the LAST dispatch of each kernel is a full-size one (the first is the 1/16 warm-up)
+    print(k[:60], {c: max(v) for c, v in sorted(d.items())})
+PY
+  ;;
 smallself)
   # self-attention N = 1024 d = 80 at 2 rows: 2 x 4 half-tile key groups (default) against round 5's 2 x 2
   rm -f $O/r6_smallself.md

@@ -36,7 +36,7 @@ for case in sorted(os.listdir(out)):
             for c in ('SQ_ACTIVE_INST_ANY', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY'):
                 if c in m: m[c + '_frac_of_wave_cycles'] = m[c] / m['SQ_WAVE_CYCLES']
         if 'FETCH_SIZE' in m and 'WRITE_SIZE' in m:
-            m['hbm_side_bytes'] = (m['FETCH_SIZE'] + m['WRITE_SIZE']) * 1024.0
+            m['hbm_side_bytes'] = (2.0 * m['FETCH_SIZE'] + m['WRITE_SIZE']) * 1024.0      # a read request moves a 128-byte line, FETCH_SIZE tallies 64 (profiles/r06_linefill.txt; rounds 4 - 5 summed them 1 : 1)
         res.setdefault(case, {})[k[:110]] = m
         print(case, '|', k[:90])
         for c, v in sorted(m.items()): print('     %-34s %16.4f' % (c, v))
