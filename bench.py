@@ -937,9 +937,9 @@ def main():
                         r["traffic_over_algorithmic"] = round(r["hbm_bytes"] / alg[k], 2)
                 result["counters_cross_route"] = {"case": CROSS_COUNTER_CASE[1], "kernels": cross, "traffic_correction": TRAFFIC_CORRECTION,
                                                   "source": "LIVE: rocprofv3 --pmc passes of this run over tests/native/attn_check --product-only --only %s" % CROSS_COUNTER_CASE[0]}
-            # the batched route (configs 3 / 4: 16 folded rows, N = 4096, C = 320): the general kernel with several query blocks per workgroup
+            # the batched route (configs 3 / 4: 16 folded rows, N = 4096, C = 320): the small kernel walking several query blocks per workgroup
             # (VERDICT round 5 item 5). Algorithmic bytes: Q + O (2 x 2 B N C) + K / V (2 x 2 B M C) + the shared map's 32-column span (N x 32 x 4)
-            cross16 = live_counters(CROSS16_COUNTER_CASE[0], ["cross_fused_kernel"], flags=("--product-only",))
+            cross16 = live_counters(CROSS16_COUNTER_CASE[0], ["cross_lean_kernel", "cross_fused_kernel"], flags=("--product-only",))
             if cross16:
                 alg16 = 2 * 2 * 16 * 4096 * 320 + 2 * 2 * 16 * 77 * 320 + 4096 * 32 * 4
                 for k, r in cross16.items():

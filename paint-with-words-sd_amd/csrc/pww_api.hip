@@ -31,7 +31,7 @@ const DebugKnobs &debug_knobs() {
             {"attn_rf", &k.attn_rf}, {"attn_ksplit", &k.attn_ksplit}, {"attn_fold", &k.attn_fold}, {"attn_nw8", &k.attn_nw8},
             {"attn_pair_major", &k.attn_pair_major}, {"attn_head_pairs", &k.attn_head_pairs}, {"cross_head_major", &k.cross_head_major}, {"attn_wide_store", &k.attn_wide_store}, {"cross_wg_per_cu", &k.cross_wg_per_cu},
             {"cross_assume_resident", &k.cross_assume_resident}, {"cross_gate_weight", &k.cross_gate_weight},
-            {"cross_tile_nbuf", &k.cross_tile_nbuf}, {"cross_bias_lds", &k.cross_bias_lds}, {"cross_lean", &k.cross_lean},
+            {"cross_tile_nbuf", &k.cross_tile_nbuf}, {"cross_bias_lds", &k.cross_bias_lds}, {"cross_lean", &k.cross_lean}, {"cross_lean_multi", &k.cross_lean_multi},
             {"cross_lean_nw", &k.cross_lean_nw}, {"attn_ksplit_nw", &k.attn_ksplit_nw}, {"attn_ksplit1", &k.attn_ksplit1}, {"attn_ksplit_half", &k.attn_ksplit_half},
             {"attn_hot_sum", &k.attn_hot_sum}, {"attn_fold_limit_f16", &k.attn_fold_limit_f16}};
         const char *p = e;

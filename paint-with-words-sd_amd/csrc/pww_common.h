@@ -69,6 +69,7 @@ struct DebugKnobs {
     int cross_tile_nbuf = 2;       // 1: never double-buffer the bias tile
     int cross_bias_lds = 2;        // bias rows: 0 per lane from global memory / 1 LDS tile in single-block launches only / 2 LDS tile everywhere
     int cross_lean = 1;            // pass-2-only launches on the small kernel (pww_cross_lean.hip): 0 never / 1 where it fits (default) / 2 also for large batches
+    int cross_lean_multi = 1;      // batched launches (> 1024 blocks of 128 rows, head dim <= 64): the small kernel walking several blocks per workgroup; 0: the general kernel (round 5)
     int cross_lean_nw = 0;         // waves per workgroup of that kernel: 0 by problem size / 2 / 4
     int attn_ksplit1 = 0;          // 1: the small self-attention launches (N >= 512 at d = 80 / 96, N >= 128 at d = 128 / 160) on the single-buffered key-split kernel of round 5 (measured slower: default off)
     int attn_hot_sum = 8;          // f16 d = 40 self-attention: a workgroup whose first key stage leaves a row sum below this follows the running maximum lazily (0: never -- round 5; -1: always)

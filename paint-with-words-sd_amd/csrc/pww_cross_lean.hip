@@ -235,6 +235,8 @@ struct LeanParams {
     double *stats_out;        // optional [B][4]
     int nqb;                  // query blocks per (image, head)
     int tile_stride;          // floats per LDS tile row (16 / 32 / 64: bias_cols rounded up to a power of two)
+    int nchunk;               // MULTI: workgroups per (image, head); workgroup c walks the query blocks c, c + nchunk, ...
+    int head_major;           // MULTI: the H heads of one (image, chunk) unit adjacent on one XCD (needs B * nchunk % 8 == 0)
 };
 
 constexpr int LEAN_PUNROLL = 4;        // partials per lane folded from the prologue's load batch (256 per image); more take the tail loop
@@ -250,8 +252,15 @@ constexpr int LEAN_ROWS = 2 * KVBLK;   // key rows the LDS image has room for (o
 // offset and one LDS address per operand, computed once; pass i adds a uniform step (global side) and an immediate (LDS side); rows past
 // M, the head-dim padding and idle threads are out of range of the buffer descriptor (zeros, no memory traffic) -- no compare, no select,
 // no branch per chunk. Grid = (query block, head, image): no integer division either.
-template <typename T, int KS, int DT, int NW>
-__global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_lean_kernel(const LeanParams lp) {
+//
+// MULTI (round 6: the batched launches -- 16 folded rows x 4096 tokens = 4096 query blocks -- which round 5 left to the general kernel of
+// pww_cross.hip): the same kernel walking SEVERAL query blocks per workgroup, the next block's Q fragments and bias rows in flight under the
+// current block's MFMAs; K / V staged and the partials folded once per workgroup. At 16 rows the launch is bound by bytes in flight (94 MB
+// in 38 us with the general kernel: 256 VGPRs = 2 waves per SIMD, one block ahead): this form fits 168 registers at d = 40 -- 3 workgroups per CU, as
+// many as the LDS holds (d = 64: 2, it spilled at 168) -- and keeps the grid 1-D with the heads of one (image, chunk) unit adjacent on one XCD (they share the lines of every Q / O row:
+// profiles/r06_sector_sharing.md).
+template <typename T, int KS, int DT, int NW, bool MULTI = false>
+__global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : (MULTI && KS <= 3) ? 3 : 2)) cross_lean_kernel(const LeanParams lp) {
     typedef typename Vec<T>::v8 V8;
     typedef KTile<KS> KT;
     typedef VTile<DT> VT;
@@ -268,7 +277,19 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_lean_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
-    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;      // query block c of every head on XCD c % 8 when there are 8 k blocks: the heads share its bias rows
+    int qb, h, b;
+    if constexpr (MULTI) {
+        if (lp.head_major) {
+            const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+            const int unit = (j / p.H) * 8 + xcd;
+            h = j % p.H; b = unit % p.B; qb = unit / p.B;
+        } else {
+            const int bh = blockIdx.x % (p.B * p.H);
+            qb = blockIdx.x / (p.B * p.H); b = bh / p.H; h = bh - b * p.H;
+        }
+    } else {
+        qb = blockIdx.x; h = blockIdx.y; b = blockIdx.z;      // query block c of every head on XCD c % 8 when there are 8 k blocks: the heads share its bias rows
+    }
     tl_stamp(p, 0);
 
     // ---- every global load of the workgroup, before anything is waited for: gate, partials, Q fragments, K / V chunks, bias rows
@@ -298,10 +319,11 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_lean_kernel(
     const T *Kp = reinterpret_cast<const T *>(p.k) + b * p.k_sb + h * p.k_sh;
     const T *Vp = reinterpret_cast<const T *>(p.v) + b * p.v_sb + h * p.v_sh;
     T *Op = reinterpret_cast<T *>(p.o) + b * p.o_sb + h * p.o_sh;
-    const int qrow = (qb * NW + wave) * 32 + l31;
-    const bool qvalid = qrow < p.N;
+    int qrow = (qb * NW + wave) * 32 + l31;
+    bool qvalid = qrow < p.N;
     V8 qf[KS];
-    load_q_frags_buf<T, KS>(qf, head_srd(Qp, p.N, p.q_sn, p.D), (unsigned)((long)qrow * p.q_sn * 2), hi, p.D);      // (rows past N: beyond the descriptor)
+    const auto srd_q = head_srd(Qp, p.N, p.q_sn, p.D);
+    load_q_frags_buf<T, KS>(qf, srd_q, (unsigned)((long)qrow * p.q_sn * 2), hi, p.D);      // (rows past N: beyond the descriptor)
 
     // K / V: thread -> (row kr of a pass, 16-byte column kc); pass i = rows i * KRPP .. of the head
     u32x4 kreg[KPASS], vreg[VPASS];
@@ -334,6 +356,7 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_lean_kernel(
 #pragma unroll
         for (int i = 0; i < LEAN_TILE_LOADS; ++i) treg[i] = __builtin_amdgcn_raw_buffer_load_b128(bias.srd, i < tile_passes ? t0 + (unsigned)i * tstep : OOB_OFF, 0, 0);
     }
+    [[maybe_unused]] const unsigned tstep_m = (unsigned)(tile_rp * p.b_sn * 4);
     tl_stamp(p, 6);
 
     // ---- fold the image's partials: EVERY WAVE folds all of them itself (<= 4 per lane from the batch above, shuffles only -- no LDS, no
@@ -425,33 +448,71 @@ __global__ void __launch_bounds__(NW * 64, (DT >= 4 ? 1 : 2)) cross_lean_kernel(
     // ---- scores -> (bias) -> softmax -> PV: the FIRST 64-key tile is all live (the host sends M < 64 to the general kernel), sets the row's
     // reference and starts O^T from a zero constant (STEP 1); the second keeps that reference unless a score exceeds it by 2^8 (STEP 2)
     const float c1 = p.scale_log2e;
-    f32x16 oacc[DT];
-    float m_run = -INFINITY, l_run = 0.f;
-    if (biased) {
-        attn_tile<T, KS, DT, 2, false, RSM, 1>(oacc, m_run, l_run, qf, Kl, Vl, 0, p.M, l31, hi, bias, coeff, c1);
-        if (KVBLK < p.M)
-            attn_tile<T, KS, DT, 2, true, RSM, 2>(oacc, m_run, l_run, qf, Kl + KT::BYTES, Vl + VT::BYTES, KVBLK, p.M, l31, hi, bias, coeff, c1);
-    } else {
-        attn_tile<T, KS, DT, 0, false, RSM, 1>(oacc, m_run, l_run, qf, Kl, Vl, 0, p.M, l31, hi, bias, coeff, c1);
-        if (KVBLK < p.M)
-            attn_tile<T, KS, DT, 0, true, RSM, 2>(oacc, m_run, l_run, qf, Kl + KT::BYTES, Vl + VT::BYTES, KVBLK, p.M, l31, hi, bias, coeff, c1);
-    }
-    float l_tot;
-    if (RSM) {      // row D of O^T: tile D / 32, register (D % 32) / 2, held by the hi == 0 half
-        const int rl = p.D & 31, tl = p.D >> 5;
-        float lv = 0.f;
+    for (;;) {
+        // MULTI: the NEXT block's Q fragments and bias rows are requested before this block is computed (a block past the last one:
+        // beyond the descriptors -- zeros, no traffic)
+        [[maybe_unused]] V8 qn[KS];
+        constexpr int TLN = 4;            // MULTI takes maps of at most 32 staged columns (the host's rule): 4 pieces per lane
+        [[maybe_unused]] u32x4 tn[TLN];
+        [[maybe_unused]] const int nblk = qb + lp.nchunk;
+        if constexpr (MULTI) {
+            // (K / V fragments are the same for every block: left alone, hipcc hoists their LDS reads out of this loop and spills 88 - 136 bytes
+            // per lane at the 168 registers three waves per SIMD leave)
+            asm volatile("" ::: "memory");
+            const int nrow = (nblk * NW + wave) * 32 + l31;
+            load_q_frags_buf<T, KS>(qn, srd_q, nblk < lp.nqb ? (unsigned)((long)nrow * p.q_sn * 2) : OOB_OFF, hi, p.D);
+            if (biased) {
+                const unsigned t0 = (t_col && nblk < lp.nqb) ? (unsigned)((((long)(nblk * NW + wave) * 32 + rowl0) * p.b_sn + pc * 4) * 4) : OOB_OFF;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const float c = rl == 0 ? oacc[dt][0] : rl == 8 ? oacc[dt][4] : rl == 16 ? oacc[dt][8] : oacc[dt][12];
-            lv = dt == tl ? c : lv;
+                for (int i = 0; i < TLN; ++i) tn[i] = __builtin_amdgcn_raw_buffer_load_b128(bias.srd, i < tile_passes ? t0 + (unsigned)i * tstep_m : OOB_OFF, 0, 0);
+            }
         }
-        const float other = __shfl_xor(lv, 32);
-        l_tot = hi ? other : lv;
-    } else {
-        l_tot = l_run + __shfl_xor(l_run, 32);
+        f32x16 oacc[DT];
+        float m_run = -INFINITY, l_run = 0.f;
+        if (biased) {
+            attn_tile<T, KS, DT, 2, false, RSM, 1>(oacc, m_run, l_run, qf, Kl, Vl, 0, p.M, l31, hi, bias, coeff, c1);
+            if (KVBLK < p.M)
+                attn_tile<T, KS, DT, 2, true, RSM, 2>(oacc, m_run, l_run, qf, Kl + KT::BYTES, Vl + VT::BYTES, KVBLK, p.M, l31, hi, bias, coeff, c1);
+        } else {
+            attn_tile<T, KS, DT, 0, false, RSM, 1>(oacc, m_run, l_run, qf, Kl, Vl, 0, p.M, l31, hi, bias, coeff, c1);
+            if (KVBLK < p.M)
+                attn_tile<T, KS, DT, 0, true, RSM, 2>(oacc, m_run, l_run, qf, Kl + KT::BYTES, Vl + VT::BYTES, KVBLK, p.M, l31, hi, bias, coeff, c1);
+        }
+        float l_tot;
+        if (RSM) {      // row D of O^T: tile D / 32, register (D % 32) / 2, held by the hi == 0 half
+            const int rl = p.D & 31, tl = p.D >> 5;
+            float lv = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const float c = rl == 0 ? oacc[dt][0] : rl == 8 ? oacc[dt][4] : rl == 16 ? oacc[dt][8] : oacc[dt][12];
+                lv = dt == tl ? c : lv;
+            }
+            const float other = __shfl_xor(lv, 32);
+            l_tot = hi ? other : lv;
+        } else {
+            l_tot = l_run + __shfl_xor(l_run, 32);
+        }
+        const float inv = 1.f / l_tot;
+        store_o_block<T, DT>(Op + (long)(qvalid ? qrow : 0) * p.o_sn, oacc, inv, p.D, hi, qvalid, p.o_wide != 0);
+        if constexpr (!MULTI) break;
+        else {
+            if (nblk >= lp.nqb) break;       // (workgroup-uniform)
+            qb = nblk;
+            qrow = (qb * NW + wave) * 32 + l31;
+            qvalid = qrow < p.N;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) qf[ks] = qn[ks];
+            // the wave's own rows of the tile: its reads of the block just computed are behind it in program order (LDS runs in order per wave)
+            if (biased && t_col) {
+#pragma unroll
+                for (int i = 0; i < TLN; ++i)
+                    if (i < tile_passes) {
+                        const int row = wave * 32 + rowl0 + i * tile_rp;
+                        *reinterpret_cast<u32x4 *>(tile + (long)row * lp.tile_stride * 4 + ((pc ^ tile_swz(row, 1 << cprl)) << 4)) = tn[i];
+                    }
+            }
+        }
     }
-    const float inv = 1.f / l_tot;
-    store_o_block<T, DT>(Op + (long)(qvalid ? qrow : 0) * p.o_sn, oacc, inv, p.D, hi, qvalid, p.o_wide != 0);
     tl_stamp(p, 4);
 }
 
@@ -480,6 +541,56 @@ static int launch_lean(LeanParams lp, hipStream_t stream) {
     if (lp.a.H > 65535 || lp.a.B > 65535) { set_error("cross_attn_lean: more than 65535 heads or images"); return PWW_EINVAL; }
     launch_attn_kernel(kern, dim3((unsigned)lp.nqb, (unsigned)lp.a.H, (unsigned)lp.a.B), dim3(NW * 64), lds, stream, lp);
     return check_hip(hipGetLastError(), "cross_lean_kernel launch");
+}
+
+// MULTI: several query blocks per workgroup. Workgroups per (image, head) = what is resident at once (by LDS and registers: the occupancy query), at
+// most one per block; with B * nchunk a multiple of 8 the heads of a unit share an XCD (a slightly smaller grid is taken for that when it costs
+// at most a quarter of the workgroups).
+static int lean_device_cus() {
+    static thread_local int cus[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev >= 0 && dev < 8 && cus[dev]) return cus[dev];
+    hipDeviceProp_t prop;
+    const int n = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (dev >= 0 && dev < 8) cus[dev] = n;
+    return n;
+}
+template <typename T, int KS, int DT, int NW>
+static int launch_lean_multi(LeanParams lp, hipStream_t stream) {
+    constexpr size_t stage = (size_t)LEAN_ROWS * (KTile<KS>::STRIDE + VTile<DT>::STRIDE);
+    const size_t lds = stage + (size_t)NW * 32 * lp.tile_stride * 4;
+    auto kern = cross_lean_kernel<T, KS, DT, NW, true>;
+    static thread_local size_t lds_attr[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // per device
+    static thread_local int per_cu_seen[8][3] = {};                          // per device and tile stride (16 / 32 / 64)
+    int dev = 0;
+    if (check_hip(hipGetDevice(&dev), "hipGetDevice")) return PWW_EHIP;
+    if (lds > 64 * 1024 && (dev >= 8 || lds > lds_attr[dev])) {
+        if (check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute"))
+            return PWW_EHIP;
+        if (dev < 8) lds_attr[dev] = lds;
+    }
+    const int ts = lp.tile_stride == 16 ? 0 : lp.tile_stride == 32 ? 1 : 2;
+    int per_cu = dev < 8 ? per_cu_seen[dev][ts] : 0;
+    if (per_cu <= 0) {
+        if (check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NW * 64, lds), "hipOccupancyMaxActiveBlocksPerMultiprocessor")) return PWW_EHIP;
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 4) per_cu = 4;
+        if (dev < 8) per_cu_seen[dev][ts] = per_cu;
+    }
+    lp.nqb = (lp.a.N + NW * 32 - 1) / (NW * 32);
+    const long BH = (long)lp.a.B * lp.a.H;
+    long nchunk = (long)per_cu * lean_device_cus() / BH;
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > lp.nqb) nchunk = lp.nqb;
+    lp.head_major = 0;
+    if (debug_knobs().cross_head_major) {
+        for (long c = nchunk; c >= 1 && 4 * c >= 3 * nchunk; --c)
+            if ((lp.a.B * c) % 8 == 0) { nchunk = c; lp.head_major = 1; break; }
+    }
+    lp.nchunk = (int)nchunk;
+    launch_attn_kernel(kern, dim3((unsigned)(BH * nchunk)), dim3(NW * 64), lds, stream, lp);
+    return check_hip(hipGetLastError(), "cross_lean_kernel (several blocks per workgroup) launch");
 }
 
 template <typename T, int NW> static int dispatch_lean_d(const LeanParams &lp, hipStream_t s) {
@@ -514,7 +625,10 @@ int cross_attn_lean(const void *q, const void *k, const void *v, void *o, const 
     // (the kernel forms offsets of rows just past N / M before the descriptors cut them off: keep them below 2^31)
     if (((long)(d->N + 128) * d->q_stride[2] + d->D) * 2 >= (1L << 31) || (long)(d->N + 128) * d->bias_stride[2] * 4 >= (1L << 31)) return PWW_OK;
     const long blocks128 = (long)d->B * d->H * ((d->N + 127) / 128);
-    if (mode == 1 && blocks128 > LEAN_MAX_BLOCKS128) return PWW_OK;
+    // beyond LEAN_MAX_BLOCKS128: the several-blocks-per-workgroup form of this kernel for head dims <= 64 (SD1.5's and SD2.1's finest level),
+    // the general kernel for the rest (PWW_DEBUG=cross_lean_multi=0: the general kernel, round 5's route)
+    const bool multi = blocks128 > LEAN_MAX_BLOCKS128 && mode == 1;
+    if (multi && (d->D > 64 || bias_cols > 32 || !debug_knobs().cross_lean_multi)) return PWW_OK;
     LeanParams lp;
     attn_fill_params(lp.a, q, k, v, o, bias, gate, d);
     lp.a.bias_coeff = gate;
@@ -532,6 +646,13 @@ int cross_attn_lean(const void *q, const void *k, const void *v, void *o, const 
     if (lean_nw_knob() == 2 && d->D <= 96) nw = 2;
     if (lean_nw_knob() == 4) nw = 4;
     int rc;
+    lp.nchunk = 1; lp.head_major = 0;
+    if (multi) {
+        if (d->dtype == PWW_DTYPE_F16) rc = d->D <= 48 ? launch_lean_multi<f16, 3, 2, 4>(lp, stream) : launch_lean_multi<f16, 4, 2, 4>(lp, stream);
+        else rc = d->D <= 48 ? launch_lean_multi<bf16, 3, 2, 4>(lp, stream) : launch_lean_multi<bf16, 4, 2, 4>(lp, stream);
+        *launched = rc == PWW_OK;
+        return rc;
+    }
     if (d->dtype == PWW_DTYPE_F16) rc = nw == 4 ? dispatch_lean_d<f16, 4>(lp, stream) : dispatch_lean_d<f16, 2>(lp, stream);
     else rc = nw == 4 ? dispatch_lean_d<bf16, 4>(lp, stream) : dispatch_lean_d<bf16, 2>(lp, stream);
     *launched = rc == PWW_OK;

@@ -248,14 +248,16 @@ def test_head_group_workgroup_orders_are_bit_identical_to_round5s(gpu_device):
     fills per 640-byte row became 8 and 5, profiles/r06_sector_sharing.md). Both are permutations of the grid: every output must be
     BIT-identical to round 5's order (PWW_DEBUG=attn_head_pairs=0,cross_head_major=0; own processes: the library reads its knobs once) and
     inside the per-call bars -- self-attention at 2 / 3 / 4 / 16 rows (even and odd pair counts, ragged N, hot logits), d = 80 / 160, and the
-    batched cross route with partials, the 32-column bound and the gated-images hint at 16 / 8 / 6 rows (unit counts that are and are not a
-    multiple of 8)."""
+    batched cross route with partials, the 32-column bound and the gated-images hint at 16 / 8 / 6 / 5 rows and SD2.1's 9216 tokens x 5 heads
+    of 64. The batched cross launches run on the small kernel's several-blocks-per-workgroup form since round 6 (34 us against the general
+    kernel's 37 at 16 rows): the same tile code in the same order -- bit-identical to the general kernel too (PWW_DEBUG=cross_lean_multi=0)."""
     script = os.path.join(cases.REPO, "tools", "diag_wg_order.py")
     runs = {}
-    for name, knobs in (("round 6", ""), ("round 5", "attn_head_pairs=0,cross_head_major=0"), ("groups of four", "attn_head_pairs=4")):
+    for name, knobs in (("round 6", ""), ("round 5", "attn_head_pairs=0,cross_head_major=0"), ("groups of four", "attn_head_pairs=4"),
+                        ("general cross kernel", "cross_lean_multi=0"), ("round 5, general cross kernel", "cross_lean_multi=0,cross_head_major=0")):
         out = subprocess.run(["timeout", "600", sys.executable, script], capture_output=True, text=True, env=dict(os.environ, PWW_DEBUG=knobs))
         assert out.returncode == 0, (name, out.stdout[-2000:], out.stderr[-2000:])
         runs[name] = [l for l in out.stdout.splitlines() if l.startswith("CASE")]
-        assert len(runs[name]) == 20 and not [l for l in runs[name] if "FAIL" in l]
+        assert len(runs[name]) == 24 and not [l for l in runs[name] if "FAIL" in l]
     print("\n".join(runs["round 6"]))
-    assert runs["round 6"] == runs["round 5"] == runs["groups of four"]
+    assert runs["round 6"] == runs["round 5"] == runs["groups of four"] == runs["general cross kernel"] == runs["round 5, general cross kernel"]

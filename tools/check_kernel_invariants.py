@@ -127,7 +127,7 @@ def main():
     for name, r in lean.items():
         if "cross_lean_kernel" in name or "qk_parts_kernel" in name:
             check(int(r["ScratchSize [bytes/lane]"]) == 0, "%s: %s VGPRs, %s B scratch (no scratch)" % (name[:60], r["VGPRs"], r["ScratchSize [bytes/lane]"]))
-    isa = kernel_isa(lean_src, r"_ZN3pww17cross_lean_kernelIDF16bLi10ELi5ELi4EEEvNS_10LeanParamsE")
+    isa = kernel_isa(lean_src, r"_ZN3pww17cross_lean_kernelIDF16bLi10ELi5ELi4ELb0EEEvNS_10LeanParamsE")
     lines = [l.strip() for l in next(iter(isa.values()))]
     nbar = sum(1 for l in lines if l.startswith("s_barrier"))
     check(nbar == 1, "cross_lean_kernel (bf16, d = 160): %d barrier(s) in the kernel (one)" % nbar)
@@ -143,7 +143,7 @@ def main():
     mf = [i for i, l in enumerate(lines) if l.startswith("v_mfma")]
     gated = sum(1 for i in mf if any(lines[j].startswith("s_waitcnt") and "lgkmcnt(0)" in lines[j] for j in range(max(0, i - 1), i)))
     check(gated * 4 <= len(mf), "cross_lean_kernel: %d of %d MFMAs directly behind a full LDS wait (at most a quarter)" % (gated, len(mf)))
-    isa = kernel_isa(lean_src, r"_ZN3pww15qk_parts_kernelIDF16bLi10ELb0EEEvNS_13QkPartsParamsE")
+    isa = kernel_isa(lean_src, r"_ZN3pww15qk_parts_kernelIDF16bLi10ELb0EEEv\w+")
     lines = [l.strip() for l in next(iter(isa.values()))]
     check(not any(l.startswith(("s_barrier", "ds_write", "ds_read")) for l in lines), "qk_parts_kernel (fine form): no barrier, no LDS traffic besides the shuffles' ds_bpermute")
     # ---- 4. (round 5) cross-attention + to_out in one launch: the two-phase form must stay inside the 256 architectural registers (past them

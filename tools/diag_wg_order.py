@@ -1,7 +1,8 @@
 """Workgroup orders of round 6 (groups of adjacent heads on one XCD: pww_attn_core.h wg_to_pair_block, pww_cross_kernel.h head_major) are
 PERMUTATIONS of the launch's workgroups: the arithmetic of every workgroup is untouched, so the results must be bit-identical to round 5's
 order (PWW_DEBUG=attn_head_pairs=0,cross_head_major=0; the library reads its knobs once per process: run this script once per setting and
-compare the lines). One line per case: sha256 of the output, max error against fp64 on sampled rows.
+compare the lines). So is the batched cross-attention launch on the small kernel's several-blocks-per-workgroup form against the general
+kernel (PWW_DEBUG=cross_lean_multi=0): same tile code, same order of operations. One line per case: sha256 of the output, max error against fp64 on sampled rows.
     python tools/diag_wg_order.py            (on a GPU box; tests/test_round6_gpu.py runs it twice)"""
 import hashlib
 import math
@@ -79,7 +80,9 @@ def main():
              ("self d=160 B=2 N=256", lambda dt: self_case(dev, dt, 2, 256, 8, 160, 7)),
              ("cross d=40 B=16 N=4096 M=77 gated 8", lambda dt: cross_case(dev, dt, 16, 4096, 8, 40, 77, 8, 8)),
              ("cross d=40 B=8 N=4096 M=77 gated 4", lambda dt: cross_case(dev, dt, 8, 4096, 8, 40, 77, 4, 9)),
-             ("cross d=40 B=6 N=4000 M=77 gated 3 (ragged)", lambda dt: cross_case(dev, dt, 6, 4000, 8, 40, 77, 3, 10))]
+             ("cross d=40 B=6 N=4000 M=77 gated 3 (ragged)", lambda dt: cross_case(dev, dt, 6, 4000, 8, 40, 77, 3, 10)),
+             ("cross d=40 B=5 N=4096 M=77 gated 2", lambda dt: cross_case(dev, dt, 5, 4096, 8, 40, 77, 2, 11)),
+             ("cross d=64 B=8 N=9216 M=77 gated 4 (SD2.1)", lambda dt: cross_case(dev, dt, 8, 9216, 5, 64, 77, 4, 12))]
     for name, fn in cases:
         for dt in (torch.float16, torch.bfloat16):
             h, err = fn(dt)

@@ -114,6 +114,16 @@ sectors4)
   done
   for v in "" "attn_head_pairs=0"; do PWW_DEBUG="$v" timeout 300 python tools/time_small_attn.py self --out $O/r6_sectors4_small.md 2>&1 | grep -v amdgpu.ids | tail -6 | tee -a $O/r6_sectors4.log; done
   ;;
+leanmulti)
+  # the batched cross launch (16 rows x 4096 tokens): the small kernel walking several blocks per workgroup (default) against the general kernel
+  rm -f $O/r6_leanmulti.log
+  for v in "" "cross_lean_multi=0"; do
+    echo "=== PWW_DEBUG=$v" | tee -a $O/r6_leanmulti.log
+    (cd tests/native && for c in qproj_sd15_n4096_b16 qproj_sd15_n4096_b16_f16 qproj_sd21_n9216_b8; do PWW_DEBUG="$v" timeout 200 ./attn_check --only $c 2>&1 | grep "^TIME\|^FAIL\|^PASS"; done) | cut -c1-330 | tee -a $O/r6_leanmulti.log
+    PWW_DEBUG="$v" timeout 300 python tools/diag_wg_order.py 2>&1 | grep "CASE cross" | tee -a $O/r6_leanmulti.log
+  done
+  PWW_DEBUG="" bash tools/pmc_traffic.sh qproj_sd15_n4096_b16 gpurun_out/pmc_leanmulti --product-only 2>&1 | grep -A12 "cross_lean\|cross_fused" | tee -a $O/r6_leanmulti.log
+  ;;
 linefill)
   # what one TCC_EA0_RDREQ moves (tools/ubench_linefill.cpp): time per touched line for full / half / sector / head-slice reads of a 2 GiB buffer,
   # and the request counters of the same kernels

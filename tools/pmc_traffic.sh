@@ -15,7 +15,7 @@ for f in glob.glob(out + '/*/**/*counter_collection.csv', recursive=True):
         agg[row['Kernel_Name']][row['Counter_Name']].append(float(row['Counter_Value']))
 res = {}
 for k, d in agg.items():
-    if 'attn_fwd' not in k and 'qk_reduce_kernel' not in k and 'cross_fused' not in k: continue
+    if 'attn_fwd' not in k and 'qk_reduce_kernel' not in k and 'cross_fused' not in k and 'cross_lean' not in k: continue
     res[k] = {c: sum(v) / len(v) for c, v in d.items()}
     print(k[:70]); [print('   %-26s %14.1f (n=%d)' % (c, sum(v) / len(v), len(v))) for c, v in sorted(d.items())]
 json.dump(res, open(out + '/traffic.json', 'w'), indent=1)
