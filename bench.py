@@ -862,11 +862,21 @@ def main():
                                            sum(rgb.numel() + (-(-rgb.shape[0] // r)) * (-(-rgb.shape[1] // r)) * len(cols) * 4 for r in ratios))
         ops.cfg_combine = timer.wrap_stream("cfg_combine", orig_cfg, lambda c, u, g: c.numel() * (2 * c.element_size() + 4))
         pw_api.DEFAULT_MODE = "folded"
+        # which path the folded-reference self-attention kernel's workgroups take ON THE WORKLOAD's own q / k (the kernel's debug counters,
+        # summed over every d = 40 launch of the pass): range-free / lazy reference / lazy reference on the exact scale / exact recomputation
+        import ctypes as _ct
+        from pww_hip import _lib as _pl
+        path_counts = torch.zeros(4, dtype=torch.int32, device=device)
+        _pl.load().pww_debug_path_counts(_ct.c_void_p(path_counts.data_ptr()))
         try:
             one_step(0)
+            torch.cuda.synchronize()
         finally:
+            _pl.load().pww_debug_path_counts(None)
             ops.attention, ops.qk_stats, ops.mask_build, ops.cfg_combine, ops.qproj_stat, ops.qk_parts = orig, orig_stats, orig_mask, orig_cfg, orig_qproj, orig_qkparts
             pw_api.DEFAULT_MODE = args.mode
+        pc = path_counts.tolist()
+        workload_paths = {"fast": pc[0], "lazy": pc[1], "lazy_exact_scale": pc[3], "exact": pc[2]}
         H, W = request["rgb"].shape[:2]
         n_dom = (H // 8) * (W // 8)
         us_situ, n_launch, b_rows = timer.mean_us(lambda k: k[0] == "self" and k[2] == n_dom)
@@ -910,7 +920,9 @@ def main():
                                   "avg_us": round(us, 2), "avg_us_method": "kernel-only HIP event timestamps (hipExtLaunchKernelGGL start/stop events) of every launch of this "
                                   "class in an eager pass of the same workload, on the launch stream",
                                   "avg_us_back_to_back_graph_replay": round(us_b2b, 2), "avg_us_event_bracket_eager": round(us_situ, 2),
-                                  "launches": n_launch, "flops_per_launch": flops}
+                                  "launches": n_launch, "flops_per_launch": flops,
+                                  "workload_paths": workload_paths, "workload_paths_note": "workgroups of the d = 40 folded-reference launches of the instrumented pass per path "
+                                  "(pww_debug_path_counts) on the workload's own q / k"}
         # counters measured NOW: a kernel change that doubles the traffic shows in the driver's own line
         if us and world == 1 and not args.no_live_counters and not args.live_traffic and not args.tiny:      # (N > 1: the labelled constant; the scaling runs need no second profiler process next to seven other ranks)
             t_pmc = time.perf_counter()

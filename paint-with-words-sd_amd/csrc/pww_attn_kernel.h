@@ -804,45 +804,60 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
     stage_load(kreg, vreg, plan, srd_k, srd_v, k_step, v_step);     // past the last key: zeros (out of range)
     __syncthreads();
 
+    // Full stages; ONE barrier per stage. Store / load are unconditional (stages past the end read zeros and land in a buffer nobody reads).
+    // Stage 0 is written out in front of the loop: it sets the reference and carries the guards, the loop behind it is the steady state and
+    // nothing else (hipcc peeled the first iteration of the one-loop form for bf16 and did not for f16, whose loop kept the first stage's
+    // branches, 10 - 13 waits and ~140 more instructions in its body: 458 against 407 us at 16 rows).
     int st = 0;
-    for (; st < nfull; ++st) {   // full stages; ONE barrier per stage. Store / load are unconditional (stages past the
-        char *cur = smem + (st & 1) * STAGE_BYTES;                  // end read zeros and land in a buffer nobody reads),
-        char *nxt = smem + ((st & 1) ^ 1) * STAGE_BYTES;            // so the whole body up to the reference check is one block
-        stage_store<DT, KPT, VPT>(kreg, vreg, plan, nxt);
-        stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
-        fold_stage2<T, KS, DT, SUB_BYTES, RangeFree<T>::value>(oacc, mref, first, qf, cur, st * STAGE_KEYS, l31, hi, p.D, ref_floor);
+    bool steady = false;
+    if (nfull > 0) {
+        stage_store<DT, KPT, VPT>(kreg, vreg, plan, smem + STAGE_BYTES);
+        stage_load(kreg, vreg, plan, srd_k, srd_v, 2u * k_step, 2u * v_step);
+        fold_stage2<T, KS, DT, SUB_BYTES, RangeFree<T>::value>(oacc, mref, first, qf, smem, 0, l31, hi, p.D, ref_floor);
         first = false;
-        if (st == 0) {       // magnitude guard, early form: the first stage's row maximum (m_ref minus the range-free headroom)
-            const float m0 = mref - (RangeFree<T>::value ? RfHeadroom<T>::value : 0.f);
-            if (__syncthreads_or(qvalid && !(fabsf(m0) <= p.fold_limit))) {
-                // a FIRST stage already past the limit: the 8-wave f16 form starts over on the exact scale (stage 0 is still in its buffer, stage 1
-                // parked, stage 2 in registers: one stage computed twice); everything else recomputes on exact_rows after the loop
-                if constexpr (CAN_RAW) { raw = true; redo0 = true; } else { early = true; }
-                break;
-            }
+        // magnitude guard, early form: the first stage's row maximum (m_ref minus the range-free headroom)
+        const float m0 = mref - (RangeFree<T>::value ? RfHeadroom<T>::value : 0.f);
+        if (__syncthreads_or(qvalid && !(fabsf(m0) <= p.fold_limit))) {
+            // a FIRST stage already past the limit: the 8-wave f16 form starts over on the exact scale (stage 0 is still in its buffer, stage 1
+            // parked, stage 2 in registers: one stage computed twice); everything else recomputes on exact_rows after the loop
+            if constexpr (CAN_RAW) { raw = true; redo0 = true; } else { early = true; }
+        } else {
+            st = 1;
+            steady = true;
             if constexpr (CAN_SWITCH) {
                 // HOT ROWS (round 6). The f16 range-free reference has 16 binary orders of room above the first stage's maximum: a row whose
                 // logits spread over more than that (scaled-logit std >= ~3: what trained SD layers produce) overflows P to inf at some later
                 // key, and the whole workgroup used to redo its rows on the exact path (733 us instead of 484 at 16 rows, scaled-logit std 4).
                 // The first stage says which rows those are: its row sum relative to its own maximum is the effective number of keys that
                 // carry the softmax -- ~128 e^(sigma^2 / 2 - 2.6 sigma) of the stage's 128 for logits of std sigma: 40 at 0.5, 16 at 1, 5 at 3 --
-                // and a workgroup with a row below p.hot_sum (8) follows the running maximum lazily from here on: the SECOND loop below (the
-                // FOLD_TAU reference of the non-range-free form: one max per score and stage, +8 % on that workgroup; P can no longer
+                // and a WAVE with a row below p.hot_sum (8) follows the running maximum lazily from here on: the SECOND loop below (the
+                // FOLD_TAU reference of the non-range-free form: one max per score and stage, +2 % on that wave; P can no longer
                 // overflow). Two loops, not one loop with two bodies: that form spilled 350 - 480 bytes per lane.
                 // (row D of O^T sits in the hi == 0 half; the bf16 reference sits 2^RfHeadroom above the stage's maximum: the sum is taken relative to the maximum)
                 const float l0 = __shfl(tl_sum(), l31) * __builtin_amdgcn_exp2f(RfHeadroom<T>::value);
-                lazy = __syncthreads_or((qvalid && l0 < p.hot_sum) || p.hot_sum < 0.f) != 0;
-                if (lazy) { ++st; break; }
+                // (8 waves: per WAVE, like the switch to the third loop below -- the guard's vote above was this stage's barrier; the 4-wave
+                // form keeps round 6's first version, a workgroup-wide vote: the per-wave form spilled 24 bytes there)
+                if constexpr (CAN_RAW) lazy = __any((qvalid && l0 < p.hot_sum) || p.hot_sum < 0.f) != 0;
+                else lazy = __syncthreads_or((qvalid && l0 < p.hot_sum) || p.hot_sum < 0.f) != 0;
+                steady = !lazy;
             }
-        } else {
+        }
+    }
+    if (steady) {
+        for (; st < nfull; ++st) {
+            char *cur = smem + (st & 1) * STAGE_BYTES;
+            char *nxt = smem + ((st & 1) ^ 1) * STAGE_BYTES;
+            stage_store<DT, KPT, VPT>(kreg, vreg, plan, nxt);
+            stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
+            fold_stage2<T, KS, DT, SUB_BYTES, RangeFree<T>::value>(oacc, mref, false, qf, cur, st * STAGE_KEYS, l31, hi, p.D, ref_floor);
             __syncthreads();
         }
     }
     if constexpr (CAN_SWITCH) {
         if (lazy && !early && !raw) {
-            // second loop: lazy reference, folded scale. The stage's barrier also carries a vote: a row whose reference comes within
-            // FOLD_TAU + 1 of the magnitude guard's limit (the folded scale's rounding error grows with the logits: FOLD_LIMIT_F16) takes
-            // the workgroup to the third loop -- BEFORE the error is made, not after the pass.
+            // second loop: lazy reference, folded scale. A row whose reference comes within FOLD_TAU + 1 of the magnitude guard's limit (the
+            // folded scale's rounding error grows with the logits: FOLD_LIMIT_F16) takes its WAVE to the third loop -- BEFORE the error is
+            // made, not after the pass.
             const float lim_sw = p.fold_limit - FOLD_TAU - 1.f;
             for (; st < nfull; ++st) {
                 char *cur = smem + (st & 1) * STAGE_BYTES;
@@ -851,7 +866,13 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
                 stage_load(kreg, vreg, plan, srd_k, srd_v, (unsigned)(st + 2) * k_step, (unsigned)(st + 2) * v_step);
                 fold_stage2<T, KS, DT, SUB_BYTES, false>(oacc, mref, false, qf, cur, st * STAGE_KEYS, l31, hi, p.D, ref_floor);
                 if constexpr (CAN_RAW) {
-                    if (__syncthreads_or(qvalid && !(fabsf(mref) <= lim_sw))) { raw = true; ++st; break; }
+                    // per WAVE: the modes differ in a wave's own arithmetic only (its Q fragments, its reference), every loop keeps the stage
+                    // protocol -- one barrier per stage -- so waves of one workgroup may sit in different loops. (A workgroup-wide vote here,
+                    // __syncthreads_or = a reduction through LDS behind two barriers, cost every lazy stage ~10 %: config 3's dominant launch
+                    // 484 -> 530 us when the third loop first shipped.)
+                    const bool hot = __any(qvalid && !(fabsf(mref) <= lim_sw));
+                    __syncthreads();
+                    if (hot) { raw = true; ++st; break; }
                 } else {
                     __syncthreads();
                 }
@@ -939,7 +960,10 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
         if (raw) est_max = 0.f;                                          // exact scale: no magnitude limit (mref is a raw-domain value there)
         const bool bad = qvalid && !(lsum > 0.f && lsum < 3.0e38f && asum < 3.0e38f && fabsf(est_max) <= p.fold_limit);
         const bool redo = early || __syncthreads_or(bad);
-        if (p.path_counts && threadIdx.x == 0) atomicAdd(p.path_counts + (redo ? 2 : raw ? 3 : lazy ? 1 : 0), 1u);     // debug: which path this workgroup took
+        if (p.path_counts) {      // debug: which path this workgroup took (exact-scale: any of its waves; the extra vote only runs when somebody counts)
+            const bool raw_any = __syncthreads_or(raw) != 0, lazy_any = __syncthreads_or(lazy) != 0;
+            if (threadIdx.x == 0) atomicAdd(p.path_counts + (redo ? 2 : raw_any ? 3 : lazy_any ? 1 : 0), 1u);
+        }
         if (redo) {
             float l_unused;
             // after a COMPLETE fast pass only the waves that hold a bad row recompute (the others keep their results and help staging);
