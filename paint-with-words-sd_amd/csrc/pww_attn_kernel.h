@@ -766,6 +766,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
         return lv;
     };
     tl_stamp(p, 0);
+    const unsigned long long tl_c0 = p.timeline ? clock64() : 0ull;
 
     StagePlan<KPT, VPT> plan;
     make_plan<T, KS, DT, NT, NSUB, KPT, VPT>(plan, tid, p.D, p.k_sm, p.v_sm);
@@ -983,6 +984,7 @@ __global__ void __launch_bounds__(NW * 64, (NW == 2 ? 1 : MinWaves<DT, NW, false
     const float inv = 1.f / lsum;
     store_o_block<T, DT>(Op + (long)(qvalid ? qrow : 0) * p.o_sn, oacc, inv, p.D, hi, qvalid, p.o_wide != 0);
     tl_stamp(p, 3);
+    tl_cycles(p, tl_c0);
 }
 
 // ---- host dispatch ---------------------------------------------------------------------------

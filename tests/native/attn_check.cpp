@@ -39,7 +39,7 @@ static bool g_timeline = false;      // --timeline: print the phase time stamps 
 template <typename F> static void timeline_report(const char *name, const char *what, F launch) {
     const size_t wgs = 1 << 16, bytes = wgs * 8 * sizeof(unsigned long long);
     unsigned long long *buf; HIPCHECK(hipMalloc(&buf, bytes));
-    for (int rep = 0; rep < 3; ++rep) launch();                       // warm
+    for (int rep = 0; rep < 24; ++rep) launch();                      // warm (long enough for the clock to settle under the launch's own load)
     HIPCHECK(hipDeviceSynchronize());
     HIPCHECK(hipMemset(buf, 0, bytes));
     pww_debug_timeline(buf, bytes);
