@@ -74,6 +74,15 @@ prof)
     python tools/rocpd_stats.py "$DB" --top 60 --grid --match pww --split-b2b attn_fwd_fold_kernel; echo; echo "## pww kernels of the TIMED steps (hipGraph replay: what the product pays per launch)"; python tools/rocpd_stats.py "$DB" --top 60 --grid --match pww --window $W; echo; echo "## every kernel of the TIMED steps"; python tools/rocpd_stats.py "$DB" --top 45 --grid --window $W; } > $O/r6_bench_c2_kernel_stats.md 2>&1
   tail -1 $O/r6_bench_c2_prof.json | cut -c1-200; grep -c "" $O/r6_bench_c2_kernel_stats.md
   ;;
+profc3)
+  # config 3 (fp16, 16 folded rows: the throughput mode) under the kernel trace: where the time of the batched workload goes
+  OUT=/tmp/pww_prof_r06_c3; rm -rf $OUT; R=$PWD
+  (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $OUT -o run -- python $R/bench.py --config 3 --steps 1 --warmup 1 --cpu-steps 0 --no-reference-ops --no-live-counters --no-roofline-pass > $R/$O/r6_bench_c3_prof.json 2> $R/$O/r6_bench_c3_prof.log) || true
+  DB=$(find $OUT -name "*.db" | head -1)
+  W=$(grep "timed region CLOCK_MONOTONIC" $O/r6_bench_c3_prof.log | sed 's/.*ns //')
+  { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --config 3 --steps 1 --warmup 1 --cpu-steps 0 --no-reference-ops --no-live-counters --no-roofline-pass (round 6)"; echo; echo "## pww kernels of the TIMED step (8 images, 16 folded rows)"; python tools/rocpd_stats.py "$DB" --top 60 --grid --match pww --window $W; echo; echo "## every kernel of the TIMED step"; python tools/rocpd_stats.py "$DB" --top 45 --grid --window $W; } > $O/r6_bench_c3_kernel_stats.md
+  tail -1 $O/r6_bench_c3_prof.json | cut -c1-200; grep -c "" $O/r6_bench_c3_kernel_stats.md
+  ;;
 igemm)
   # stock-op setting A/B: MIOpen's bf16 NHWC asm implicit-GEMM forward solver brings two tensor-op launches per convolution (fp32 workspace
   # zero + cast: 1736 + 1736 launches per 2 images in the trace); with the solver disabled find mode picks among the others
