@@ -76,7 +76,8 @@ def _build(lib, units, defines, objdir, verbose, jobs=None):
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out))
         if verbose and out.strip():
             print(out)
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + sorted(objs) + ["-o", lib], check=True)
+    # (-s: the host-side symbol table goes -- 100 KB; the exported entry points live in .dynsym, kernel names in the embedded code objects)
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-s"] + sorted(objs) + ["-o", lib], check=True)
     return lib
 
 

@@ -256,6 +256,10 @@ __global__ void __launch_bounds__(NT) gn_apply_nhwc(GN_KARGS) {
 
 // One launch, workgroup = (group, image), NHWC: thread t owns the 4-channel piece t % ppp of every PLs-th pixel (ppp = cg / 4 pieces per
 // pixel of the group, PLs = 256 / ppp pixels in flight): its parameters are loaded once, its <= 24 pieces stay in registers.
+// (Round 6 measured two variations and kept neither, profiles/r06_gn_single_launch_ab.txt: the groups that do not fit -- the 20 two-launch
+// norms of a forward -- as ONE launch of 1024 threads streaming the group twice: -3 % on the headline, 64 workgroups move 80 - 250 KB each
+// three times through one CU's path to L2 where the two launches spread the bytes over 512; and this kernel rewritten branch-free with
+// buffer offsets and the second phase re-converting the pieces, 2700 instructions instead of 3600: -0.6 %.)
 template <typename T, int ACT>
 __global__ void __launch_bounds__(GN_NT) gn_group_nhwc(GN_KARGS) {
     GN_UNPACK

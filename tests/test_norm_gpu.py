@@ -44,7 +44,10 @@ def _close(y, ref, dtype, steps=1):
 
 # the norms of the SD1.5 / SD2.1 UNets at 2 folded rows (and one 16-row case): (B, C, H, W)
 SHAPES = [(2, 320, 64, 64), (2, 640, 32, 32), (2, 1280, 16, 16), (2, 1280, 8, 8), (2, 2560, 8, 8), (2, 1920, 16, 16), (2, 960, 32, 32),
-          (16, 640, 32, 32), (2, 320, 96, 96), (3, 64, 8, 8), (1, 32, 4, 2)]
+          (16, 640, 32, 32), (2, 320, 96, 96), (3, 64, 8, 8), (1, 32, 4, 2),
+          # (round 6) more of the shapes that take the two-launch form at 2 rows (10- and 30-channel groups, the 64 x 64 level), one odd batch and one
+          # non-square level; [2, 320, 96, 96] above is SD2.1's
+          (2, 640, 64, 64), (2, 960, 64, 64), (2, 1280, 32, 32), (2, 1920, 32, 32), (2, 320, 32, 32), (1, 320, 64, 64), (3, 320, 40, 24)]
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
