@@ -771,6 +771,20 @@ def main():
     # instead of repeating the search N times side by side. One node: the ranks share a file system.
     staged = world > 1 and args.warmup > 0 and on_gpu and os.environ.get("PWW_MIOPEN_FIND", "1") != "0"
     db_files = 0
+    if on_gpu and os.environ.get("PWW_FIND_PREWARM", "1") == "1" and os.environ.get("PWW_MIOPEN_FIND", "1") != "0" and args.warmup > 0 and not args.tiny:
+        # One eager pass in MIOpen's immediate mode BEFORE the warm-up pass that carries the find search: clocks, allocator and code caches are
+        # warm when the solvers are timed. The search times every candidate once, and with a cold GPU its choices moved the batched configs from
+        # process to process on ONE box (config 4: 10.5 / 8.7 / 10.4 / 9.1 / 8.7 images/s; with the pre-pass 10.0 / 10.0 / 9.6 / 9.8; config 5:
+        # 2.88 / 2.31 / 2.99 against 2.79 / 3.08 / 2.88; configs 2 and 3: no difference -- profiles/r06_miopen_find_prepass.txt). Untimed, 0.3 - 1.4 s;
+        # PWW_FIND_PREWARM=0 skips it.
+        prev_bm, prev_mode = torch.backends.cudnn.benchmark, pw_api.DEFAULT_MODE
+        torch.backends.cudnn.benchmark, pw_api.DEFAULT_MODE = False, "eager"
+        try:
+            one_step(0)
+            torch.cuda.synchronize()
+        finally:
+            torch.backends.cudnn.benchmark, pw_api.DEFAULT_MODE = prev_bm, prev_mode
+        log("immediate-mode pre-pass done")
     for phase in ((0, 1) if staged else (None,)):
         mine = phase is None or (phase == 0) == (rank == 0)
         if mine:
